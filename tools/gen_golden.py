@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE itself (build container only).
+
+Runs /root/reference's CraftingWorldEnvRay (imported under tools/gym_stub) from injected
+numpy RandomState states and writes small .npz fixtures to tests/golden/.  A fixture is data
+only: config kwargs, the initial MT19937 state, the action sequence, and what the reference
+returned / held after every step and every reset.  tests/test_oracle_golden.py replays them
+through the C oracle; tests/test_hip_parity.py (gpu) replays them through the HIP engine.
+
+    python tools/gen_golden.py            # regenerate every fixture
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from refharness import (bits, codes_from_onehot, crc, import_reference, make_ref_env,  # noqa: E402
+                        scripted_action)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+TASK_LIST = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe',
+             'MoveHammer', 'MoveSticks']
+
+# name, env kwargs, rng seed, steps, policy ('random' | 'scripted'), full images kept for the first K resets
+SCENARIOS = [
+    ('ray21_random',      dict(size=(21, 21)),                                   12345, 1500, 'random',   2),
+    ('ray21_scripted',    dict(size=(21, 21)),                                   777,   2500, 'scripted', 2),
+    ('ray5_random',       dict(size=(5, 5), max_steps=50),                       4242,  6000, 'random',   3),
+    ('ray5_subset',       dict(size=(5, 5), max_steps=40, reward_style='subset'), 99,   5000, 'random',   1),
+    ('ray5_scripted',     dict(size=(5, 5), max_steps=60),                       31337, 4000, 'scripted', 1),
+    ('ray8_scripted',     dict(size=(8, 8), max_steps=100),                      2024,  5000, 'scripted', 2),
+    ('ray8_nostack',      dict(size=(8, 8), max_steps=100, stacking=False),      5,     3000, 'scripted', 1),
+    ('ray8_selected',     dict(size=(8, 8), max_steps=80, number_of_tasks=2,
+                               selected_tasks=['MoveAxe', 'EatBread', 'GoToHouse', 'ChopTree']), 6, 4000, 'scripted', 1),
+    ('ray8_subset_sel',   dict(size=(8, 8), max_steps=80, reward_style='subset',
+                               selected_tasks=['BuildHouse', 'MakeBread', 'MoveSticks']), 8, 4000, 'scripted', 1),
+    ('ray6_fixedinit',    dict(size=(6, 6), max_steps=40, fixed_init_state=3),   11,    3000, 'random',   2),
+    ('ray32_random',      dict(size=(32, 32)),                                   32,    700,  'random',   1),
+    ('ray32_scripted',    dict(size=(32, 32), max_steps=300),                    3232,  1500, 'scripted', 1),
+    ('ray4_tiny',         dict(size=(4, 4), max_steps=30),                       404,   3000, 'random',   1),
+]
+
+
+def capture(cls, kwargs, seed, steps, policy, keep_images):
+    rng = np.random.RandomState(seed)
+    st = rng.get_state()
+    key0, pos0 = st[1].copy(), int(st[2])
+    env = make_ref_env(cls, rng, **kwargs)
+    pol_rng = np.random.RandomState(seed ^ 0x5EED)
+    size = env.STATE_W
+
+    R = dict(desired=[], grid=[], agent=[], rng_pos=[], rng_crc=[], obs_crc=[], desired_img_crc=[],
+             init_img_crc=[], at_step=[], ep_no=[])
+    S = dict(action=[], reward=[], done=[], achieved=[], agent=[], hold=[], step_num=[], grid_crc=[],
+             obs_crc=[], grid=[])
+    imgs_desired, imgs_obs = [], []
+
+    def record_reset(t):
+        obs = env.reset()
+        codes, agent, hold = codes_from_onehot(env.obs_one_hot)
+        assert hold == 0
+        R['desired'].append(bits(env.desired_goal_vector))
+        R['grid'].append(codes)
+        R['agent'].append(agent)
+        s = env.np_random.get_state()
+        R['rng_pos'].append(int(s[2]))
+        R['rng_crc'].append(crc(s[1].astype(np.uint32)))
+        R['obs_crc'].append(crc(obs['observation'].astype(np.uint8)))
+        R['desired_img_crc'].append(crc(obs['desired_goal'].astype(np.uint8)))
+        R['init_img_crc'].append(crc(obs['init_observation'].astype(np.uint8)))
+        R['at_step'].append(t)
+        R['ep_no'].append(env.ep_no)
+        assert obs['achieved_goal'] is obs['observation']
+        if len(imgs_desired) < keep_images:
+            imgs_desired.append(obs['desired_goal'].astype(np.uint8))
+            imgs_obs.append(obs['observation'].astype(np.uint8))
+
+    record_reset(0)
+    n_success = 0
+    for t in range(steps):
+        if policy == 'random' or pol_rng.rand() < 0.15:
+            a = int(pol_rng.randint(6))
+        else:
+            a = scripted_action(env, pol_rng)
+        obs, reward, done, info = env.step(a)
+        codes, agent, hold = codes_from_onehot(env.obs_one_hot)
+        S['action'].append(a)
+        S['reward'].append(int(reward))
+        S['done'].append(bool(done))
+        S['achieved'].append(bits(info['achieved_goal']))
+        S['agent'].append(agent)
+        S['hold'].append(hold)
+        S['step_num'].append(env.step_num)
+        S['grid_crc'].append(crc(codes))
+        S['obs_crc'].append(crc(obs['observation'].astype(np.uint8)))
+        if size <= 8:
+            S['grid'].append(codes)
+        n_success += int(reward == env.MAX_STEPS)
+        if done:
+            record_reset(t + 1)
+
+    kw = dict(kwargs)
+    kw['size'] = list(kw['size'])
+    out = dict(
+        meta=np.frombuffer(json.dumps(dict(kwargs=kw, seed=seed, steps=steps, policy=policy,
+                                           n_success=n_success, n_resets=len(R['desired']),
+                                           env='CraftingWorldEnvRay')).encode(), dtype=np.uint8),
+        key0=key0.astype(np.uint32), pos0=np.int32(pos0),
+        action=np.array(S['action'], np.int8), reward=np.array(S['reward'], np.int32),
+        done=np.array(S['done'], np.uint8), achieved=np.array(S['achieved'], np.uint16),
+        agent=np.array(S['agent'], np.uint8), hold=np.array(S['hold'], np.uint8),
+        step_num=np.array(S['step_num'], np.int32), grid_crc=np.array(S['grid_crc'], np.uint32),
+        obs_crc=np.array(S['obs_crc'], np.uint32),
+        r_desired=np.array(R['desired'], np.uint16), r_grid=np.array(R['grid'], np.uint8),
+        r_agent=np.array(R['agent'], np.uint8), r_rng_pos=np.array(R['rng_pos'], np.int32),
+        r_rng_crc=np.array(R['rng_crc'], np.uint32), r_obs_crc=np.array(R['obs_crc'], np.uint32),
+        r_desired_img_crc=np.array(R['desired_img_crc'], np.uint32),
+        r_init_img_crc=np.array(R['init_img_crc'], np.uint32),
+        r_at_step=np.array(R['at_step'], np.int32), r_ep_no=np.array(R['ep_no'], np.int32),
+        img_desired=np.array(imgs_desired, np.uint8), img_obs=np.array(imgs_obs, np.uint8),
+        final_obs=env.obs_image.astype(np.uint8),
+    )
+    if size <= 8:
+        out['grid'] = np.array(S['grid'], np.uint8)
+    return out, n_success
+
+
+def main():
+    classes = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for name, kwargs, seed, steps, policy, keep in SCENARIOS:
+        out, n_success = capture(classes['ray'], kwargs, seed, steps, policy, keep)
+        path = os.path.join(OUT, name + '.npz')
+        np.savez_compressed(path, **out)
+        ach = np.bitwise_or.reduce(out['achieved']) if len(out['achieved']) else 0
+        print('%-18s steps=%5d resets=%4d successes=%3d achieved-bits-seen=%s  %6.1f KB' % (
+            name, steps, len(out['r_desired']), n_success, format(int(ach), '09b'), os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    main()
