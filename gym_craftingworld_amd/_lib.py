@@ -1,0 +1,115 @@
+"""ctypes binding of libcraftingworld.so (C ABI: include/craftingworld.h).
+
+The library is the product: there is no Python/CPU fallback.  If the shared object is missing
+this module raises at import of the engine (build it with `python -c "import __graft_entry__ as g;
+g.build()"` or `make -C gym_craftingworld_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcraftingworld.so')
+
+CW_ABI_VERSION = 1
+CW_MT_N = 624
+CW_MAX_TASKS = 16
+CW_MAX_MENUS = 256
+
+CW_OK, CW_ERR_INVALID, CW_ERR_HIP, CW_ERR_STATE = 0, -1, -2, -3
+CW_OBS_STATE, CW_OBS_PIXELS_FULL, CW_OBS_PIXELS_DIRTY = 0, 1, 2
+CW_ACT_I32, CW_ACT_I64, CW_ACT_U8 = 0, 1, 2
+
+
+class cw_task_menu(C.Structure):
+    _fields_ = [('n_selected', C.c_int32), ('number_of_tasks', C.c_int32), ('stacking', C.c_int32),
+                ('reward_subset', C.c_int32), ('selected_bits', C.c_int32 * CW_MAX_TASKS)]
+
+
+class cw_config(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('size', C.c_int32),
+                ('max_steps', C.c_int32), ('n_task_list', C.c_int32), ('fixed_init_state', C.c_int32),
+                ('obs_mode', C.c_int32), ('auto_reset', C.c_int32), ('n_menus', C.c_int32),
+                ('menus', C.POINTER(cw_task_menu)), ('env_menu', C.POINTER(C.c_uint8))]
+
+
+class cw_buffer_table(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('desired_goal', C.c_void_p), ('init_obs', C.c_void_p),
+                ('reward', C.c_void_p), ('done', C.c_void_p), ('achieved', C.c_void_p),
+                ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('hdr', C.c_void_p),
+                ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t)]
+
+
+class cw_state_view(C.Structure):
+    _fields_ = [('grid', C.c_void_p), ('init_grid', C.c_void_p), ('goal_grid', C.c_void_p),
+                ('agent_rc', C.c_void_p), ('init_agent_rc', C.c_void_p), ('goal_agent_rc', C.c_void_p),
+                ('hold', C.c_void_p), ('achieved', C.c_void_p), ('desired', C.c_void_p),
+                ('step_num', C.c_void_p), ('ep_no', C.c_void_p)]
+
+
+# every symbol include/craftingworld.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+ABI = {
+    'cw_create': (C.c_int, [C.POINTER(cw_config), C.c_int, C.POINTER(_VP)]),
+    'cw_destroy': (C.c_int, [_VP]),
+    'cw_seed_mt': (C.c_int, [_VP, _VP, _VP]),
+    'cw_seed_int': (C.c_int, [_VP, _VP]),
+    'cw_get_mt': (C.c_int, [_VP, _VP, _VP]),
+    'cw_generate_fixed_states': (C.c_int, [_VP, _VP]),
+    'cw_reset': (C.c_int, [_VP, _VP]),
+    'cw_step': (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    'cw_render': (C.c_int, [_VP, _VP, _VP]),
+    'cw_export_grid': (C.c_int, [_VP, _VP, _VP]),
+    'cw_export_onehot': (C.c_int, [_VP, _VP, _VP]),
+    'cw_get_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
+    'cw_set_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
+    'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
+    'cw_num_envs': (C.c_int, [_VP]),
+    'cw_abi_version': (C.c_int, []),
+    'cw_last_error': (C.c_char_p, []),
+}
+# host-only helpers (MT19937 state conversion), exported for tests of the host logic
+HOST_HELPERS = {
+    'cwh_mt_from_numpy': (C.c_int, [_VP, C.c_int]),
+    'cwh_mt_to_numpy': (None, [_VP, C.c_int, _VP]),
+    'cwh_mt_init_genrand': (None, [_VP, C.c_uint32]),
+}
+
+_lib = None
+
+
+class CraftingWorldError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcraftingworld.so (after torch, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CraftingWorldError(
+            'HIP extension %s is missing; build it (python -c "import __graft_entry__ as g; g.build()"). '
+            'There is no CPU fallback.' % LIB_PATH)
+    try:
+        import torch  # noqa: F401  -- loads torch's libamdhip64 first so the SONAME resolves to it
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for table in (ABI, HOST_HELPERS):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    if lib.cw_abi_version() != CW_ABI_VERSION:
+        raise CraftingWorldError('libcraftingworld.so ABI %d != binding %d' % (lib.cw_abi_version(), CW_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == CW_OK:
+        return
+    msg = (load().cw_last_error() or b'').decode(errors='replace')
+    if rc == CW_ERR_INVALID:
+        raise ValueError('%s: %s' % (what, msg))
+    raise CraftingWorldError('%s failed (%d): %s' % (what, rc, msg))

@@ -1,0 +1,517 @@
+// cw_engine.cpp -- host side of the C ABI in include/craftingworld.h: engine lifetime, device
+// buffers, MT19937 state conversion, dense<->slot state conversion, kernel launches.
+// No CPU fallback exists: every compute entry point enqueues HIP kernels (cw_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/craftingworld.h"
+#include "cw_layout.h"
+
+extern "C" {
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st);
+hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
+hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
+hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
+hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(CW_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+struct cw_engine {
+    int device = 0;
+    int obs_mode = 0;
+    int parity = 0;
+    int auto_reset = 1;
+    bool has_reset = false;
+    CwParams P{};
+    std::vector<void *> allocs;
+    std::vector<CwMenuDev> menus;
+    int n = 0, S = 0, ncell = 0, K = 0;
+};
+
+// ------------------------------------------------------------------------------ MT19937 (host)
+// numpy RandomState (key, pos)  <->  the engine's consume-and-replace form (cw_mt.h).
+static inline uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far)
+{
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+extern "C" {
+
+// in place: words < pos become next-generation (numpy's twist loop, first `pos` iterations);
+// returns the engine index (pos mod 624)
+int cwh_mt_from_numpy(uint32_t *s, int pos)
+{
+    if (pos < 0) pos = 0;
+    if (pos > CW_MT_N) pos = CW_MT_N;
+    for (int k = 0; k < pos; k++)
+        s[k] = mt_twist(s[k], s[(k + 1) % CW_MT_N], s[(k + 397) % CW_MT_N]);
+    return pos % CW_MT_N;
+}
+
+// inverse: from engine form (s, idx) recover a numpy key whose stream from position idx is
+// identical.  Words < idx are un-twisted; key[0]'s low 31 bits are unrecoverable and unused
+// by MT19937 (set to 0).
+void cwh_mt_to_numpy(const uint32_t *s, int idx, uint32_t *key)
+{
+    for (int j = idx; j < CW_MT_N; j++) key[j] = s[j];
+    for (int j = 0; j < idx; j++) key[j] = 0;
+    for (int j = idx - 1; j >= 0; j--) {
+        const uint32_t m = (j < CW_MT_N - 397) ? key[j + 397] : s[j - (CW_MT_N - 397)];
+        uint32_t t = s[j] ^ m;
+        const uint32_t odd = t >> 31;
+        if (odd) t ^= 0x9908b0dfu;
+        const uint32_t y = (t << 1) | odd;     // (G[j] & UPPER) | (G[j+1] & LOWER)
+        key[j] |= y & 0x80000000u;
+        if (j + 1 < idx) key[j + 1] |= y & 0x7fffffffu;
+    }
+}
+
+void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
+{
+    s[0] = seed;
+    for (int i = 1; i < CW_MT_N; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ helpers
+template <typename T>
+static int dev_alloc(cw_engine *e, T **out, size_t count)
+{
+    void *p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(&p, bytes));
+    HIP_TRY(hipMemset(p, 0, bytes));
+    e->allocs.push_back(p);
+    *out = (T *)p;
+    return CW_OK;
+}
+
+static int upload_mt(cw_engine *e, const std::vector<uint32_t> &words, const std::vector<int32_t> &idx)
+{
+    HIP_TRY(hipMemcpy(e->P.mt, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->P.mt_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CW_OK;
+}
+
+extern "C" {
+
+const char *cw_last_error(void) { return g_err; }
+int cw_abi_version(void) { return CW_ABI_VERSION; }
+int cw_num_envs(const cw_engine *e) { return e ? e->n : 0; }
+
+int cw_create(const cw_config *cfg, int device, cw_engine **out)
+{
+    if (!cfg || !out) return fail(CW_ERR_INVALID, "cw_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != CW_ABI_VERSION)
+        return fail(CW_ERR_INVALID, "cw_create: abi_version %d != %d", cfg->abi_version, CW_ABI_VERSION);
+    if (cfg->num_envs < 1) return fail(CW_ERR_INVALID, "cw_create: num_envs must be >= 1");
+    if (cfg->size < 4 || cfg->size > 255)
+        return fail(CW_ERR_INVALID, "cw_create: size must be in 4..255 (square grids only; non-square is a reference defect)");
+    if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(CW_ERR_INVALID, "cw_create: max_steps must be in 1..65535");
+    if (cfg->n_task_list < 9 || cfg->n_task_list > CW_MAX_TASKS)
+        return fail(CW_ERR_INVALID, "cw_create: len(task_list) must be in 9..%d", CW_MAX_TASKS);
+    if (cfg->fixed_init_state < 0 || cfg->fixed_init_state > 64)
+        return fail(CW_ERR_INVALID, "cw_create: fixed_init_state must be in 0..64");
+    if (cfg->obs_mode < CW_OBS_STATE || cfg->obs_mode > CW_OBS_PIXELS_DIRTY) return fail(CW_ERR_INVALID, "cw_create: bad obs_mode");
+    if (cfg->n_menus < 1 || cfg->n_menus > CW_MAX_MENUS || !cfg->menus) return fail(CW_ERR_INVALID, "cw_create: n_menus must be in 1..%d", CW_MAX_MENUS);
+
+    std::vector<CwMenuDev> menus(cfg->n_menus);
+    for (int m = 0; m < cfg->n_menus; m++) {
+        const cw_task_menu &src = cfg->menus[m];
+        if (src.n_selected < 1 || src.n_selected > CW_MAX_TASKS)
+            return fail(CW_ERR_INVALID, "cw_create: menu %d: len(selected_tasks) must be in 1..%d", m, CW_MAX_TASKS);
+        if (src.number_of_tasks < 1) return fail(CW_ERR_INVALID, "cw_create: menu %d: number_of_tasks must be >= 1", m);
+        CwMenuDev d{};
+        d.n_selected = src.n_selected;
+        d.number_of_tasks = src.number_of_tasks > src.n_selected ? src.n_selected : src.number_of_tasks;  // ray.py:80-81
+        d.stacking = src.stacking ? 1 : 0;
+        d.reward_subset = src.reward_subset ? 1 : 0;
+        for (int i = 0; i < src.n_selected; i++) {
+            if (src.selected_bits[i] < 0 || src.selected_bits[i] >= cfg->n_task_list)
+                return fail(CW_ERR_INVALID, "cw_create: menu %d: selected task %d is not in task_list", m, i);
+            d.sel_bits |= (uint64_t)src.selected_bits[i] << (4 * i);
+        }
+        menus[m] = d;
+    }
+    if (cfg->env_menu)
+        for (int i = 0; i < cfg->num_envs; i++)
+            if (cfg->env_menu[i] >= cfg->n_menus) return fail(CW_ERR_INVALID, "cw_create: env_menu[%d] out of range", i);
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CW_ERR_INVALID, "cw_create: device %d not present (%d devices)", device, ndev);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "cw_create: hipSetDevice(%d) failed", device);
+
+    cw_engine *e = new (std::nothrow) cw_engine();
+    if (!e) return fail(CW_ERR_INVALID, "cw_create: out of host memory");
+    e->device = device;
+    e->obs_mode = cfg->obs_mode;
+    e->auto_reset = cfg->auto_reset ? 1 : 0;
+    e->n = cfg->num_envs;
+    e->S = cfg->size;
+    e->ncell = cfg->size * cfg->size;
+    e->K = cfg->fixed_init_state;
+    e->menus = menus;
+    CwParams &P = e->P;
+    const size_t N = (size_t)e->n;
+    P.n_envs = e->n;
+    P.size = e->S;
+    P.ncell = e->ncell;
+    P.max_steps = cfg->max_steps;
+    P.task_mask = (1u << cfg->n_task_list) - 1u;
+    P.pool_k = e->K;
+    P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
+    P.frame_bytes = 48u * (uint32_t)e->ncell;
+
+    int rc = CW_OK;
+#define ALLOC(field, count)                                     \
+    if (rc == CW_OK) rc = dev_alloc(e, &P.field, (count))
+    ALLOC(hdr, N);
+    ALLOC(pos, N);
+    ALLOC(init_pos, N);
+    ALLOC(init_agent, N);
+    ALLOC(goal_pos, N);
+    ALLOC(goal_codes, N);
+    ALLOC(goal_agent, N);
+    ALLOC(ep_no, N);
+    ALLOC(mt, N * CW_MT_N);
+    ALLOC(mt_idx, N);
+    ALLOC(pool, N * (size_t)e->K * 9);
+    ALLOC(reward, N);
+    ALLOC(done, N);
+    ALLOC(achieved_out, N);
+    ALLOC(desired_out, N);
+    ALLOC(episode_length, N);
+    ALLOC(done_list, N);
+    ALLOC(done_count, 2);
+    ALLOC(counters, 4);
+    if (cfg->obs_mode != CW_OBS_STATE) {
+        ALLOC(obs, N * P.frame_bytes);
+        ALLOC(desired_img, N * P.frame_bytes);
+        ALLOC(init_img, N * P.frame_bytes);
+    }
+#undef ALLOC
+    CwMenuDev *dmenus = nullptr;
+    if (rc == CW_OK) rc = dev_alloc(e, &dmenus, menus.size());
+    if (rc == CW_OK && hipMemcpy(dmenus, menus.data(), menus.size() * sizeof(CwMenuDev), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(CW_ERR_HIP, "cw_create: menu upload failed");
+    P.menus = dmenus;
+    if (rc == CW_OK) {
+        // header: menu id per env; everything else zero until cw_reset
+        std::vector<uint32_t> h(N * 4, 0u);
+        for (size_t i = 0; i < N; i++) {
+            h[i * 4 + 0] = (uint32_t)(cfg->env_menu ? cfg->env_menu[i] : 0) << 24;
+            h[i * 4 + 3] = CW_CODES_INITIAL;
+        }
+        if (hipMemcpy(P.hdr, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(CW_ERR_HIP, "cw_create: header upload failed");
+    }
+    if (rc != CW_OK) {
+        for (void *p : e->allocs) (void)hipFree(p);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    // default stream: env i seeded like numpy RandomState(i); callers normally reseed
+    std::vector<uint32_t> seeds(N);
+    for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
+    rc = cw_seed_int(e, seeds.data());
+    if (rc != CW_OK) {
+        cw_destroy(e);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int cw_destroy(cw_engine *e)
+{
+    if (!e) return CW_OK;
+    DeviceGuard guard(e->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+    return CW_OK;
+}
+
+int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
+{
+    if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_seed_mt: null argument");
+    DeviceGuard guard(e->device);
+    const size_t N = (size_t)e->n;
+    std::vector<uint32_t> words(keys, keys + N * CW_MT_N);
+    std::vector<int32_t> idx(N);
+    for (size_t i = 0; i < N; i++) {
+        if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
+        idx[i] = cwh_mt_from_numpy(&words[i * CW_MT_N], pos[i]);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return upload_mt(e, words, idx);
+}
+
+int cw_seed_int(cw_engine *e, const uint32_t *seeds)
+{
+    if (!e || !seeds) return fail(CW_ERR_INVALID, "cw_seed_int: null argument");
+    DeviceGuard guard(e->device);
+    const size_t N = (size_t)e->n;
+    std::vector<uint32_t> words(N * CW_MT_N);
+    std::vector<int32_t> idx(N);
+    for (size_t i = 0; i < N; i++) {
+        cwh_mt_init_genrand(&words[i * CW_MT_N], seeds[i]);
+        idx[i] = cwh_mt_from_numpy(&words[i * CW_MT_N], CW_MT_N);   // init_genrand leaves pos = 624
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return upload_mt(e, words, idx);
+}
+
+int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
+{
+    if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_get_mt: null argument");
+    DeviceGuard guard(e->device);
+    const size_t N = (size_t)e->n;
+    std::vector<uint32_t> words(N * CW_MT_N);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) cwh_mt_to_numpy(&words[i * CW_MT_N], pos[i], keys + i * CW_MT_N);
+    return CW_OK;
+}
+
+int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
+{
+    if (!e) return fail(CW_ERR_INVALID, "cw_generate_fixed_states: null engine");
+    if (e->K == 0) return CW_OK;
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_pool(&e->P, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_reset(cw_engine *e, cw_stream_t stream)
+{
+    if (!e) return fail(CW_ERR_INVALID, "cw_reset: null engine");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_reset_all(&e->P, e->obs_mode, (hipStream_t)stream));
+    e->has_reset = true;
+    return CW_OK;
+}
+
+int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream)
+{
+    if (!e || !actions) return fail(CW_ERR_INVALID, "cw_step: null argument");
+    if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step: bad action dtype %d", action_dtype);
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream));
+    e->parity ^= 1;
+    return CW_OK;
+}
+
+int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
+{
+    if (!e || !out_frames) return fail(CW_ERR_INVALID, "cw_render: null argument");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_render called before cw_reset");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_render_ext(&e->P, out_frames, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_grid: null argument");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_export(&e->P, out, 0, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_export(&e->P, out, 1, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_buffers(cw_engine *e, cw_buffer_table *out)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_buffers: null argument");
+    const CwParams &P = e->P;
+    out->obs = P.obs;
+    out->desired_goal = P.desired_img;
+    out->init_obs = P.init_img;
+    out->reward = P.reward;
+    out->done = P.done;
+    out->achieved = P.achieved_out;
+    out->desired = P.desired_out;
+    out->episode_length = P.episode_length;
+    out->hdr = (uint8_t *)P.hdr;
+    out->slot_pos = (uint16_t *)P.pos;
+    out->counters = (uint64_t *)P.counters;
+    out->frame_bytes = P.frame_bytes;
+    return CW_OK;
+}
+
+// ------------------------------------------------------------------------------ state get/set
+static void slots_to_grid(const uint16_t *pos, uint32_t codes, int ncell, uint8_t *grid)
+{
+    memset(grid, 0, (size_t)ncell);
+    for (int k = 0; k < 8; k++)
+        if (pos[k] < (uint32_t)ncell) grid[pos[k]] = (uint8_t)((codes >> (4 * k)) & 15u);
+}
+
+int cw_get_state(cw_engine *e, cw_state_view *v)
+{
+    if (!e || !v) return fail(CW_ERR_INVALID, "cw_get_state: null argument");
+    DeviceGuard guard(e->device);
+    const size_t N = (size_t)e->n;
+    const int S = e->S, nc = e->ncell;
+    std::vector<uint32_t> hdr(N * 4), goal_codes(N);
+    std::vector<uint16_t> pos(N * 8), ipos(N * 8), gpos(N * 8), iagent(N), gagent(N);
+    std::vector<int32_t> epno(N);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(goal_codes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        const uint32_t *h = &hdr[i * 4];
+        if (v->grid) slots_to_grid(&pos[i * 8], h[3], nc, v->grid + i * nc);
+        if (v->init_grid) slots_to_grid(&ipos[i * 8], CW_CODES_INITIAL, nc, v->init_grid + i * nc);
+        if (v->goal_grid) slots_to_grid(&gpos[i * 8], goal_codes[i], nc, v->goal_grid + i * nc);
+        if (v->agent_rc) { v->agent_rc[i * 2] = h[0] & 0xFF; v->agent_rc[i * 2 + 1] = (h[0] >> 8) & 0xFF; }
+        if (v->init_agent_rc) { v->init_agent_rc[i * 2] = (uint8_t)(iagent[i] / S); v->init_agent_rc[i * 2 + 1] = (uint8_t)(iagent[i] % S); }
+        if (v->goal_agent_rc) { v->goal_agent_rc[i * 2] = (uint8_t)(gagent[i] / S); v->goal_agent_rc[i * 2 + 1] = (uint8_t)(gagent[i] % S); }
+        if (v->hold) v->hold[i] = (h[0] >> 16) & 0xFF;
+        if (v->achieved) v->achieved[i] = (uint16_t)(h[1] & 0xFFFF);
+        if (v->desired) v->desired[i] = (uint16_t)(h[1] >> 16);
+        if (v->step_num) v->step_num[i] = (int32_t)(h[2] & 0xFFFF);
+        if (v->ep_no) v->ep_no[i] = epno[i];
+    }
+    return CW_OK;
+}
+
+int cw_set_state(cw_engine *e, const cw_state_view *v)
+{
+    if (!e || !v) return fail(CW_ERR_INVALID, "cw_set_state: null argument");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_set_state called before cw_reset");
+    DeviceGuard guard(e->device);
+    const size_t N = (size_t)e->n;
+    const int S = e->S, nc = e->ncell;
+    std::vector<uint32_t> hdr(N * 4);
+    std::vector<uint16_t> pos(N * 8), ipos(N * 8);
+    std::vector<int32_t> epno(N);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        uint32_t *h = &hdr[i * 4];
+        uint32_t hold = (h[0] >> 16) & 0xFF;
+        if (v->hold) {
+            if (v->hold[i] > 3) return fail(CW_ERR_INVALID, "cw_set_state: hold[%zu]=%d outside 0..3", i, v->hold[i]);
+            hold = v->hold[i];
+        }
+        if (v->agent_rc) {
+            if (v->agent_rc[i * 2] >= S || v->agent_rc[i * 2 + 1] >= S) return fail(CW_ERR_INVALID, "cw_set_state: agent of env %zu off the grid", i);
+            h[0] = (h[0] & 0xFFFF0000u) | v->agent_rc[i * 2] | ((uint32_t)v->agent_rc[i * 2 + 1] << 8);
+        }
+        if (v->grid) {
+            // every object on the grid takes a slot; the held object (if any) takes one more
+            uint32_t codes = 0;
+            int k = 0;
+            const uint8_t *g = v->grid + i * nc;
+            for (int c = 0; c < nc; c++) {
+                if (g[c] == 0) continue;
+                if (g[c] > 8) return fail(CW_ERR_INVALID, "cw_set_state: env %zu cell %d has code %d > 8", i, c, g[c]);
+                if (k >= 8) return fail(CW_ERR_INVALID, "cw_set_state: env %zu has more than 8 objects (outside the reference's reachable states)", i);
+                pos[i * 8 + k] = (uint16_t)c;
+                codes |= (uint32_t)g[c] << (4 * k);
+                k++;
+            }
+            if (hold) {
+                if (k >= 8) return fail(CW_ERR_INVALID, "cw_set_state: env %zu: 8 objects on the grid plus a held one", i);
+                pos[i * 8 + k] = CW_POS_HELD;
+                codes |= hold << (4 * k);
+                k++;
+            }
+            for (; k < 8; k++) pos[i * 8 + k] = CW_POS_GONE;
+            h[3] = codes;
+        } else if (v->hold) {
+            return fail(CW_ERR_INVALID, "cw_set_state: hold given without grid");
+        }
+        h[0] = (h[0] & 0xFF00FFFFu) | (hold << 16);
+        if (v->init_grid) {
+            const uint8_t *g = v->init_grid + i * nc;
+            for (int k = 0; k < 8; k++) ipos[i * 8 + k] = CW_POS_GONE;
+            for (int c = 0; c < nc; c++) {
+                if (g[c] == 0) continue;
+                if (g[c] > 8) return fail(CW_ERR_INVALID, "cw_set_state: env %zu init cell %d has code %d > 8", i, c, g[c]);
+                if (ipos[i * 8 + g[c] - 1] != CW_POS_GONE)
+                    return fail(CW_ERR_INVALID, "cw_set_state: env %zu init grid holds object %d twice (sample_state places one of each, ray.py:605-608)", i, g[c]);
+                ipos[i * 8 + g[c] - 1] = (uint16_t)c;
+            }
+        }
+        if (v->achieved) h[1] = (h[1] & 0xFFFF0000u) | v->achieved[i];
+        if (v->desired) h[1] = (h[1] & 0x0000FFFFu) | ((uint32_t)v->desired[i] << 16);
+        if (v->step_num) {
+            if (v->step_num[i] < 0 || v->step_num[i] > 65535) return fail(CW_ERR_INVALID, "cw_set_state: step_num[%zu] outside 0..65535", i);
+            h[2] = (h[2] & 0xFFFF0000u) | (uint32_t)v->step_num[i];
+        }
+        if (v->ep_no) epno[i] = v->ep_no[i];
+    }
+    HIP_TRY(hipMemcpy(e->P.hdr, hdr.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->P.pos, pos.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->P.init_pos, ipos.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->P.ep_no, epno.data(), N * 4, hipMemcpyHostToDevice));
+    if (e->obs_mode != CW_OBS_STATE)   // the persistent frame must follow the injected state
+        HIP_TRY(cwk_launch_render_ext(&e->P, e->P.obs, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return CW_OK;
+}
+
+}  // extern "C"

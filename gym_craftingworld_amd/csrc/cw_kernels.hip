@@ -1,0 +1,680 @@
+// cw_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the CraftingWorld engine.
+//
+//   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward,
+//                     done, wave-ballot compaction of the done list; in DIRTY pixel mode also
+//                     render_edit() (ray.py:522-557) of the <=2 changed cells.
+//   cw_reset_kernel   one lane per finished env: reset() of ray.py:156-218 = task draw, legacy
+//                     Fisher-Yates placement on the env's MT19937 stream, imagine_obs().
+//   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520, 12 B per lane per
+//                     store so that each wave store instruction covers 768 contiguous bytes.
+//   cw_export_*       dense grid / one-hot views of the slot state.
+//
+// All integer; no MFMA (nothing here is a contraction: the reference's tensordot with a one-hot
+// operand is a table lookup).  Bounding resource: HBM write bandwidth for cw_render_kernel,
+// issue/latency for the others.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cw_layout.h"
+#include "cw_mt.h"
+
+#define CW_WAVE 64
+
+enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6, HOUSE = 7, WHEAT = 8 };
+// TASK_LIST bit order, ray.py:40-41
+enum { T_MAKEBREAD = 0, T_EATBREAD = 1, T_BUILDHOUSE = 2, T_CHOPTREE = 3, T_CHOPROCK = 4,
+       T_GOTOHOUSE = 5, T_MOVEAXE = 6, T_MOVEHAMMER = 7, T_MOVESTICKS = 8 };
+
+// COLORS_N (ray.py:28-30) as R | G<<8 | B<<16, index = cell code
+__constant__ uint32_t CW_RGB24[9] = {
+    0x000000u,
+    110u | (69u << 8) | (39u << 16),    // sticks
+    255u | (105u << 8) | (180u << 16),  // axe
+    100u | (100u << 8) | (200u << 16),  // hammer
+    100u | (100u << 8) | (100u << 16),  // rock
+    0u | (128u << 8) | (0u << 16),      // tree
+    205u | (133u << 8) | (63u << 16),   // bread
+    197u | (91u << 8) | (97u << 16),    // house
+    240u | (230u << 8) | (140u << 16),  // wheat
+};
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+
+__device__ __forceinline__ void unpack_pos(const uint4 &v, uint32_t sp[8])
+{
+    sp[0] = v.x & 0xFFFFu; sp[1] = v.x >> 16;
+    sp[2] = v.y & 0xFFFFu; sp[3] = v.y >> 16;
+    sp[4] = v.z & 0xFFFFu; sp[5] = v.z >> 16;
+    sp[6] = v.w & 0xFFFFu; sp[7] = v.w >> 16;
+}
+__device__ __forceinline__ uint4 pack_pos(const uint32_t sp[8])
+{
+    return make_uint4(sp[0] | (sp[1] << 16), sp[2] | (sp[3] << 16), sp[4] | (sp[5] << 16), sp[6] | (sp[7] << 16));
+}
+// slot index whose object sits in `cell`, or -1 (at most one object per cell, ray.py:334)
+__device__ __forceinline__ int slot_at(const uint32_t sp[8], uint32_t cell)
+{
+    int idx = -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) idx = (sp[k] == cell) ? k : idx;
+    return idx;
+}
+__device__ __forceinline__ uint32_t code_of(uint32_t codes, int idx)
+{
+    return idx < 0 ? 0u : ((codes >> (4 * idx)) & 15u);
+}
+__device__ __forceinline__ uint32_t rgb_of_code(uint32_t code)
+{
+    // 9-entry table as a select chain (per-lane index; avoids a divergent constant-memory load)
+    uint32_t c = 0;
+    c = code == 1 ? (110u | (69u << 8) | (39u << 16)) : c;
+    c = code == 2 ? (255u | (105u << 8) | (180u << 16)) : c;
+    c = code == 3 ? (100u | (100u << 8) | (200u << 16)) : c;
+    c = code == 4 ? (100u | (100u << 8) | (100u << 16)) : c;
+    c = code == 5 ? (0u | (128u << 8) | (0u << 16)) : c;
+    c = code == 6 ? (205u | (133u << 8) | (63u << 16)) : c;
+    c = code == 7 ? (197u | (91u << 8) | (97u << 16)) : c;
+    c = code == 8 ? (240u | (230u << 8) | (140u << 16)) : c;
+    return c;
+}
+
+// One cell's 4 pixels of one pixel row = 12 bytes R G B R | G B R G | B R G B.
+__device__ __forceinline__ u32x3 cell_row_dwords(uint32_t rgb)
+{
+    u32x3 d;
+    d.x = rgb | (rgb << 24);
+    d.y = (rgb >> 8) | (rgb << 16);
+    d.z = (rgb >> 16) | (rgb << 8);
+    return d;
+}
+// agent overlay on pixels 1,2 of the cell row (bytes 3..8): ray.py:483-486 / :555-557
+__device__ __forceinline__ u32x3 overlay_dwords(u32x3 d, uint32_t o)
+{
+    d.x = (d.x & 0x00FFFFFFu) | (o << 24);
+    d.y = (o >> 8) | (o << 16);
+    d.z = (d.z & 0xFFFFFF00u) | (o >> 16);
+    return d;
+}
+
+// render_edit (ray.py:522-557): repaint one cell of the persistent frame, one lane does 4 x 12 B
+__device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell, uint32_t code,
+                                           bool agent_here, uint32_t hold, uint32_t div_magic)
+{
+    const uint32_t r = __umulhi(cell, div_magic);
+    const uint32_t c = cell - r * S;
+    const uint32_t rgb = rgb_of_code(code);
+    const u32x3 base = cell_row_dwords(rgb);
+    const uint32_t row_bytes = 12u * S;
+    uint8_t *p = frame + (size_t)(4u * r) * row_bytes + 12u * c;
+#pragma unroll
+    for (int dy = 0; dy < 4; dy++) {
+        u32x3 d = base;
+        if (agent_here && (dy == 1 || dy == 2)) {
+            uint32_t o = (dy == 2 && hold != 0) ? rgb_of_code(hold) : 0x00FFFFFFu;
+            d = overlay_dwords(d, o);
+        }
+        *(u32x3_a4 *)(p + dy * row_bytes) = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------ step
+__global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype,
+                                                      int parity, int paint_dirty)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        P.done_count[parity ^ 1] = 0;   // the other parity's counter is idle during this step
+        atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
+    }
+    const bool live = i < P.n_envs;
+    bool done = false, success = false, invalid = false;
+    if (live) {
+        int a;
+        if (act_dtype == 0) a = ((const int32_t *)actions)[i];
+        else if (act_dtype == 1) a = (int)((const long long *)actions)[i];
+        else a = ((const uint8_t *)actions)[i];
+
+        uint4 h = P.hdr[i];
+        uint32_t sp[8];
+        unpack_pos(P.pos[i], sp);
+        const int S = P.size;
+        int ar = h.x & 0xFF, ac = (h.x >> 8) & 0xFF;
+        uint32_t hold = (h.x >> 16) & 0xFF;
+        uint32_t achieved = h.y & 0xFFFFu;
+        const uint32_t desired = h.y >> 16;
+        uint32_t step_num = (h.z & 0xFFFFu) + 1u;                 // ray.py:309
+        const uint32_t flags = (h.z >> 16) & ~CW_FLAG_RESET;
+        uint32_t codes = h.w;
+
+        invalid = (unsigned)a > 5u;
+        bool changed = false;
+        const uint32_t cell = ar * S + ac;
+        const int idx_here = slot_at(sp, cell);
+        const uint32_t code_here = code_of(codes, idx_here);
+        uint32_t dirty0 = cell, dirty1 = 0xFFFFFFFFu;
+
+        if (a == 4) {                                             // pickup, ray.py:314-327
+            if (code_here >= STICKS && code_here <= HAMMER && hold == 0) {
+                hold = code_here;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sp[k] = (k == idx_here) ? CW_POS_HELD : sp[k];
+                changed = true;
+            }
+        } else if (a == 5) {                                      // drop, ray.py:329-341
+            if (hold != 0 && idx_here < 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) sp[k] = (sp[k] == CW_POS_HELD) ? cell : sp[k];
+                hold = 0;
+                changed = true;
+            }
+        } else if (!invalid) {                                    // __move_agent, ray.py:380-440
+            const int dr = (a == 0) ? -1 : (a == 2) ? 1 : 0;      // ACTIONS = up,right,down,left, :130-131
+            const int dc = (a == 1) ? 1 : (a == 3) ? -1 : 0;
+            const int nr = min(max(ar + dr, 0), S - 1);           // Coord.__add__, coord.py:22-25
+            const int nc = min(max(ac + dc, 0), S - 1);
+            uint32_t old_obj = 0;                                 // None
+            uint32_t cur_code = code_here;
+            if (nr != ar || nc != ac) {                           // :395-396
+                const uint32_t ncell = nr * S + nc;
+                const int idx_t = slot_at(sp, ncell);
+                const uint32_t t = code_of(codes, idx_t);
+                const bool cant = (t == ROCK && hold != 3) || (t == TREE && hold != 2);  // :401-405
+                if (!cant) {
+                    changed = true;
+                    dirty1 = ncell;
+                    ar = nr; ac = nc;
+                    old_obj = t;                                  // :411 (None when empty, :417-419)
+                    uint32_t nw = t;
+                    if (t == ROCK || t == BREAD) nw = EMPTY;      // :423-425
+                    else if (t == TREE) nw = STICKS;              // :426-428
+                    else if (t == STICKS && hold == 3) nw = HOUSE; // :429-432
+                    else if (t == WHEAT && hold == 2) nw = BREAD;  // :433-438
+                    if (nw != t) {
+                        codes = (codes & ~(15u << (4 * idx_t))) | (nw << (4 * idx_t));
+                        if (nw == EMPTY) {
+#pragma unroll
+                            for (int k = 0; k < 8; k++) sp[k] = (k == idx_t) ? CW_POS_GONE : sp[k];
+                        }
+                    }
+                    cur_code = nw;
+                }
+            }
+            // eval_task_edit, ray.py:646-703 -- runs after every move action, failed ones included
+            const uint32_t pcell = ar * S + ac;
+            if (old_obj == BREAD) achieved |= 1u << T_EATBREAD;            // :657-659
+            else if (old_obj == ROCK) achieved |= 1u << T_CHOPROCK;        // :660-662
+            else if (old_obj == TREE) achieved |= 1u << T_CHOPTREE;        // :663-665
+            achieved = (cur_code == HOUSE) ? (achieved | (1u << T_GOTOHOUSE))
+                                           : (achieved & ~(1u << T_GOTOHOUSE));  // :668
+            if (hold != 0) {
+                const uint4 ip = P.init_pos[i];
+                const uint32_t ip_sticks = ip.x & 0xFFFFu, ip_axe = ip.x >> 16;
+                const uint32_t ip_hammer = ip.y & 0xFFFFu, ip_tree = ip.z & 0xFFFFu;
+                if (hold == 1) {                                           // :672-684
+                    const bool home = (pcell == ip_sticks) ||
+                                      (pcell == ip_tree && (achieved & (1u << T_CHOPTREE)));
+                    achieved = home ? (achieved & ~(1u << T_MOVESTICKS)) : (achieved | (1u << T_MOVESTICKS));
+                } else if (hold == 2) {                                    // :685-693
+                    if (old_obj == WHEAT) achieved |= 1u << T_MAKEBREAD;
+                    achieved = (pcell == ip_axe) ? (achieved & ~(1u << T_MOVEAXE)) : (achieved | (1u << T_MOVEAXE));
+                } else {                                                   // :694-702
+                    if (old_obj == STICKS) achieved |= 1u << T_BUILDHOUSE;
+                    achieved = (pcell == ip_hammer) ? (achieved & ~(1u << T_MOVEHAMMER)) : (achieved | (1u << T_MOVEHAMMER));
+                }
+            }
+        }
+
+        // reward, ray.py:348-363 + 747-767
+        int reward = -1;
+        if (changed) {
+            const uint32_t am = achieved & P.task_mask, dm = desired & P.task_mask;
+            bool hit;
+            if (flags & CW_FLAG_SUBSET)  // np.max(desired - achieved) == 0
+                hit = ((dm & ~am) == 0) && (((~(dm ^ am)) & P.task_mask) != 0);
+            else                         // short_circuit_check == array_equal
+                hit = (am == dm);
+            reward = hit ? P.max_steps : -1;
+        }
+        success = (reward == P.max_steps);
+        done = (step_num >= (uint32_t)P.max_steps) || success;             // :367
+
+        // write back
+        h.x = (uint32_t)ar | ((uint32_t)ac << 8) | (hold << 16) | (h.x & 0xFF000000u);
+        h.y = achieved | (desired << 16);
+        h.z = step_num | (flags << 16);
+        h.w = codes;
+        P.hdr[i] = h;
+        P.pos[i] = pack_pos(sp);
+        P.reward[i] = reward;
+        P.done[i] = done ? 1 : 0;
+        P.achieved_out[i] = (uint16_t)achieved;
+        P.desired_out[i] = (uint16_t)desired;
+        if (done) P.episode_length[i] = (int32_t)step_num;
+
+        if (paint_dirty && changed) {                                      // render_edit, :358
+            uint8_t *frame = P.obs + (size_t)i * P.frame_bytes;
+            const uint32_t acell = ar * S + ac;
+            paint_cell(frame, S, dirty0, code_of(codes, slot_at(sp, dirty0)), dirty0 == acell, hold, P.div_magic);
+            if (dirty1 != 0xFFFFFFFFu)
+                paint_cell(frame, S, dirty1, code_of(codes, slot_at(sp, dirty1)), dirty1 == acell, hold, P.div_magic);
+        }
+    }
+
+    // done-mask compaction with wavefront ballots (64-bit on CDNA)
+    const unsigned long long m_done = __ballot(done);
+    const unsigned long long m_succ = __ballot(success);
+    const unsigned long long m_inv = __ballot(invalid);
+    if (m_done | m_inv) {
+        const int lane = threadIdx.x & (CW_WAVE - 1);
+        int base = 0;
+        if (lane == 0) {
+            if (m_done) {
+                base = atomicAdd(&P.done_count[parity], __popcll(m_done));
+                atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
+            }
+            if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
+            if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
+        }
+        base = __shfl(base, 0);
+        if (done) {
+            const unsigned long long below = m_done & ((1ull << lane) - 1ull);
+            P.done_list[base + __popcll(below)] = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ reset
+// Fisher-Yates of arange(ncell) (RandomState.shuffle, ray.py:610-612) tracking only the 9 tokens
+// that matter: values 0..7 = objects, 8 = agent (diag rows, ray.py:605-608).  All tokens start
+// at positions 0..8; position i > 8 holds a non-token until its own swap and is final after
+// it, so the loop keeps a 9-nibble map "which token sits at low position q" in registers and
+// writes a token's final cell once, to this lane's LDS column.  Every lane consumes exactly one
+// raw MT word per round (rejected draws just do not advance i), so the wavefront stays in
+// lockstep -- no per-lane inner rejection loops.  new_cell[k] = old_row[perm[k]] means token v
+// ends in the cell whose perm entry is v.
+__device__ __forceinline__ void shuffle_tokens(CwMt &mt, int n, uint16_t *tok_col /* [9] stride CW_WAVE */)
+{
+    unsigned long long low = 0x876543210ull;        // nibble q = token at low position q (15 = none)
+    int i = n - 1;
+    while (i >= 1) {
+        const uint32_t mask = 0xFFFFFFFFu >> __clz(i);
+        const uint32_t v = mt.next() & mask;
+        if (v <= (uint32_t)i) {                      // accepted: swap(perm[i], perm[v])
+            const uint32_t b = (v <= 8u) ? (uint32_t)((low >> (4u * v)) & 15ull) : 15u;
+            const uint32_t a = (i <= 8) ? (uint32_t)((low >> (4u * i)) & 15ull) : 15u;
+            if (b != 15u) tok_col[b * CW_WAVE] = (uint16_t)i;   // position i is final from now on
+            if (v <= 8u) low = (low & ~(15ull << (4u * v))) | ((unsigned long long)a << (4u * v));
+            i--;
+        }
+    }
+    const uint32_t t0 = (uint32_t)(low & 15ull);
+    if (t0 != 15u) tok_col[t0 * CW_WAVE] = 0;
+}
+
+// k-th (row-major) cell not in the occupied set {present slots} (+ extra cell if extra >= 0)
+__device__ __forceinline__ uint32_t kth_unoccupied(const uint32_t fp[8], int extra, uint32_t k)
+{
+    uint32_t cand = k;
+#pragma unroll 1
+    for (int it = 0; it < 10; it++) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) cnt += (fp[s] <= cand) ? 1u : 0u;   // GONE = 0xFFFF never counts
+        cnt += (extra >= 0 && (uint32_t)extra <= cand) ? 1u : 0u;
+        const uint32_t nc = k + cnt;
+        if (nc == cand) break;
+        cand = nc;
+    }
+    return cand;
+}
+// among slots whose code == want (and present), the one with rank `which` in cell order
+__device__ __forceinline__ int nth_with_code(const uint32_t fp[8], const uint32_t fc[8], uint32_t want, uint32_t which)
+{
+    int sel = -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const bool cand = (fc[k] == want) && (fp[k] < CW_POS_HELD);
+        uint32_t rank = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+            rank += ((fc[m] == want) && (fp[m] < fp[k])) ? 1u : 0u;
+        sel = (cand && rank == which) ? k : sel;
+    }
+    return sel;
+}
+__device__ __forceinline__ uint32_t count_code(const uint32_t fp[8], const uint32_t fc[8], uint32_t want)
+{
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) n += ((fc[k] == want) && (fp[k] < CW_POS_HELD)) ? 1u : 0u;
+    return n;
+}
+#define CW_SET_SLOT(arr, idx, val)                                         \
+    _Pragma("unroll") for (int _k = 0; _k < 8; _k++) arr[_k] = (_k == (idx)) ? (val) : arr[_k];
+
+__global__ __launch_bounds__(CW_WAVE) void cw_reset_kernel(CwParams P, int parity, int all_envs)
+{
+    __shared__ uint16_t s_tok[9 * CW_WAVE];
+    const int t = blockIdx.x * CW_WAVE + threadIdx.x;
+    const int count = all_envs ? P.n_envs : P.done_count[parity];
+    if (t >= count) return;
+    const int env = all_envs ? t : P.done_list[t];
+    const int lane = threadIdx.x;
+    uint16_t *tok_col = s_tok + lane;
+
+    const uint4 h_old = P.hdr[env];
+    const uint32_t menu_id = h_old.x >> 24;
+    const CwMenuDev M = P.menus[menu_id];
+
+    CwMt mt;
+    mt.open(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env]);
+
+    // task draw, ray.py:169-174
+    const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
+    unsigned long long perm = 0xFEDCBA9876543210ull;             // task_idx = arange(n_selected)
+    for (int i = M.n_selected - 1; i >= 1; i--) {                 // RandomState.shuffle
+        const uint32_t j = mt.interval((uint32_t)i);
+        const unsigned long long ni = (perm >> (4 * i)) & 15ull, nj = (perm >> (4 * j)) & 15ull;
+        perm = (perm & ~(15ull << (4 * i))) | (nj << (4 * i));
+        perm = (perm & ~(15ull << (4 * j))) | (ni << (4 * j));
+    }
+    uint32_t desired = 0;
+    for (uint32_t q = 0; q < ntasks; q++) {
+        const uint32_t idx = (uint32_t)((perm >> (4 * q)) & 15ull);
+        desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
+    }
+
+    // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
+    uint32_t fp[8], fc[8];
+    uint32_t agent;
+    if (P.pool_k == 0) {
+        shuffle_tokens(mt, P.ncell, tok_col);
+#pragma unroll
+        for (int k = 0; k < 8; k++) fp[k] = tok_col[k * CW_WAVE];
+        agent = tok_col[8 * CW_WAVE];
+    } else {
+        const uint32_t pk = mt.randint((uint32_t)P.pool_k);
+        const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
+#pragma unroll
+        for (int k = 0; k < 8; k++) fp[k] = pp[k];
+        agent = pp[8];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) fc[k] = k + 1;
+    const uint4 init_packed = pack_pos(fp);
+    const uint32_t init_agent = agent;
+
+    // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
+    if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
+        CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
+    }
+    if (desired & (1u << T_EATBREAD)) {                           // :232-237
+        const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
+        const int s = nth_with_code(fp, fc, BREAD, which);
+        CW_SET_SLOT(fc, s, (uint32_t)EMPTY);
+        CW_SET_SLOT(fp, s, CW_POS_GONE);
+    }
+    if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
+        CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
+    }
+    if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
+        const int s = nth_with_code(fp, fc, STICKS, which_stick);
+        const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
+        CW_SET_SLOT(fp, s, to);
+    }
+    if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
+        const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
+        const int s = nth_with_code(fp, fc, STICKS, which);
+        CW_SET_SLOT(fc, s, (uint32_t)HOUSE);
+    }
+    if (desired & (1u << T_CHOPROCK)) {                           // :265-268
+        CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
+        CW_SET_SLOT(fp, 3, CW_POS_GONE);
+    }
+    if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
+        const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
+        const int s = nth_with_code(fp, fc, HOUSE, which);
+#pragma unroll
+        for (int k = 0; k < 8; k++) agent = (k == s) ? fp[k] : agent;
+    }
+    if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+        CW_SET_SLOT(fp, 1, to);
+    }
+    if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+        CW_SET_SLOT(fp, 2, to);
+    }
+
+    // commit
+    P.mt_idx[env] = mt.k;
+    uint32_t goal_codes = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) goal_codes |= fc[k] << (4 * k);
+    P.goal_pos[env] = pack_pos(fp);
+    P.goal_codes[env] = goal_codes;
+    P.goal_agent[env] = (uint16_t)agent;
+    P.init_pos[env] = init_packed;
+    P.init_agent[env] = (uint16_t)init_agent;
+    P.pos[env] = init_packed;
+    const uint32_t ar = __umulhi(init_agent, P.div_magic);
+    const uint32_t ac = init_agent - ar * P.size;
+    uint4 h;
+    h.x = ar | (ac << 8) | (menu_id << 24);                       // hold = 0
+    h.y = desired << 16;                                          // achieved = 0, ray.py:176
+    h.z = (CW_FLAG_RESET | (M.reward_subset ? CW_FLAG_SUBSET : 0u)) << 16;   // step_num = 0, :203
+    h.w = CW_CODES_INITIAL;
+    P.hdr[env] = h;
+    if ((h_old.z & 0xFFFFu) != 0) P.ep_no[env] += 1;             // :200-201
+}
+
+// generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
+__global__ __launch_bounds__(CW_WAVE) void cw_pool_kernel(CwParams P)
+{
+    __shared__ uint16_t s_tok[9 * CW_WAVE];
+    const int env = blockIdx.x * CW_WAVE + threadIdx.x;
+    if (env >= P.n_envs) return;
+    uint16_t *tok_col = s_tok + threadIdx.x;
+    CwMt mt;
+    mt.open(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env]);
+    for (int k = 0; k < P.pool_k; k++) {
+        shuffle_tokens(mt, P.ncell, tok_col);
+        uint16_t *pp = P.pool + ((size_t)env * P.pool_k + k) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; q++) pp[q] = tok_col[q * CW_WAVE];
+    }
+    P.mt_idx[env] = mt.k;
+}
+
+// ------------------------------------------------------------------------------------ render
+// One wavefront paints one frame.  The frame is an array of 4S*S "items" of 12 bytes (one cell's
+// 4 pixels on one pixel row); item `it` sits at byte 12*it, so lane l of a wave storing item
+// base+l writes 12 B and the 64 lanes together 768 contiguous bytes per store instruction.
+// The slot positions/colours are wave-uniform (SGPRs); a cell's colour is an 8-compare chain.
+__device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
+                                             int S, uint32_t div_magic, const uint32_t sp[8],
+                                             const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
+                                             int lane)
+{
+    const uint32_t n_items = 4u * S * S;
+    for (uint32_t it = lane; it < n_items; it += CW_WAVE) {
+        const uint32_t y = __umulhi(it, div_magic);      // pixel row
+        const uint32_t c = it - y * S;                   // cell column
+        const uint32_t cell = (y >> 2) * S + c;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? rgb[k] : col;
+        u32x3 d = cell_row_dwords(col);
+        const uint32_t sub = y & 3u;
+        if (cell == agent_cell && (sub == 1u || sub == 2u))
+            d = overlay_dwords(d, (sub == 2u) ? hold_rgb : 0x00FFFFFFu);
+        __builtin_nontemporal_store(d, (u32x3_a4 *)(dst0 + (size_t)it * 12u));
+        if (dst1) __builtin_nontemporal_store(d, (u32x3_a4 *)(dst1 + (size_t)it * 12u));
+    }
+}
+
+// mode 0: every env -> P.obs; envs flagged RESET additionally -> init_img (same pixels) and
+//         desired_img (goal state).                     (FULL pixel mode, after step+reset)
+// mode 1: envs in the done list only -> obs, init_img, desired_img   (DIRTY pixel mode)
+// mode 2: every env -> ext_out only                      (cw_render into a caller buffer)
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int parity, uint8_t *ext_out)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
+    const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
+    const int n_jobs = (mode == 1) ? P.done_count[parity] : P.n_envs;
+    for (int job = wave; job < n_jobs; job += n_waves) {
+        const int env = __builtin_amdgcn_readfirstlane((mode == 1) ? P.done_list[job] : job);
+        const uint4 h = P.hdr[env];
+        const uint4 pp = P.pos[env];
+        uint32_t sp[8], rgb[8];
+        unpack_pos(pp, sp);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sp[k] = __builtin_amdgcn_readfirstlane(sp[k]);
+            rgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((h.w >> (4 * k)) & 15u)];
+        }
+        const uint32_t hx = __builtin_amdgcn_readfirstlane(h.x);
+        const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
+        const uint32_t hold = (hx >> 16) & 0xFFu;
+        const uint32_t hold_rgb = hold ? CW_RGB24[hold] : 0x00FFFFFFu;
+        const bool was_reset = (mode == 1) || ((__builtin_amdgcn_readfirstlane(h.z) >> 16) & CW_FLAG_RESET);
+        const size_t off = (size_t)env * P.frame_bytes;
+        uint8_t *d0 = (mode == 2) ? ext_out + off : P.obs + off;
+        uint8_t *d1 = (mode != 2 && was_reset) ? P.init_img + off : nullptr;
+        render_frame(d0, d1, P.size, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
+        if (mode != 2 && was_reset) {                            // desired_goal = render(final_state), ray.py:299
+            uint32_t gp[8], grgb[8];
+            unpack_pos(P.goal_pos[env], gp);
+            const uint32_t gc = P.goal_codes[env];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                gp[k] = __builtin_amdgcn_readfirstlane(gp[k]);
+                grgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((gc >> (4 * k)) & 15u)];
+            }
+            const uint32_t ga = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[env]);
+            render_frame(P.desired_img + off, nullptr, P.size, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ exports
+// dense grid codes [N][S][S]; one thread per 4 cells
+__global__ __launch_bounds__(256) void cw_export_grid_kernel(CwParams P, uint8_t *out)
+{
+    const size_t total = (size_t)P.n_envs * P.ncell;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t env = (uint32_t)(g / P.ncell);
+        const uint32_t cell = (uint32_t)(g - (size_t)env * P.ncell);
+        uint32_t sp[8];
+        unpack_pos(P.pos[env], sp);
+        out[g] = (uint8_t)code_of(P.hdr[env].w, slot_at(sp, cell));
+    }
+}
+// one-hot [N][S][S][12] (observation_vector_space, ray.py:94-98): 0-7 objects, 8 agent, 9-11 hold
+__global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8_t *out)
+{
+    const size_t total = (size_t)P.n_envs * P.ncell;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t env = (uint32_t)(g / P.ncell);
+        const uint32_t cell = (uint32_t)(g - (size_t)env * P.ncell);
+        const uint4 h = P.hdr[env];
+        uint32_t sp[8];
+        unpack_pos(P.pos[env], sp);
+        const uint32_t code = code_of(h.w, slot_at(sp, cell));
+        const uint32_t agent_cell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+        const uint32_t hold = (h.x >> 16) & 0xFFu;
+        uint32_t bits = code ? (1u << (code - 1)) : 0u;
+        if (cell == agent_cell) bits |= (1u << 8) | (hold ? (1u << (8 + hold)) : 0u);
+        // 12 bytes of 0/1
+        u32x3 d;
+        d.x = (bits & 1u) | ((bits >> 1 & 1u) << 8) | ((bits >> 2 & 1u) << 16) | ((bits >> 3 & 1u) << 24);
+        d.y = (bits >> 4 & 1u) | ((bits >> 5 & 1u) << 8) | ((bits >> 6 & 1u) << 16) | ((bits >> 7 & 1u) << 24);
+        d.z = (bits >> 8 & 1u) | ((bits >> 9 & 1u) << 8) | ((bits >> 10 & 1u) << 16) | ((bits >> 11 & 1u) << 24);
+        *(u32x3_a4 *)(out + g * 12) = d;
+    }
+}
+
+__global__ void cw_iota_kernel(int32_t *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+static inline int cw_render_grid(int jobs)
+{
+    // 4 waves per block; enough blocks to fill 256 CUs several times over, grid-stride beyond
+    int blocks = (jobs + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+extern "C" {
+
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity,
+                           int obs_mode, int auto_reset, hipStream_t st)
+{
+    const int n = P->n_envs;
+    hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
+                       parity, obs_mode == 2 ? 1 : 0);
+    if (auto_reset)
+        hipLaunchKernelGGL(cw_reset_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P, parity, 0);
+    if (obs_mode == 1)
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, parity, (uint8_t *)nullptr);
+    else if (obs_mode == 2 && auto_reset)
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n) < 1024 ? cw_render_grid(n) : 1024), dim3(256), 0, st, *P, 1,
+                           parity, (uint8_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st)
+{
+    const int n = P->n_envs;
+    hipLaunchKernelGGL(cw_reset_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P, 0, 1);
+    if (obs_mode != 0)   // every env carries the RESET flag now: mode 0 writes all three frames
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, 0, (uint8_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
+{
+    const int n = P->n_envs;
+    hipLaunchKernelGGL(cw_pool_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, out);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st)
+{
+    const size_t total = (size_t)P->n_envs * P->ncell;
+    int blocks = (int)((total + 255) / 256 < 256 * 32 ? (total + 255) / 256 : 256 * 32);
+    if (blocks < 1) blocks = 1;
+    if (onehot) hipLaunchKernelGGL(cw_export_onehot_kernel, dim3(blocks), dim3(256), 0, st, *P, out);
+    else hipLaunchKernelGGL(cw_export_grid_kernel, dim3(blocks), dim3(256), 0, st, *P, out);
+    return hipGetLastError();
+}
+
+}  // extern "C"

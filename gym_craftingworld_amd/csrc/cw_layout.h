@@ -1,0 +1,80 @@
+// cw_layout.h -- HBM data layout of the batched CraftingWorld engine (host + device).
+//
+// State is SPARSE, not a dense grid: the reference world always holds exactly the 8 objects
+// sample_state() placed (ray.py:599-628) -- they transform in place (tree->sticks, sticks->house,
+// wheat->bread), vanish (rock, bread) or are carried, but never multiply -- so an env is
+//   header (16 B) + 8 object slots (cell index u16 each, 4-bit code each).
+// Every per-env array is a structure-of-arrays of 16-byte records, so one wavefront reads
+// 64 x 16 B = 1 KiB contiguous per load (env i handled by lane i): fully coalesced, and the
+// step kernel never makes a data-dependent (gather) access to HBM.  "What is in cell p" is 8
+// register compares.  Dense views (grid codes, one-hot, pixels) are materialised by the
+// render/export kernels through an LDS-free compare chain against the slots.
+#pragma once
+#include <stdint.h>
+
+#define CW_POS_GONE 0xFFFFu   // slot's object no longer exists
+#define CW_POS_HELD 0xFFFEu   // slot's object is in the agent's hand
+
+// hdr.flags
+#define CW_FLAG_RESET 0x1u    // env was (re)set by the last cw_reset / auto-reset (render: also write desired/init frames)
+#define CW_FLAG_SUBSET 0x2u   // reward_style is not None (compute_reward_subset, ray.py:763-767)
+
+// Packed header, one uint4 per env:
+//   x = agent_r | agent_c << 8 | hold << 16 | menu << 24
+//   y = achieved | desired << 16
+//   z = step_num | flags << 16
+//   w = slot codes, 4 bits each (slot k = bits 4k..4k+3); code 0 = gone
+// Slot positions, one uint4 per env: 8 x u16, slot k = (word[k>>1] >> 16*(k&1)) & 0xFFFF.
+// Slot k initially holds object k (code k+1) -- OBJECTS order, ray.py:21.
+
+#define CW_CODES_INITIAL 0x87654321u  // slot k has code k+1
+
+// One ordered selected_tasks list, device form (cw_task_menu packed): selected_bits as nibbles.
+struct CwMenuDev {
+    uint64_t sel_bits;       // nibble i = task_list.index(selected_tasks[i])
+    int32_t n_selected;
+    int32_t number_of_tasks;
+    int32_t stacking;
+    int32_t reward_subset;
+};
+
+// Everything the kernels need, passed by value.
+struct CwParams {
+    // per-env state (SoA of 16-byte records unless noted)
+    uint4 *hdr;              // [N]
+    uint4 *pos;              // [N] current slot positions
+    uint4 *init_pos;         // [N] positions at reset of objects 0..7 (INIT_OBS_VECTOR, ray.py:183)
+    uint16_t *init_agent;    // [N] agent cell at reset
+    uint4 *goal_pos;         // [N] imagine_obs final_state slot positions (ray.py:220-299)
+    uint32_t *goal_codes;    // [N]
+    uint16_t *goal_agent;    // [N]
+    int32_t *ep_no;          // [N]
+    // MT19937 per env, env-contiguous [N][624], "consume-and-replace" convention (cw_mt.h)
+    uint32_t *mt;
+    int32_t *mt_idx;         // [N] next word index 0..623
+    // fixed_init_state pool: [N][K][9] u16 (objects 0..7 + agent cell)
+    uint16_t *pool;
+    // outputs
+    int32_t *reward;         // [N]
+    uint8_t *done;           // [N]
+    uint16_t *achieved_out;  // [N]
+    uint16_t *desired_out;   // [N]
+    int32_t *episode_length; // [N]
+    uint8_t *obs;            // [N][P][P][3] or null
+    uint8_t *desired_img;
+    uint8_t *init_img;
+    // done-list compaction (double-buffered by step parity)
+    int32_t *done_list;      // [N]
+    int32_t *done_count;     // [2]
+    unsigned long long *counters; // [4]
+    const CwMenuDev *menus;
+    // constants
+    int32_t n_envs;
+    int32_t size;            // S
+    int32_t ncell;           // S*S
+    int32_t max_steps;
+    uint32_t task_mask;      // (1 << n_task_list) - 1
+    int32_t pool_k;          // fixed_init_state
+    uint32_t div_magic;      // floor(2^32 / S) + 1 : x / S == mulhi(x, magic) for x < 2^18
+    uint32_t frame_bytes;    // 48 * S * S
+};

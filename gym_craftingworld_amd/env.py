@@ -1,0 +1,199 @@
+"""Single-env gym.Env-shaped façades over the HIP engine with num_envs=1 -- the drop-in for
+`gym.make('craftingworld-v3')` & co. (reference registration: gym_craftingworld/__init__.py:5-18).
+
+Same ctor kwargs, return shapes and aliasing as the reference classes:
+  CraftingWorldEnv        <- CraftingWorldEnvRay      (craftingworld_ray.py:53)
+  CraftingWorldEnvFlat    <- CraftingWorldEnvFlat     (craftingworld_flat.py:46)
+  CraftingWorldEnvOneHot  <- CraftingWorldEnvOneHot   (carftingworld_onehot.py:53)
+Host arrays are numpy (uint8 by default; reference_dtypes=True up-casts to the reference's int64).
+No auto-reset: after done the caller calls reset(), exactly like the reference loop
+(docs/source/envs/gen_info.rst:62-82).  Compute still runs on the GPU; there is no CPU path.
+"""
+import numpy as np
+import torch
+
+from . import seeding
+from .spaces import Box, Dict, Discrete
+from .vec_env import ACTION_NAMES, TASK_LIST, CraftingWorldVecEnv
+
+
+class CraftingWorldEnv:
+    metadata = {'render.modes': ['human', 'Non']}
+    _default_size = (21, 21)
+    _default_max_steps = 300
+
+    def __init__(self, size=None, fixed_init_state=0, max_steps=None, store_gif=False, render_save_rate=1,
+                 task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True,
+                 reward_style=None, device=None, reference_dtypes=False, seed=None):
+        size = self._default_size if size is None else size
+        max_steps = self._default_max_steps if max_steps is None else max_steps
+        self._vec = CraftingWorldVecEnv(1, size=size, fixed_init_state=fixed_init_state, max_steps=max_steps,
+                                        store_gif=store_gif, render_save_rate=render_save_rate, task_list=task_list,
+                                        selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
+                                        stacking=stacking, reward_style=reward_style, obs_mode='pixels_dirty',
+                                        device=device, seed=seed, seed_style='gym', auto_reset=False)
+        v = self._vec
+        self.STATE_W, self.STATE_H = v.STATE_W, v.STATE_H
+        self.MAX_STEPS = v.MAX_STEPS
+        self.task_list, self.selected_tasks = v.task_list, v.selected_tasks
+        self.number_of_tasks, self.stacking = v.number_of_tasks, stacking
+        self.fixed_init_state = fixed_init_state
+        self._dtype = np.int64 if reference_dtypes else np.uint8
+        P = 4 * v.size
+        img = lambda: Box(low=0, high=255, shape=(P, P, 3), dtype=self._dtype)  # noqa: E731
+        self.observation_space = Dict(dict(observation=img(), desired_goal=img(), achieved_goal=img(),
+                                           init_observation=img()))                # ray.py:85-92
+        self.observation_vector_space = v.observation_vector_space                # ray.py:94-110
+        self.action_space = Discrete(len(ACTION_NAMES))                            # ray.py:133
+        self.ACTIONS = list(ACTION_NAMES)
+        self.ep_no = 0
+        self.step_num = 0
+        self.obs_image = np.zeros((P, P, 3), self._dtype)
+        self.desired_goal = np.zeros((P, P, 3), self._dtype)
+        self.INIT_OBS = np.zeros((P, P, 3), self._dtype)
+        self.observation = None
+        self.desired_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)  # ray.py:112
+        self.achieved_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)
+        self._act = torch.zeros(1, dtype=torch.int32, device=v.device)
+
+    # -- reference attributes derived from the device state on demand --------------------
+    @property
+    def obs_one_hot(self):
+        return self._vec.one_hot()[0].cpu().numpy().astype(int)
+
+    @property
+    def agent_pos(self):
+        r, c = self._vec.agent_rc[0].cpu().tolist()
+        return (r, c)
+
+    @property
+    def INIT_OBS_VECTOR(self):
+        st = self._vec.get_state()
+        return _one_hot_from(st['init_grid'][0], st['init_agent_rc'][0], 0)
+
+    def seed(self, seed=None):
+        return self._vec.seed(seed)                                               # ray.py:145-147
+
+    def set_rng_state(self, key, pos):
+        """Inject a numpy RandomState state (`env.np_random.set_state` in reference terms)."""
+        self._vec.set_rng_states(np.asarray(key)[None], np.asarray([pos]))
+
+    def get_rng_state(self):
+        k, p = self._vec.get_rng_states()
+        return k[0], int(p[0])
+
+    def _pull_goals(self):
+        hdr = self._vec.hdr[0].cpu().numpy()
+        ach = int(hdr[4]) | (int(hdr[5]) << 8)
+        des = int(hdr[6]) | (int(hdr[7]) << 8)
+        n = len(self.task_list)
+        self.achieved_goal_vector[0, :] = [(ach >> i) & 1 for i in range(n)]      # mutated in place, like ray.py:659
+        self.desired_goal_vector[0, :] = [(des >> i) & 1 for i in range(n)]
+
+    def _obs_dict(self):
+        self.observation = {'observation': self.obs_image, 'desired_goal': self.desired_goal,
+                            'achieved_goal': self.obs_image, 'init_observation': self.INIT_OBS}   # ray.py:194-196
+        return self.observation
+
+    def reset(self, render_next=False):
+        if self.step_num != 0:                                                    # ray.py:200-201
+            self.ep_no += 1
+        self.step_num = 0
+        o = self._vec.reset()
+        self.obs_image[...] = o['observation'][0].cpu().numpy()
+        self.desired_goal[...] = o['desired_goal'][0].cpu().numpy()
+        self.INIT_OBS[...] = o['init_observation'][0].cpu().numpy()
+        self._pull_goals()
+        return self._obs_dict()
+
+    def step(self, action):
+        a = int(action)
+        if not 0 <= a < len(self.ACTIONS):
+            raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
+        self._act[0] = a
+        o, reward, done, _ = self._vec.step(self._act)
+        self.step_num += 1
+        self.obs_image[...] = o['observation'][0].cpu().numpy()
+        self._pull_goals()
+        info = {'task_success': self.achieved_goal_vector, 'desired_goal': self.desired_goal_vector,
+                'achieved_goal': self.achieved_goal_vector}                        # ray.py:376-378
+        return self._obs_dict(), int(reward[0].item()), bool(done[0].item()), info
+
+    def render(self, state=None, mode='Non', tile_size=4):
+        if state is not None or mode == 'human':
+            raise NotImplementedError('render(state=...) / mode="human" (matplotlib popup) are out of scope')
+        return self._vec.render()[0].cpu().numpy().astype(self._dtype)
+
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        return self._vec.compute_reward(achieved_goal, desired_goal, info)
+
+    def close(self):
+        self._vec.close()
+
+
+class CraftingWorldEnvFlat(CraftingWorldEnv):
+    """craftingworld_flat.py:46-198: Box observation (the frame only), 8x8 / 100 steps defaults,
+    no fixed_init_state kwarg."""
+    _default_size = (8, 8)
+    _default_max_steps = 100
+
+    def __init__(self, size=None, max_steps=None, store_gif=False, render_save_rate=1, task_list=TASK_LIST,
+                 selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True, reward_style=None, **kw):
+        super().__init__(size=size, max_steps=max_steps, store_gif=store_gif, render_save_rate=render_save_rate,
+                         task_list=task_list, selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
+                         stacking=stacking, reward_style=reward_style, **kw)
+        P = 4 * self.STATE_W
+        self.observation_space = Box(low=0, high=255, shape=(P, P, 3), dtype=self._dtype)   # flat.py:57
+
+    def reset(self, render_next=False):
+        super().reset()
+        return self.obs_image                                                     # flat.py:119
+
+    def step(self, action):
+        _, r, d, info = super().step(action)
+        return self.obs_image, r, d, info                                         # flat.py:185
+
+
+def _one_hot_from(grid, agent_rc, hold):
+    S = grid.shape[0]
+    oh = np.zeros((S, S, 12), dtype=int)
+    r, c = np.nonzero(grid)
+    oh[r, c, grid[r, c] - 1] = 1
+    oh[agent_rc[0], agent_rc[1], 8] = 1
+    if hold:
+        oh[agent_rc[0], agent_rc[1], 8 + hold] = 1
+    return oh
+
+
+class CraftingWorldEnvOneHot(CraftingWorldEnv):
+    """carftingworld_onehot.py:53-389: observations are the (S,S,12) one-hot states instead of
+    images (observation/achieved_goal = current, desired_goal = imagine_obs final state,
+    init_observation = state at reset); dynamics identical."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        S = self.STATE_W
+        oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=int)  # noqa: E731
+        self.observation_space = Dict(dict(observation=oh(), desired_goal=oh(), achieved_goal=oh(),
+                                           init_observation=oh()))                # onehot.py:84-103
+        self._oh = np.zeros((S, S, 12), dtype=int)
+        self._oh_goal = np.zeros((S, S, 12), dtype=int)
+        self._oh_init = np.zeros((S, S, 12), dtype=int)
+
+    def _oh_dict(self):
+        self.observation = {'observation': self._oh, 'desired_goal': self._oh_goal, 'achieved_goal': self._oh,
+                            'init_observation': self._oh_init}
+        return self.observation
+
+    def reset(self, render_next=False):
+        super().reset()
+        st = self._vec.get_state()
+        self._oh[...] = _one_hot_from(st['grid'][0], st['agent_rc'][0], int(st['hold'][0]))
+        self._oh_goal[...] = _one_hot_from(st['goal_grid'][0], st['goal_agent_rc'][0], 0)   # onehot.py:310
+        self._oh_init[...] = self._oh                                             # onehot.py:203
+        return self._oh_dict()
+
+    def step(self, action):
+        _, r, d, info = super().step(action)
+        self._oh[...] = self._vec.one_hot()[0].cpu().numpy()                     # onehot.py:369-371
+        return self._oh_dict(), r, d, info

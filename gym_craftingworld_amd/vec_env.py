@@ -1,0 +1,307 @@
+"""CraftingWorldVecEnv -- N CraftingWorld envs stepped by hand-written HIP kernels on one MI355X.
+
+Mirrors the reference's CraftingWorldEnvRay (gym_craftingworld/envs/craftingworld_ray.py,
+"ray.py") batched the gym.vector.VectorEnv way: same ctor kwargs (ray.py:59-60), same action
+ids (ray.py:130-131), same rewards/done rule (ray.py:361-367), same four-image Dict observation
+(ray.py:194-196), auto-reset of finished envs.  All compute happens in libcraftingworld.so
+(include/craftingworld.h); this file is host plumbing: config marshalling, torch views of the
+engine's device buffers, stream hand-off.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import seeding
+from ._wrap import tensor_view
+from .spaces import Box, Dict, Discrete, MultiDiscrete
+
+TASK_LIST = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe',
+             'MoveHammer', 'MoveSticks']                       # ray.py:40-41
+OBJECTS = ['sticks', 'axe', 'hammer', 'rock', 'tree', 'bread', 'house', 'wheat']   # ray.py:21
+PICKUPABLE = ['sticks', 'axe', 'hammer']                       # ray.py:20
+ACTION_NAMES = ['up', 'right', 'down', 'left', 'pickup', 'drop']   # ray.py:130-131
+
+_OBS_MODES = {'state': L.CW_OBS_STATE, 'pixels': L.CW_OBS_PIXELS_FULL, 'pixels_dirty': L.CW_OBS_PIXELS_DIRTY}
+_ACT_DTYPES = {torch.int32: L.CW_ACT_I32, torch.int64: L.CW_ACT_I64, torch.uint8: L.CW_ACT_U8}
+
+
+def _menu_struct(task_list, selected_tasks, number_of_tasks, stacking, reward_style):
+    m = L.cw_task_menu()
+    selected_tasks = list(selected_tasks)
+    if not 1 <= len(selected_tasks) <= L.CW_MAX_TASKS:
+        raise ValueError('selected_tasks must hold 1..%d tasks' % L.CW_MAX_TASKS)
+    m.n_selected = len(selected_tasks)
+    n = number_of_tasks if number_of_tasks is not None else len(selected_tasks)      # ray.py:79
+    m.number_of_tasks = min(int(n), len(selected_tasks))                             # ray.py:80-81
+    if m.number_of_tasks < 1:
+        raise ValueError('number_of_tasks must be >= 1')
+    m.stacking = 1 if stacking is True else 0                                        # `is True`, ray.py:169
+    m.reward_subset = 0 if reward_style is None else 1                               # ray.py:71-74
+    tl = list(task_list)
+    for i, t in enumerate(selected_tasks):
+        m.selected_bits[i] = tl.index(t)                                             # ValueError like ray.py:174
+    return m
+
+
+class CraftingWorldVecEnv:
+    """Batched drop-in for CraftingWorldEnvRay; see module docstring.
+
+    Extra (non-reference) kwargs: num_envs, obs_mode ('pixels' full-frame render every step |
+    'pixels_dirty' persistent frame with <=2 repainted cells per step, the reference's own
+    render_edit strategy | 'state' no pixel buffers), device, seed, seed_style, auto_reset,
+    task_menus + env_menu (heterogeneous ordered task lists: env i uses task_menus[env_menu[i]],
+    each menu a dict with any of selected_tasks / number_of_tasks / stacking / reward_style).
+    """
+
+    metadata = {'render.modes': ['Non']}
+
+    def __init__(self, num_envs, size=(21, 21), fixed_init_state=0, max_steps=300, store_gif=False,
+                 render_save_rate=1, task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None,
+                 stacking=True, reward_style=None, obs_mode='pixels', device=None, seed=None,
+                 seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None):
+        if store_gif:
+            raise NotImplementedError('the GIF episode recorder (ray.py:565-597) is host-side debug I/O, out of scope')
+        w, h = size
+        if w != h:
+            raise ValueError('non-square grids raise IndexError in the reference (SURVEY.md §8a); rejected')
+        if obs_mode not in _OBS_MODES:
+            raise ValueError('obs_mode must be one of %s' % sorted(_OBS_MODES))
+        if not torch.cuda.is_available():
+            raise L.CraftingWorldError('no MI355X visible to torch: the CraftingWorld engine has no CPU fallback')
+        self._lib = L.load()
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != 'cuda':
+            raise ValueError('device must be a cuda (HIP) device')
+        self.device = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
+        self.num_envs = int(num_envs)
+        self.STATE_W = self.STATE_H = self.size = int(w)
+        self.MAX_STEPS = int(max_steps)
+        self.task_list = list(task_list)
+        self.selected_tasks = list(selected_tasks)
+        self.stacking = stacking
+        self.fixed_init_state = int(fixed_init_state)
+        self.obs_mode = obs_mode
+        self.auto_reset = bool(auto_reset)
+        self.seed_style = seed_style
+
+        defaults = dict(selected_tasks=selected_tasks, number_of_tasks=number_of_tasks, stacking=stacking,
+                        reward_style=reward_style)
+        menus = [dict(defaults)] if task_menus is None else [dict(defaults, **m) for m in task_menus]
+        self._menus = (L.cw_task_menu * len(menus))(*[_menu_struct(self.task_list, **m) for m in menus])
+        self.number_of_tasks = self._menus[0].number_of_tasks
+        if env_menu is not None:
+            env_menu = np.ascontiguousarray(env_menu, dtype=np.uint8)
+            if env_menu.shape != (self.num_envs,):
+                raise ValueError('env_menu must have shape (num_envs,)')
+        self._env_menu = env_menu
+
+        cfg = L.cw_config()
+        cfg.abi_version = L.CW_ABI_VERSION
+        cfg.num_envs = self.num_envs
+        cfg.size = self.size
+        cfg.max_steps = self.MAX_STEPS
+        cfg.n_task_list = len(self.task_list)
+        cfg.fixed_init_state = self.fixed_init_state
+        cfg.obs_mode = _OBS_MODES[obs_mode]
+        cfg.auto_reset = 1 if self.auto_reset else 0
+        cfg.n_menus = len(menus)
+        cfg.menus = self._menus
+        cfg.env_menu = env_menu.ctypes.data_as(C.POINTER(C.c_uint8)) if env_menu is not None else None
+        h_ = C.c_void_p()
+        L.check(self._lib.cw_create(C.byref(cfg), self.device.index, C.byref(h_)), 'cw_create')
+        self._h = h_
+
+        # zero-copy views of the engine's buffers
+        tab = L.cw_buffer_table()
+        L.check(self._lib.cw_buffers(self._h, C.byref(tab)), 'cw_buffers')
+        N, P, di = self.num_envs, 4 * self.size, self.device.index
+        v = lambda p, shape, dt: tensor_view(p, shape, dt, di)  # noqa: E731
+        self._obs = v(tab.obs, (N, P, P, 3), torch.uint8)
+        self._desired_img = v(tab.desired_goal, (N, P, P, 3), torch.uint8)
+        self._init_img = v(tab.init_obs, (N, P, P, 3), torch.uint8)
+        self.reward = v(tab.reward, (N,), torch.int32)
+        self._done_u8 = v(tab.done, (N,), torch.uint8)
+        self.done = self._done_u8.view(torch.bool)
+        self.achieved_mask = v(tab.achieved, (N,), torch.int16)      # bit i = task_list[i] (bit pattern of a u16)
+        self.desired_mask = v(tab.desired, (N,), torch.int16)
+        self.episode_length = v(tab.episode_length, (N,), torch.int32)
+        self.hdr = v(tab.hdr, (N, 16), torch.uint8)                  # packed current state, layout in craftingworld.h
+        self.slot_pos = v(tab.slot_pos, (N, 8), torch.int16)
+        self.counters = v(tab.counters, (4,), torch.int64)
+        self.agent_rc = self.hdr[:, 0:2]
+        self.hold = self.hdr[:, 2]
+
+        pix = (P, P, 3)
+        self.single_action_space = Discrete(len(ACTION_NAMES))       # ray.py:133
+        self.action_space = MultiDiscrete([len(ACTION_NAMES)] * N)
+        if obs_mode == 'state':
+            self.single_observation_space = Dict(dict(hdr=Box(0, 255, (16,), np.uint8), slot_pos=Box(-2, 32767, (8,), np.int16)))
+        else:
+            self.single_observation_space = Dict({k: Box(0, 255, pix, np.uint8) for k in
+                                                  ('observation', 'desired_goal', 'achieved_goal', 'init_observation')})
+        self.observation_space = self.single_observation_space       # batched along axis 0 of every tensor
+        self.observation_vector_space = Dict(dict(                   # ray.py:94-110
+            observation=Box(0, 1, (self.size, self.size, 12), np.uint8),
+            desired_goal=Box(0, 1, (1, len(self.task_list)), np.uint8),
+            achieved_goal=Box(0, 1, (1, len(self.task_list)), np.uint8),
+            init_observation=Box(0, 1, (self.size, self.size, 12), np.uint8)))
+        self._pending = False
+        self._actions_keepalive = None
+        self.seed(seed)                                              # ray.py:70 (OS entropy when None)
+        if self.fixed_init_state:                                    # ray.py:116-118
+            L.check(self._lib.cw_generate_fixed_states(self._h, self._stream()), 'cw_generate_fixed_states')
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.cw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ------------------------------------------------------------------ RNG (ray.py:145-147)
+    def seed(self, seed=None):
+        """Env i gets seed+i.  seed_style 'numpy': stream of numpy RandomState(seed+i);
+        'gym': gym<=0.21 np_random(seed+i) hashing (seeding.py, unpinned)."""
+        base = seeding.create_seed(seed)
+        seeds = [(base + i) for i in range(self.num_envs)]
+        if self.seed_style == 'gym':
+            keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
+            pos = np.empty(self.num_envs, dtype=np.int32)
+            for i, s in enumerate(seeds):
+                keys[i], pos[i] = seeding.mt_state_from_seed(s)
+            self.set_rng_states(keys, pos)
+        else:
+            arr = np.array([s & 0xFFFFFFFF for s in seeds], dtype=np.uint32)
+            L.check(self._lib.cw_seed_int(self._h, arr.ctypes.data_as(C.c_void_p)), 'cw_seed_int')
+        return seeds
+
+    def set_rng_states(self, keys, pos):
+        """Inject numpy RandomState states: keys uint32 [N,624], pos [N] (get_state()[1:3])."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        if keys.shape != (self.num_envs, L.CW_MT_N) or pos.shape != (self.num_envs,):
+            raise ValueError('keys must be [N,624] and pos [N]')
+        L.check(self._lib.cw_seed_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_seed_mt')
+
+    def get_rng_states(self):
+        """-> (keys uint32 [N,624], pos int32 [N]) accepted by RandomState.set_state, same stream."""
+        keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
+        pos = np.empty(self.num_envs, dtype=np.int32)
+        L.check(self._lib.cw_get_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_get_mt')
+        return keys, pos
+
+    # ------------------------------------------------------------------ gym.vector surface
+    def _observation(self):
+        if self.obs_mode == 'state':
+            return {'hdr': self.hdr, 'slot_pos': self.slot_pos}
+        return {'observation': self._obs, 'desired_goal': self._desired_img, 'achieved_goal': self._obs,
+                'init_observation': self._init_img}                  # achieved_goal IS observation, ray.py:194-196
+
+    def reset(self):
+        L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')
+        return self._observation()
+
+    def step_async(self, actions):
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dtype not in _ACT_DTYPES:
+            actions = actions.to(torch.int32)
+        actions = actions.contiguous()
+        if actions.numel() != self.num_envs:
+            raise ValueError('expected %d actions, got %d' % (self.num_envs, actions.numel()))
+        self._actions_keepalive = actions
+        L.check(self._lib.cw_step(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], self._stream()),
+                'cw_step')
+        self._pending = True
+
+    def step_wait(self):
+        if not self._pending:
+            raise RuntimeError('step_wait without step_async')
+        self._pending = False
+        info = {'task_success': self.achieved_mask, 'desired_goal': self.desired_mask,
+                'achieved_goal': self.achieved_mask, 'episode_length': self.episode_length}
+        return self._observation(), self.reward, self.done, info
+
+    def step(self, actions):
+        """-> (obs, reward int32[N], done bool[N], info); all device tensors, results are ordered on the
+        current torch stream (no host sync).  Finished envs are already reset: obs rows of done
+        envs show the first frame of the new episode; info masks are the terminal ones."""
+        self.step_async(actions)
+        return self.step_wait()
+
+    # ------------------------------------------------------------------ views / checkpoints
+    def render(self, out=None):
+        """render() of ray.py:442-520 for every env -> uint8 [N,4S,4S,3] (works in every obs_mode)."""
+        P = 4 * self.size
+        if out is None:
+            out = torch.empty((self.num_envs, P, P, 3), dtype=torch.uint8, device=self.device)
+        L.check(self._lib.cw_render(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_render')
+        return out
+
+    def grid(self, out=None):
+        """Dense cell codes uint8 [N,S,S] (0 empty, k+1 = OBJECTS[k])."""
+        if out is None:
+            out = torch.empty((self.num_envs, self.size, self.size), dtype=torch.uint8, device=self.device)
+        L.check(self._lib.cw_export_grid(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_grid')
+        return out
+
+    def one_hot(self, out=None):
+        """obs_one_hot of ray.py:119 for every env: uint8 [N,S,S,12]."""
+        if out is None:
+            out = torch.empty((self.num_envs, self.size, self.size, 12), dtype=torch.uint8, device=self.device)
+        L.check(self._lib.cw_export_onehot(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_onehot')
+        return out
+
+    def mask_to_vector(self, mask):
+        """int16 bit mask [N] -> 0/1 tensor [N, len(task_list)] (achieved_goal_vector layout, ray.py:114)."""
+        bits = torch.arange(len(self.task_list), device=mask.device, dtype=torch.int32)
+        return ((mask.to(torch.int32).unsqueeze(1) >> bits) & 1).to(torch.uint8)
+
+    def get_state(self):
+        """Host snapshot (numpy) of every env: the de-facto checkpoint."""
+        N, S = self.num_envs, self.size
+        out = dict(grid=np.empty((N, S, S), np.uint8), init_grid=np.empty((N, S, S), np.uint8),
+                   goal_grid=np.empty((N, S, S), np.uint8), agent_rc=np.empty((N, 2), np.uint8),
+                   init_agent_rc=np.empty((N, 2), np.uint8), goal_agent_rc=np.empty((N, 2), np.uint8),
+                   hold=np.empty(N, np.uint8), achieved=np.empty(N, np.uint16), desired=np.empty(N, np.uint16),
+                   step_num=np.empty(N, np.int32), ep_no=np.empty(N, np.int32))
+        view = L.cw_state_view(**{k: a.ctypes.data_as(C.c_void_p) for k, a in out.items()})
+        L.check(self._lib.cw_get_state(self._h, C.byref(view)), 'cw_get_state')
+        return out
+
+    def set_state(self, **fields):
+        """Overwrite dynamic state from numpy arrays (any subset of grid, init_grid, agent_rc, hold,
+        achieved, desired, step_num, ep_no)."""
+        dt = dict(grid=np.uint8, init_grid=np.uint8, agent_rc=np.uint8, hold=np.uint8, achieved=np.uint16,
+                  desired=np.uint16, step_num=np.int32, ep_no=np.int32)
+        keep = {}
+        view = L.cw_state_view()
+        for k, a in fields.items():
+            if k not in dt:
+                raise ValueError('cannot set %r' % k)
+            keep[k] = np.ascontiguousarray(a, dtype=dt[k])
+            if keep[k].shape[0] != self.num_envs:
+                raise ValueError('%s must have num_envs rows' % k)
+            setattr(view, k, keep[k].ctypes.data_as(C.c_void_p))
+        L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state')
+
+    def compute_reward(self, achieved_goal, desired_goal, info=None):
+        """compute_reward_equal / compute_reward_subset of ray.py:757-767 on 0/1 goal vectors
+        (host convenience for HER-style relabelling; the per-step reward comes from the kernel)."""
+        a = np.asarray(achieved_goal).reshape(-1)
+        d = np.asarray(desired_goal).reshape(-1)
+        if self._menus[0].reward_subset:
+            return self.MAX_STEPS if np.max(d.astype(np.int64) - a.astype(np.int64)) == 0 else -1
+        return self.MAX_STEPS if np.array_equal(a, d) else -1

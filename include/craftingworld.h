@@ -1,0 +1,167 @@
+/*
+ * craftingworld.h -- C ABI of the MI355X-native batched CraftingWorld step/reset engine.
+ *
+ * The reference (lauradarcy/gym-craftingworld) has no FFI/plugin interface: its boundary is the
+ * gym Python API of CraftingWorldEnvRay (gym_craftingworld/envs/craftingworld_ray.py, "ray.py").
+ * This header is the boundary a binding for that API calls into; every entry point cites the
+ * reference interface it replaces.  Plain C: pointers, sizes, integer status codes.  No torch or
+ * HIP types appear in the signatures (cw_stream_t is a hipStream_t passed as void*).
+ *
+ * Threading: one engine per device; calls on one engine are serialized by the caller.  Every
+ * call that takes a stream only ENQUEUES work on it (no host synchronisation) unless stated.
+ * Ownership: the engine owns all device buffers for its lifetime; cw_buffers() exposes them for
+ * zero-copy wrapping (valid until cw_destroy; contents valid until the next cw_step/cw_reset --
+ * the same live-alias contract as the reference, whose step() returns obs_image itself).
+ */
+#ifndef CRAFTINGWORLD_H
+#define CRAFTINGWORLD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CW_ABI_VERSION 1
+#define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
+#define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
+#define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
+#define CW_NUM_OBJECTS 8   /* OBJECTS, ray.py:21                                   */
+
+/* status codes */
+#define CW_OK 0
+#define CW_ERR_INVALID (-1)   /* bad argument / config (cw_last_error() has the text) */
+#define CW_ERR_HIP (-2)       /* a HIP runtime call failed                             */
+#define CW_ERR_STATE (-3)     /* call order (e.g. cw_step before cw_reset)             */
+
+/* cell codes of the dense views: 0 empty, k+1 = OBJECTS[k] (ray.py:21) */
+enum { CW_EMPTY = 0, CW_STICKS = 1, CW_AXE = 2, CW_HAMMER = 3, CW_ROCK = 4, CW_TREE = 5,
+       CW_BREAD = 6, CW_HOUSE = 7, CW_WHEAT = 8 };
+
+/* observation modes (cw_config.obs_mode) */
+enum {
+    CW_OBS_STATE = 0,        /* no pixel buffers; state tensors only (BASELINE config 2)            */
+    CW_OBS_PIXELS_FULL = 1,  /* render(): whole (4S,4S,3) uint8 frame rewritten every step, ray.py:442-520 */
+    CW_OBS_PIXELS_DIRTY = 2  /* render_edit(): persistent frame, <=2 changed cells repainted, ray.py:522-557 */
+};
+
+/* action dtypes accepted by cw_step */
+enum { CW_ACT_I32 = 0, CW_ACT_I64 = 1, CW_ACT_U8 = 2 };
+
+/* One ordered selected_tasks list with its draw rules -- the ctor kwargs selected_tasks,
+ * number_of_tasks, stacking, reward_style of ray.py:59-83.  Kept as an ORDERED list because
+ * reset() shuffles indices into it (ray.py:171-174). */
+typedef struct cw_task_menu {
+    int32_t n_selected;                  /* len(selected_tasks), 1..CW_MAX_TASKS                   */
+    int32_t number_of_tasks;             /* ray.py:79-81 (clamped to n_selected by cw_create)      */
+    int32_t stacking;                    /* `stacking is True`, ray.py:169                         */
+    int32_t reward_subset;               /* reward_style is not None -> compute_reward_subset      */
+    int32_t selected_bits[CW_MAX_TASKS]; /* task_list.index(selected_tasks[i]), ray.py:174         */
+} cw_task_menu;
+
+/* CraftingWorldEnvRay.__init__ kwargs (ray.py:59-60) for a batch of num_envs envs */
+typedef struct cw_config {
+    int32_t abi_version;        /* CW_ABI_VERSION */
+    int32_t num_envs;           /* N */
+    int32_t size;               /* STATE_W == STATE_H, 4..255 (non-square rejected: reference defect) */
+    int32_t max_steps;          /* MAX_STEPS, 1..65535 */
+    int32_t n_task_list;        /* len(task_list), 9..CW_MAX_TASKS */
+    int32_t fixed_init_state;   /* 0, or pool size K per env (ray.py:116-118), K <= 64 */
+    int32_t obs_mode;           /* CW_OBS_* */
+    int32_t auto_reset;         /* 1: cw_step resets finished envs itself (gym.vector semantics);
+                                 * 0: finished envs keep stepping until cw_reset (single gym.Env semantics, ray.py:367) */
+    int32_t n_menus;            /* 1..CW_MAX_MENUS */
+    const cw_task_menu *menus;  /* host array [n_menus] */
+    const uint8_t *env_menu;    /* host array [num_envs] of menu ids, or NULL (= all envs use menu 0) */
+} cw_config;
+
+typedef struct cw_engine cw_engine;
+typedef void *cw_stream_t;      /* hipStream_t */
+
+/* Device buffers owned by the engine (cw_buffers).  N = num_envs, S = size, P = 4*S.
+ * Pixel buffers are NULL in CW_OBS_STATE. */
+typedef struct cw_buffer_table {
+    uint8_t *obs;            /* [N][P][P][3]  observation == achieved_goal image (ray.py:194-196) */
+    uint8_t *desired_goal;   /* [N][P][P][3]  imagine_obs() image, rewritten at reset (ray.py:191) */
+    uint8_t *init_obs;       /* [N][P][P][3]  INIT_OBS, rewritten at reset (ray.py:193)            */
+    int32_t *reward;         /* [N]  -1 or max_steps (ray.py:361-363)                              */
+    uint8_t *done;           /* [N]  0/1 (ray.py:367); done envs have already been auto-reset      */
+    uint16_t *achieved;      /* [N]  achieved_goal_vector as a bit mask AFTER the step, BEFORE auto-reset */
+    uint16_t *desired;       /* [N]  desired_goal_vector of the episode the step belonged to       */
+    int32_t *episode_length; /* [N]  step_num at done (valid where done==1)                        */
+    uint8_t *hdr;            /* [N][16] packed per-env header of the CURRENT state (after auto-reset):
+                              *   byte 0 agent row, 1 agent col, 2 hold (0 none,1 sticks,2 axe,3 hammer), 3 menu id,
+                              *   bytes 4-5 achieved mask (LE u16), 6-7 desired mask, 8-9 step_num, 10-11 flags,
+                              *   bytes 12-15 the 8 object slots' codes, 4 bits each (slot k in bits 4k..4k+3)      */
+    uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
+    uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
+    size_t frame_bytes;      /* P*P*3 */
+} cw_buffer_table;
+
+/* Host-side dense snapshot for parity injection / checkpointing (cw_get_state, cw_set_state).
+ * All pointers are HOST arrays supplied by the caller; a NULL pointer skips that field. */
+typedef struct cw_state_view {
+    uint8_t *grid;        /* [N][S][S] cell codes            (obs_one_hot[:,:,:8], ray.py:119)   */
+    uint8_t *init_grid;   /* [N][S][S] codes at reset        (INIT_OBS_VECTOR, ray.py:183)       */
+    uint8_t *goal_grid;   /* [N][S][S] imagine_obs final_state codes (get only)                  */
+    uint8_t *agent_rc;    /* [N][2]                          (agent_pos)                          */
+    uint8_t *init_agent_rc; /* [N][2] agent cell at reset (get only; channel 8 of INIT_OBS_VECTOR) */
+    uint8_t *goal_agent_rc; /* [N][2] (get only)                                                   */
+    uint8_t *hold;        /* [N]                                                                   */
+    uint16_t *achieved;   /* [N]                             (achieved_goal_vector)               */
+    uint16_t *desired;    /* [N]                             (desired_goal_vector)                */
+    int32_t *step_num;    /* [N]                                                                   */
+    int32_t *ep_no;       /* [N]                                                                   */
+} cw_state_view;
+
+/* --- lifetime: replaces CraftingWorldEnvRay.__init__ (ray.py:59-143) for N envs ------------- */
+int cw_create(const cw_config *cfg, int device, cw_engine **out);
+int cw_destroy(cw_engine *e);
+
+/* --- RNG: replaces seed() (ray.py:145-147) ----------------------------------------------------
+ * cw_seed_mt injects numpy RandomState states: keys[N][624], pos[N] (RandomState.get_state()[1:3]).
+ * cw_seed_int seeds env i like numpy RandomState(seeds[i]) (init_genrand).  Both are synchronous
+ * host calls.  cw_get_mt returns states a numpy RandomState accepts via set_state and that
+ * continue the identical stream. */
+int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos);
+int cw_seed_int(cw_engine *e, const uint32_t *seeds);
+int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos);
+
+/* generate_fixed_states (ray.py:149-154): draw fixed_init_state placements per env from the
+ * env's current RNG stream.  No-op when fixed_init_state == 0. */
+int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream);
+
+/* --- reset() for every env (ray.py:156-218): task draw, placement, imagine_obs, render ------ */
+int cw_reset(cw_engine *e, cw_stream_t stream);
+
+/* --- step(action) for every env (ray.py:301-378) + auto-reset of finished envs --------------
+ * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
+ * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
+ * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues: step kernel,
+ * reset kernel over the ballot-compacted done list, render kernel. */
+int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
+
+/* render(state=None) for every env into a caller-supplied DEVICE buffer [N][P][P][3] (works in
+ * every obs_mode; ray.py:442-520). */
+int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);
+
+/* Dense state views written to caller-supplied DEVICE buffers (observation_vector_space,
+ * ray.py:94-110): cw_export_grid -> [N][S][S] uint8 codes; cw_export_onehot -> [N][S][S][12]
+ * uint8 0/1 (channels 0-7 objects, 8 agent, 9-11 held item at the agent cell). */
+int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream);
+int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream);
+
+/* --- state injection / checkpoint (synchronous; SURVEY §5 "checkpoint / resume") ------------ */
+int cw_get_state(cw_engine *e, cw_state_view *host);
+int cw_set_state(cw_engine *e, const cw_state_view *host);
+
+int cw_buffers(cw_engine *e, cw_buffer_table *out);
+int cw_num_envs(const cw_engine *e);
+int cw_abi_version(void);
+const char *cw_last_error(void);   /* thread-local text of the last failing call */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,392 @@
+"""GPU parity tests: the HIP engine (through the C ABI, via gym_craftingworld_amd) against
+  (1) the golden fixtures captured from the reference itself (tests/golden, tools/gen_golden.py),
+  (2) the CPU oracle on seeded random batches (auto-reset, mixed task menus, 5x5..32x32),
+  (3) injected single-step states covering the whole transition table,
+  (4) size-independent properties at BASELINE's full batch size (65 536 envs).
+Bit-exact everywhere: the path is integer-only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import crc, fixture_names, load
+
+pytestmark = pytest.mark.gpu
+
+TASKS = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe', 'MoveHammer',
+         'MoveSticks']
+
+
+def _np_states(n, base):
+    sts = [np.random.RandomState(base + i).get_state() for i in range(n)]
+    keys = np.stack([s[1] for s in sts]).astype(np.uint32)
+    pos = np.array([s[2] for s in sts], dtype=np.int32)
+    return keys, pos
+
+
+def _hdr_fields(hdr):
+    h = hdr.cpu().numpy().astype(np.int64)
+    return dict(agent=h[:, 0:2], hold=h[:, 2], achieved=h[:, 4] | (h[:, 5] << 8), desired=h[:, 6] | (h[:, 7] << 8),
+                step_num=h[:, 8] | (h[:, 9] << 8))
+
+
+# ------------------------------------------------------------------ (1) golden fixtures
+@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty'])
+@pytest.mark.parametrize('name', fixture_names())
+def test_golden_fixture_replay(name, obs_mode):
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    meta, kw, g = load(name)
+    env = CraftingWorldVecEnv(1, obs_mode=obs_mode, seed=0, **kw)
+    env.set_rng_states(g['key0'][None], np.array([g['pos0']]))
+    if kw.get('fixed_init_state'):
+        # the pool is drawn from the env RNG at construction (ray.py:116-118): redo it on the injected stream
+        import ctypes as C
+        from gym_craftingworld_amd import _lib as L
+        L.check(env._lib.cw_generate_fixed_states(env._h, env._stream()), 'pool')
+    size = kw['size'][0]
+    ri = 0
+
+    def check_reset(obs, t):
+        nonlocal ri
+        st = env.get_state()
+        assert st['desired'][0] == g['r_desired'][ri], (name, 'desired', ri)
+        assert np.array_equal(st['grid'][0], g['r_grid'][ri]), (name, 'reset grid', ri)
+        assert tuple(st['agent_rc'][0]) == tuple(g['r_agent'][ri])
+        assert crc(obs['observation'][0].cpu().numpy()) == g['r_obs_crc'][ri], (name, 'reset obs', ri)
+        assert crc(obs['desired_goal'][0].cpu().numpy()) == g['r_desired_img_crc'][ri], (name, 'desired img', ri)
+        assert crc(obs['init_observation'][0].cpu().numpy()) == g['r_init_img_crc'][ri]
+        assert g['r_at_step'][ri] == t
+        assert st['ep_no'][0] == g['r_ep_no'][ri]
+        if ri < len(g['img_desired']):
+            assert np.array_equal(obs['desired_goal'][0].cpu().numpy(), g['img_desired'][ri])
+        ri += 1
+
+    obs = env.reset()
+    check_reset(obs, 0)
+    T = len(g['action'])
+    acts = torch.as_tensor(g['action'].astype(np.int32), device=env.device)
+    check_every = 1 if T <= 3000 else 2
+    for t in range(T):
+        obs, rew, done, info = env.step(acts[t:t + 1])
+        r, d = int(rew[0].item()), bool(done[0].item())
+        assert r == g['reward'][t], (name, 'reward', t)
+        assert d == bool(g['done'][t]), (name, 'done', t)
+        ach = int(info['achieved_goal'][0].item()) & 0xFFFF
+        assert ach == g['achieved'][t], (name, 'achieved', t, bin(ach), bin(g['achieved'][t]))
+        if d:
+            check_reset(obs, t + 1)
+        elif t % check_every == 0:
+            f = _hdr_fields(env.hdr)
+            assert tuple(f['agent'][0]) == tuple(g['agent'][t]), (name, 'agent', t)
+            assert f['hold'][0] == g['hold'][t], (name, 'hold', t)
+            assert f['step_num'][0] == g['step_num'][t]
+            assert crc(obs['observation'][0].cpu().numpy()) == g['obs_crc'][t], (name, 'obs', t)
+            assert crc(env.grid()[0].cpu().numpy()) == g['grid_crc'][t], (name, 'grid', t)
+    assert ri == len(g['r_desired'])
+    assert np.array_equal(obs['observation'][0].cpu().numpy(), g['final_obs'])
+    # the MT19937 stream position after the last reset is the reference's
+    keys, pos = env.get_rng_states()
+    assert pos[0] % 624 == g['r_rng_pos'][-1] % 624
+    env.close()
+
+
+# ------------------------------------------------------------------ (2) oracle, random batches
+CASES = [
+    dict(N=256, T=130, kw=dict(size=(5, 5), max_steps=20)),
+    dict(N=192, T=650, kw=dict(size=(21, 21), max_steps=300)),
+    dict(N=64, T=120, kw=dict(size=(32, 32), max_steps=50)),
+    dict(N=128, T=200, kw=dict(size=(6, 6), max_steps=30, reward_style='subset', stacking=False)),
+    dict(N=96, T=150, kw=dict(size=(7, 7), max_steps=25, fixed_init_state=4)),
+    dict(N=100, T=100, kw=dict(size=(4, 4), max_steps=15, selected_tasks=['GoToHouse', 'EatBread', 'MoveAxe'], number_of_tasks=2)),
+]
+
+
+@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty', 'state'])
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'N%d_S%d' % (c['N'], c['kw']['size'][0]))
+def test_random_batch_vs_oracle(case, obs_mode):
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, kw = case['N'], case['T'], case['kw']
+    keys, pos = _np_states(N, 31000)
+    # fixed_init_state pools are drawn from the env stream (ray.py:116-118): inject the stream, then redraw the pool
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, **kw)
+    env.set_rng_states(keys, pos)
+    if kw.get('fixed_init_state'):
+        from gym_craftingworld_amd import _lib as L
+        L.check(env._lib.cw_generate_fixed_states(env._h, env._stream()), 'pool')
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), **kw)
+    env.reset()
+    ora.reset()
+    acts = np.random.RandomState(5).randint(0, 6, size=(T, N)).astype(np.int64)
+    dacts = torch.as_tensor(acts, device=env.device)
+    n_done = 0
+    for t in range(T):
+        obs, rew, done, info = env.step(dacts[t])
+        # terminal masks must be read before the oracle resets
+        o_rew = np.empty(N, np.int32)
+        o_done = np.zeros(N, bool)
+        o_ach = np.empty(N, np.int64)
+        for i, e in enumerate(ora.envs):
+            _, o_rew[i], o_done[i], _ = e.step(int(acts[t, i]))
+            o_ach[i] = e.view().achieved
+            if o_done[i]:
+                e.reset()
+        assert np.array_equal(rew.cpu().numpy(), o_rew), ('reward', t)
+        assert np.array_equal(done.cpu().numpy(), o_done), ('done', t)
+        assert np.array_equal(info['achieved_goal'].cpu().numpy().astype(np.int64) & 0xFFFF, o_ach), ('achieved', t)
+        n_done += int(o_done.sum())
+        if t % 37 == 0 or t == T - 1:
+            _compare_full(env, ora, obs_mode, t)
+    assert n_done > 0
+    assert int(env.counters[1].item()) == n_done
+    assert int(env.counters[0].item()) == N * T
+    # RNG streams continue identically
+    k2, p2 = env.get_rng_states()
+    for i in (0, N // 2, N - 1):
+        rs = np.random.RandomState()
+        rs.set_state(('MT19937', k2[i], int(p2[i]), 0, 0.0))
+        ok, op = ora.envs[i].get_rng()
+        ro = np.random.RandomState()
+        ro.set_state(('MT19937', ok, op, 0, 0.0))
+        assert np.array_equal(rs.randint(0, 2**32, 700, dtype=np.uint32), ro.randint(0, 2**32, 700, dtype=np.uint32))
+    env.close()
+
+
+def _compare_full(env, ora, obs_mode, t):
+    st = env.get_state()
+    grid_dev = env.grid().cpu().numpy()
+    oh = env.one_hot().cpu().numpy()
+    frames = env.render().cpu().numpy()
+    if obs_mode != 'state':
+        o = env._observation()
+        obs, des, ini = (o[k].cpu().numpy() for k in ('observation', 'desired_goal', 'init_observation'))
+    for i, s in enumerate(ora.states()):
+        tag = ('env', i, 'step', t)
+        assert np.array_equal(st['grid'][i], s['grid']), tag
+        assert np.array_equal(grid_dev[i], s['grid']), tag
+        assert np.array_equal(st['init_grid'][i], s['init_grid']), tag
+        assert np.array_equal(st['goal_grid'][i], s['goal_grid']), tag
+        assert tuple(st['agent_rc'][i]) == s['agent'] and tuple(st['goal_agent_rc'][i]) == s['goal_agent'], tag
+        assert st['hold'][i] == s['hold'] and st['achieved'][i] == s['achieved'] and st['desired'][i] == s['desired'], tag
+        assert st['step_num'][i] == s['step_num'] and st['ep_no'][i] == s['ep_no'], tag
+        assert np.array_equal(frames[i], s['obs']), tag
+        # one-hot view: channels 0-7 objects, 8 agent, 9-11 hold (ray.py:94-98)
+        g = s['grid']
+        assert np.array_equal(oh[i, :, :, :8].argmax(-1) * oh[i, :, :, :8].any(-1) + oh[i, :, :, :8].any(-1), np.where(g > 0, g, 0)), tag
+        assert oh[i, s['agent'][0], s['agent'][1], 8] == 1 and oh[i, :, :, 8].sum() == 1, tag
+        assert oh[i, :, :, 9:].sum() == (1 if s['hold'] else 0), tag
+        if obs_mode != 'state':
+            assert np.array_equal(obs[i], s['obs']), tag
+            assert np.array_equal(des[i], s['desired_img']), tag
+            assert np.array_equal(ini[i], s['init_img']), tag
+
+
+def test_mixed_task_menus_vs_oracle():
+    """BASELINE config 4 shape: env i uses menu[i % M] (ordered selected_tasks lists)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    menus = [dict(selected_tasks=TASKS), dict(selected_tasks=['MoveSticks', 'MakeBread'], stacking=False),
+             dict(selected_tasks=['ChopRock', 'ChopTree', 'BuildHouse', 'GoToHouse'], number_of_tasks=3, reward_style='subset'),
+             dict(selected_tasks=list(reversed(TASKS)), number_of_tasks=4)]
+    N, T = 128, 160
+    env_menu = np.arange(N) % len(menus)
+    kw = dict(size=(6, 6), max_steps=25)
+    keys, pos = _np_states(N, 777)
+    env = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', task_menus=menus, env_menu=env_menu, **kw)
+    env.set_rng_states(keys, pos)
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), per_env_kwargs=[menus[m] for m in env_menu], **kw)
+    env.reset()
+    ora.reset()
+    acts = np.random.RandomState(11).randint(0, 6, size=(T, N)).astype(np.int32)
+    dacts = torch.as_tensor(acts, device=env.device)
+    for t in range(T):
+        obs, rew, done, _ = env.step(dacts[t])
+        o_rew, o_done = ora.step(acts[t])
+        assert np.array_equal(rew.cpu().numpy(), o_rew) and np.array_equal(done.cpu().numpy(), o_done), t
+    _compare_full(env, ora, 'pixels_dirty', T)
+    env.close()
+
+
+# ------------------------------------------------------------------ (3) injected transition table
+def test_injected_states_single_step():
+    """Random (grid, agent, hold, achieved, desired, init grid) x all 6 actions, one step each, both
+    reward styles -- covers blocked moves, failed-move bit flips, Move* 1->0 reversals, every
+    object under the agent, edge clamping on all four walls."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleEnv
+    rng = np.random.RandomState(2024)
+    S, N = 5, 6 * 400
+    for style in (None, 'subset'):
+        env = CraftingWorldVecEnv(N, size=(S, S), max_steps=10, obs_mode='pixels_dirty', reward_style=style, auto_reset=False)
+        env.reset()
+        grids = np.zeros((N, S, S), np.uint8)
+        inits = np.zeros((N, S, S), np.uint8)
+        agent = np.zeros((N, 2), np.uint8)
+        hold = np.zeros(N, np.uint8)
+        ach = np.zeros(N, np.uint16)
+        des = np.zeros(N, np.uint16)
+        stepn = np.zeros(N, np.int32)
+        for j in range(N // 6):
+            cells = rng.permutation(S * S)
+            nobj = rng.randint(0, 8)
+            g = np.zeros(S * S, np.uint8)
+            h = rng.randint(0, 4) if rng.rand() < 0.6 else 0
+            g[cells[:nobj]] = rng.randint(1, 9, size=nobj)
+            if h and nobj == 8:
+                h = 0
+            ig = np.zeros(S * S, np.uint8)
+            ig[rng.permutation(S * S)[:8]] = np.arange(1, 9)          # one of each, like sample_state
+            if rng.rand() < 0.5 and nobj:                              # make "at its origin" cases likely
+                ig[:] = 0
+                ig[rng.permutation(S * S)[:8]] = np.arange(1, 9)
+            a_cell = cells[rng.randint(0, S * S)] if rng.rand() < 0.5 else rng.randint(0, S * S)
+            for a in range(6):
+                i = j * 6 + a
+                grids[i] = g.reshape(S, S)
+                inits[i] = ig.reshape(S, S)
+                agent[i] = divmod(int(a_cell), S)
+                hold[i] = h
+                ach[i] = rng.randint(0, 512)
+                des[i] = rng.randint(1, 512) if rng.rand() < 0.7 else ach[i]
+                stepn[i] = rng.randint(0, 10)
+        env.set_state(grid=grids, init_grid=inits, agent_rc=agent, hold=hold, achieved=ach, desired=des, step_num=stepn)
+        acts = torch.as_tensor(np.tile(np.arange(6), N // 6).astype(np.int32), device=env.device)
+        obs, rew, done, info = env.step(acts)
+        st = env.get_state()
+        rew, done = rew.cpu().numpy(), done.cpu().numpy()
+        frames = obs['observation'].cpu().numpy()
+        o = OracleEnv(size=(S, S), max_steps=10, reward_style=style)
+        for i in range(N):
+            o.set_state(grids[i], inits[i], agent[i], hold[i], int(ach[i]), int(des[i]), int(stepn[i]))
+            oo, r, d, _ = o.step(i % 6)
+            s = o.state()
+            tag = (style, i, 'action', i % 6)
+            assert r == rew[i] and d == done[i], tag
+            assert np.array_equal(st['grid'][i], s['grid']), tag
+            assert tuple(st['agent_rc'][i]) == s['agent'] and st['hold'][i] == s['hold'], tag
+            assert st['achieved'][i] == s['achieved'], (tag, bin(st['achieved'][i]), bin(s['achieved']))
+            assert st['step_num'][i] == s['step_num'], tag
+            assert np.array_equal(frames[i], s['obs']), tag
+        env.close()
+
+
+def test_invalid_actions_counted_not_executed():
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    env = CraftingWorldVecEnv(64, size=(5, 5), max_steps=9, obs_mode='state')
+    env.reset()
+    before = env.get_state()
+    env.step(torch.full((64,), 6, dtype=torch.int64, device=env.device))
+    env.step(torch.full((64,), -1, dtype=torch.int32, device=env.device))
+    after = env.get_state()
+    assert np.array_equal(before['grid'], after['grid']) and np.array_equal(before['agent_rc'], after['agent_rc'])
+    assert (after['step_num'] == 2).all() and int(env.counters[3].item()) == 128
+    assert (env.reward.cpu().numpy() == -1).all()
+    env.close()
+
+
+# ------------------------------------------------------------------ (4) full-size properties
+def test_shard_equivalence_and_batch_position_invariance():
+    """GPU g of G owns envs [g*N/G,(g+1)*N/G): running the shards separately equals the single batch."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, T, kw = 512, 80, dict(size=(8, 8), max_steps=30)
+    keys, pos = _np_states(N, 4000)
+    acts = torch.as_tensor(np.random.RandomState(3).randint(0, 6, size=(T, N)).astype(np.int32), device='cuda')
+
+    def run(lo, hi):
+        env = CraftingWorldVecEnv(hi - lo, obs_mode='pixels', **kw)
+        env.set_rng_states(keys[lo:hi], pos[lo:hi])
+        env.reset()
+        rs, ds = [], []
+        for t in range(T):
+            o, r, d, _ = env.step(acts[t, lo:hi].contiguous())
+            rs.append(r.clone())
+            ds.append(d.clone())
+        out = (torch.stack(rs).cpu().numpy(), torch.stack(ds).cpu().numpy(), o['observation'].cpu().numpy(),
+               o['desired_goal'].cpu().numpy(), env.get_state())
+        env.close()
+        return out
+
+    whole = run(0, N)
+    parts = [run(0, 128), run(128, 320), run(320, N)]
+    assert np.array_equal(whole[0], np.concatenate([p[0] for p in parts], axis=1))
+    assert np.array_equal(whole[1], np.concatenate([p[1] for p in parts], axis=1))
+    assert np.array_equal(whole[2], np.concatenate([p[2] for p in parts], axis=0))
+    assert np.array_equal(whole[3], np.concatenate([p[3] for p in parts], axis=0))
+    for k in whole[4]:
+        assert np.array_equal(whole[4][k], np.concatenate([p[4][k] for p in parts], axis=0)), k
+
+
+@pytest.mark.parametrize('size,max_steps', [(21, 300), (32, 40)])
+def test_full_size_properties_65536(size, max_steps):
+    """BASELINE configs 3 and 5 at full batch size, through size-independent properties:
+    the frame is a pure function of the state (full-frame render == dirty-cell repaint == render()
+    of the current state), the first 256 envs equal the CPU oracle, counters add up."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T = 65536, 45
+    kw = dict(size=(size, size), max_steps=max_steps)
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', seed=123, **kw)
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', seed=123, **kw)
+    keys, pos = full.get_rng_states()
+    M = 256
+    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in range(M)], **kw)
+    full.reset()
+    dirty.reset()
+    ora.reset()
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    dones = 0
+    for t in range(T):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.int32, generator=gen)
+        of, rf, df, _ = full.step(a)
+        od, rd, dd, _ = dirty.step(a)
+        assert torch.equal(rf, rd) and torch.equal(df, dd), t
+        o_rew, o_done = ora.step(a[:M].cpu().numpy())
+        assert np.array_equal(rf[:M].cpu().numpy(), o_rew) and np.array_equal(df[:M].cpu().numpy(), o_done), t
+        dones += int(df.sum().item())
+        if t % 11 == 0 or t == T - 1:
+            assert torch.equal(of['observation'], od['observation']), t
+            assert torch.equal(of['desired_goal'], od['desired_goal']), t
+            assert torch.equal(of['init_observation'], od['init_observation']), t
+            assert torch.equal(full.render(), of['observation']), t
+    for i, s in enumerate(ora.states()):
+        assert np.array_equal(of['observation'][i].cpu().numpy(), s['obs']), i
+    assert torch.equal(full.hdr, dirty.hdr) and torch.equal(full.slot_pos, dirty.slot_pos)
+    assert int(full.counters[1].item()) == dones and int(full.counters[0].item()) == N * T
+    if max_steps <= T:
+        assert dones >= N        # every env timed out at least once (synchronized resets inside the window)
+    full.close()
+    dirty.close()
+
+
+def test_single_env_facade_matches_golden():
+    """craftingworld-v3 surface (N=1, numpy, no auto-reset) on BASELINE config 1's known-answer
+    vector: RandomState(12345) reset + 300 actions from RandomState(999)."""
+    import gym_craftingworld_amd as g
+    env = g.make('craftingworld-v3')
+    st = np.random.RandomState(12345).get_state()
+    env.set_rng_state(st[1], st[2])
+    obs = env.reset()
+    assert obs['achieved_goal'] is obs['observation']
+    assert env.desired_goal_vector.tolist() == [[1, 0, 0, 1, 0, 0, 0, 1, 0]] and env.agent_pos == (8, 5)
+    assert crc(obs['observation']) == 0xf34f1edc and crc(obs['desired_goal']) == 0x9e9a73eb
+    first = obs['observation']
+    total, done = 0, False
+    for a in np.random.RandomState(999).randint(0, 6, size=300):
+        obs, r, done, info = env.step(a)
+        total += r
+    assert obs['observation'] is first                       # live alias, mutated in place (ray.py:359)
+    assert total == -300 and done and env.agent_pos == (18, 5) and crc(obs['observation']) == 0x2c3d814f
+    assert info['achieved_goal'].sum() == 0
+    with pytest.raises(IndexError):
+        env.step(6)
+    env.close()
+    flat = g.make('craftingworldflat-v3')
+    o = flat.reset()
+    assert o.shape == (32, 32, 3)
+    o2, r, d, _ = flat.step(1)
+    assert o2 is o
+    flat.close()
+    oh = g.make('craftingworldonehot-v3', size=(6, 6))
+    o = oh.reset()
+    assert o['observation'].shape == (6, 6, 12) and o['observation'][:, :, 8].sum() == 1
+    assert o['desired_goal'][:, :, 8].sum() == 1
+    oh.close()

@@ -1,0 +1,129 @@
+"""CPU-only tests of the product's host logic: the C-ABI library loads and exports every symbol
+include/craftingworld.h declares, MT19937 state conversion (numpy form <-> the engine's
+consume-and-replace form) is stream-exact, seeding helpers, and the product never touches the
+oracle.  No compute entry point is called (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from gym_craftingworld_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'craftingworld.h')).read()
+    declared = set(re.findall(r'^\s*(?:const\s+)?(?:int|char\s*\*|const char \*)\s*\*?\s*(cw_[a-z_0-9]+)\s*\(', hdr, re.M))
+    assert len(declared) >= 16, declared
+    from gym_craftingworld_amd import _lib
+    assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cw_abi_version() == 1
+
+
+def test_struct_sizes_match_header(lib):
+    from gym_craftingworld_amd import _lib
+    assert C.sizeof(_lib.cw_task_menu) == 4 * 4 + 16 * 4
+    assert C.sizeof(_lib.cw_config) == 9 * 4 + 4 + 2 * 8      # 9 ints, pad, 2 pointers
+    assert C.sizeof(_lib.cw_buffer_table) == 12 * 8
+    assert C.sizeof(_lib.cw_state_view) == 11 * 8
+
+
+def _engine_next(s, k):
+    """cw_mt.h CwMt::next() restated for the test (consume-and-replace)."""
+    cur, nxt, far = int(s[k]), int(s[(k + 1) % 624]), int(s[(k + 397) % 624])
+    y = (cur & 0x80000000) | (nxt & 0x7fffffff)
+    s[k] = far ^ (y >> 1) ^ (0x9908b0df if y & 1 else 0)
+    o = cur
+    o ^= o >> 11
+    o ^= (o << 7) & 0x9d2c5680
+    o ^= (o << 15) & 0xefc60000
+    o ^= o >> 18
+    return o & 0xFFFFFFFF, (k + 1) % 624
+
+
+@pytest.mark.parametrize('seed,burn', [(0, 0), (1, 5), (7, 623), (123, 624), (99, 1000), (5, 227), (6, 397)])
+def test_mt_conversion_roundtrip(lib, seed, burn):
+    rs = np.random.RandomState(seed)
+    if burn:
+        rs.randint(0, 2**32, size=burn, dtype=np.uint32)
+    st = rs.get_state()
+    s = st[1].astype(np.uint32).copy()
+    idx = lib.cwh_mt_from_numpy(s.ctypes.data_as(C.c_void_p), int(st[2]))
+    draws = 1500
+    ref = rs.randint(0, 2**32, size=draws, dtype=np.uint32)
+    got = np.empty(draws, dtype=np.uint32)
+    k = idx
+    for i in range(draws):
+        got[i], k = _engine_next(s, k)
+    assert np.array_equal(ref, got)
+    # export back: numpy continues identically from the exported state
+    key = np.empty(624, dtype=np.uint32)
+    lib.cwh_mt_to_numpy(s.ctypes.data_as(C.c_void_p), k, key.ctypes.data_as(C.c_void_p))
+    rs2 = np.random.RandomState()
+    rs2.set_state(('MT19937', key, k, 0, 0.0))
+    assert np.array_equal(rs.randint(0, 2**32, size=2000, dtype=np.uint32),
+                          rs2.randint(0, 2**32, size=2000, dtype=np.uint32))
+    # and, except for the unrecoverable (and unused) low 31 bits of key[0], it IS numpy's key
+    st2 = rs_state_at(seed, burn + draws)
+    if k != 0:
+        assert st2[2] == k
+        assert np.array_equal(st2[1][1:], key[1:]) and (int(st2[1][0]) ^ int(key[0])) & 0x80000000 == 0
+
+
+def rs_state_at(seed, n):
+    rs = np.random.RandomState(seed)
+    if n:
+        rs.randint(0, 2**32, size=n, dtype=np.uint32)
+    return rs.get_state()
+
+
+def test_init_genrand_matches_numpy(lib):
+    for seed in (0, 1, 42, 2**32 - 1):
+        s = np.empty(624, dtype=np.uint32)
+        lib.cwh_mt_init_genrand(s.ctypes.data_as(C.c_void_p), seed)
+        assert np.array_equal(s, np.random.RandomState(seed).get_state()[1])
+
+
+def test_seeding_gym021_shape():
+    from gym_craftingworld_amd import seeding
+    rs, seed = seeding.np_random(123)
+    assert seed == 123 and isinstance(rs, np.random.RandomState)
+    key, pos = seeding.mt_state_from_seed(123)
+    assert key.shape == (624,) and pos == 624
+    a, _ = seeding.np_random(123)
+    assert a.randint(1 << 30) == rs.randint(1 << 30)
+    with pytest.raises(ValueError):
+        seeding.create_seed(-1)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import gym_craftingworld_amd as g
+    with pytest.raises(g.CraftingWorldError):
+        g.CraftingWorldVecEnv(2)
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(2, size=(6, 4))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under gym_craftingworld_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'gym_craftingworld_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f), errors='replace').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, re.M), f
+                assert 'cw_oracle' not in txt and 'libcw_oracle' not in txt, f
