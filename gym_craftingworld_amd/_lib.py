@@ -46,6 +46,11 @@ class cw_state_view(C.Structure):
                 ('step_num', C.c_void_p), ('ep_no', C.c_void_p)]
 
 
+class cw_profile(C.Structure):
+    _fields_ = [('steps', C.c_int32), ('ms_step_kernel', C.c_float), ('ms_reset_kernel', C.c_float),
+                ('ms_render_kernel', C.c_float), ('ms_render_kernel_max', C.c_float), ('ms_render_kernel_min', C.c_float)]
+
+
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 ABI = {
@@ -62,6 +67,8 @@ ABI = {
     'cw_export_onehot': (C.c_int, [_VP, _VP, _VP]),
     'cw_get_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
     'cw_set_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
+    'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
+    'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
     'cw_num_envs': (C.c_int, [_VP]),
     'cw_abi_version': (C.c_int, []),

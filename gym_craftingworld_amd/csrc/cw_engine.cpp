@@ -13,7 +13,7 @@
 #include "cw_layout.h"
 
 extern "C" {
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st);
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st, hipEvent_t *ev);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
@@ -63,6 +63,8 @@ struct cw_engine {
     std::vector<void *> allocs;
     std::vector<CwMenuDev> menus;
     int n = 0, S = 0, ncell = 0, K = 0;
+    std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
+    int prof_cap = 0, prof_n = 0;
 };
 
 // ------------------------------------------------------------------------------ MT19937 (host)
@@ -124,6 +126,13 @@ static int dev_alloc(cw_engine *e, T **out, size_t count)
     e->allocs.push_back(p);
     *out = (T *)p;
     return CW_OK;
+}
+
+static void prof_free(cw_engine *e)
+{
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    e->prof_ev.clear();
+    e->prof_cap = e->prof_n = 0;
 }
 
 static int upload_mt(cw_engine *e, const std::vector<uint32_t> &words, const std::vector<int32_t> &idx)
@@ -270,6 +279,7 @@ int cw_destroy(cw_engine *e)
     if (!e) return CW_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
+    prof_free(e);
     for (void *p : e->allocs) (void)hipFree(p);
     delete e;
     return CW_OK;
@@ -342,7 +352,9 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step: bad action dtype %d", action_dtype);
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
-    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream));
+    hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
+    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream, ev));
+    if (ev) e->prof_n++;
     e->parity ^= 1;
     return CW_OK;
 }
@@ -369,6 +381,45 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
     DeviceGuard guard(e->device);
     HIP_TRY(cwk_launch_export(&e->P, out, 1, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_profile_begin(cw_engine *e, int max_steps)
+{
+    if (!e || max_steps < 1 || max_steps > 100000) return fail(CW_ERR_INVALID, "cw_profile_begin: bad argument");
+    DeviceGuard guard(e->device);
+    prof_free(e);
+    e->prof_ev.resize((size_t)max_steps * 6);
+    for (auto &ev : e->prof_ev) HIP_TRY(hipEventCreate(&ev));
+    e->prof_cap = max_steps;
+    return CW_OK;
+}
+
+int cw_profile_end(cw_engine *e, cw_profile *out)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_profile_end: null argument");
+    DeviceGuard guard(e->device);
+    memset(out, 0, sizeof(*out));
+    const int n = e->prof_n;
+    if (n > 0) {
+        HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + 5]));
+        double acc[3] = {0, 0, 0};
+        float rmax = 0.f, rmin = 1e30f;
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[(size_t)i * 6 + 2 * k], e->prof_ev[(size_t)i * 6 + 2 * k + 1]));
+                acc[k] += ms;
+                if (k == 2) { rmax = ms > rmax ? ms : rmax; rmin = ms < rmin ? ms : rmin; }
+            }
+        out->steps = n;
+        out->ms_step_kernel = (float)(acc[0] / n);
+        out->ms_reset_kernel = (float)(acc[1] / n);
+        out->ms_render_kernel = (float)(acc[2] / n);
+        out->ms_render_kernel_max = rmax;
+        out->ms_render_kernel_min = rmin;
+    }
+    prof_free(e);
     return CW_OK;
 }
 

@@ -630,18 +630,22 @@ static inline int cw_render_grid(int jobs)
 extern "C" {
 
 hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity,
-                           int obs_mode, int auto_reset, hipStream_t st)
+                           int obs_mode, int auto_reset, hipStream_t st, hipEvent_t *ev /* 6 or null */)
 {
     const int n = P->n_envs;
+    if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        parity, obs_mode == 2 ? 1 : 0);
+    if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
     if (auto_reset)
         hipLaunchKernelGGL(cw_reset_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P, parity, 0);
+    if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)
         hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, parity, (uint8_t *)nullptr);
     else if (obs_mode == 2 && auto_reset)
         hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n) < 1024 ? cw_render_grid(n) : 1024), dim3(256), 0, st, *P, 1,
                            parity, (uint8_t *)nullptr);
+    if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
 

@@ -297,6 +297,16 @@ class CraftingWorldVecEnv:
             setattr(view, k, keep[k].ctypes.data_as(C.c_void_p))
         L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state')
 
+    def profile_begin(self, max_steps):
+        """Bracket each kernel of the following step() calls with HIP events on the launch stream."""
+        L.check(self._lib.cw_profile_begin(self._h, int(max_steps)), 'cw_profile_begin')
+
+    def profile_end(self):
+        """-> dict of average per-launch kernel durations (ms) since profile_begin."""
+        p = L.cw_profile()
+        L.check(self._lib.cw_profile_end(self._h, C.byref(p)), 'cw_profile_end')
+        return {k: getattr(p, k) for k, _ in p._fields_}
+
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         """compute_reward_equal / compute_reward_subset of ray.py:757-767 on 0/1 goal vectors
         (host convenience for HER-style relabelling; the per-step reward comes from the kernel)."""

@@ -156,6 +156,21 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream);
 int cw_get_state(cw_engine *e, cw_state_view *host);
 int cw_set_state(cw_engine *e, const cw_state_view *host);
 
+/* --- per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg) -----
+ * cw_profile_begin: from now on cw_step brackets each of its kernels with hipEventRecord on the
+ * stream it launches on (at most max_steps steps are kept).  cw_profile_end: synchronises the
+ * events, returns average durations in milliseconds and stops recording. */
+typedef struct cw_profile {
+    int32_t steps;           /* cw_step calls recorded */
+    float ms_step_kernel;    /* average per launch */
+    float ms_reset_kernel;
+    float ms_render_kernel;  /* 0 in CW_OBS_STATE */
+    float ms_render_kernel_max;
+    float ms_render_kernel_min;
+} cw_profile;
+int cw_profile_begin(cw_engine *e, int max_steps);
+int cw_profile_end(cw_engine *e, cw_profile *out);
+
 int cw_buffers(cw_engine *e, cw_buffer_table *out);
 int cw_num_envs(const cw_engine *e);
 int cw_abi_version(void);
