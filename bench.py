@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched CraftingWorld step/reset hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[2] (the config the metric is quoted on): 65 536 envs per GPU,
+21x21 grid, full-frame 4x4-pixel-cell uint8 observation every step, auto-reset, uniform random
+actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel + reset
+kernel over the ballot-compacted done list + full-frame render kernel).  Envs shard across
+ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
+are the timing barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt), with
+  roofline     -- dominant kernel cw_render_kernel vs the HBM roof, from HIP events recorded by the
+                  library on the launch stream (cw_profile_begin/end) over a second, identical
+                  K-step region (the first region, without events, gives `value`);
+  cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) on this host's cores,
+                  same workload shape, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(size, max_steps, seconds=12.0):
+    """Time the CPU oracle (port of the reference's step()/reset(), render_edit repaint included)
+    on all host cores: n envs x T steps with auto-reset, sized to ~`seconds` of wall time."""
+    from oracle import OracleBatch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    n = 64 * cores
+    keys_pos = []
+    for i in range(n):
+        st = np.random.RandomState(9000 + i).get_state()
+        keys_pos.append((st[1], st[2]))
+    batch = OracleBatch(n, rng_states=keys_pos, size=(size, size), max_steps=max_steps)
+    batch.reset()
+    rng = np.random.RandomState(1)
+    T0 = 2 * max_steps
+    acts = rng.randint(0, 6, size=(T0, n)).astype(np.int8)
+    t0 = time.perf_counter()
+    steps = batch.rollout(acts, nthreads=cores)           # calibration, also warms caches
+    dt = time.perf_counter() - t0
+    reps = max(1, int(seconds / max(dt, 1e-3)))
+    total, t0 = 0, time.perf_counter()
+    for _ in range(reps):
+        total += batch.rollout(acts, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=total / dt, unit='env-steps/s', cores=cores, kind='port',
+                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset, dirty-cell repaint like the reference), '
+                       '%.1f s on %d OpenMP threads' % (n, T0 * reps, size, size, max_steps, dt, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=600)      # >= 2*max_steps: both synchronized time-out steps are inside
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--envs-per-gpu', type=int, default=65536)
+    ap.add_argument('--size', type=int, default=21)
+    ap.add_argument('--max-steps', type=int, default=300)
+    ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)     # RCCL; used for the timing barrier/max only
+
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+
+    N, K, W = args.envs_per_gpu, args.steps, args.warmup
+    # shard: rank g owns envs [g*N, (g+1)*N) of the global batch; env e's stream is RandomState(e)
+    env = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=args.obs_mode,
+                              device=dev, seed=rank * N)
+    env.reset()
+    # synthetic actions: uniform in [0,6), pre-generated on device, one row per step (not part of the env)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    rows = min(K + W, 1024)
+    actions = torch.randint(0, 6, (rows, N), device=dev, dtype=torch.uint8, generator=gen)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def run(k, t_off):
+        for t in range(k):
+            env.step_async(actions[(t_off + t) % rows])
+
+    run(W, 0)
+    barrier()
+    t0 = time.perf_counter()
+    run(K, W)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # second, identical K-step region with the library's HIP events around each kernel
+    env.profile_begin(K)
+    barrier()
+    t1 = time.perf_counter()
+    run(K, W + K)
+    barrier()
+    elapsed_prof = time.perf_counter() - t1
+    prof = env.profile_end()
+    episodes = int(env.counters[1].item())
+
+    if rank == 0:
+        total_steps = float(N) * world * K
+        value = total_steps / elapsed
+        S = args.size
+        frame = 48 * S * S
+        if args.obs_mode == 'pixels':
+            # A_pix = 48 + S*S (grid read) + frame write; the render kernel's share is
+            # S*S + frame bytes per env, and one launch paints N envs (+2 more frames for each env reset that step)
+            # (the 2 extra frames written for envs reset on that step are NOT counted: achieved is understated there)
+            alg_bytes = float(N) * (S * S + frame)
+            dominant, ms = 'cw_render_kernel', prof['ms_render_kernel']
+        else:
+            alg_bytes = float(N) * 48.0
+            dominant, ms = 'cw_step_kernel', prof['ms_step_kernel']
+        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc) and args.obs_mode == 'pixels' and N == 65536 and S == 21:
+            try:
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            'metric': 'env-steps/sec at 65536 envs, 1/2/4/8 MI355X; bit-exact vs CPU ref',
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: %d envs/GPU, %dx%d grid, %s obs, auto-reset, uniform random '
+                                   'actions, max_steps=%d' % (N, S, S, {'pixels': 'full-frame 4x4-cell uint8 pixel',
+                                                                        'pixels_dirty': 'dirty-cell-repaint pixel',
+                                                                        'state': 'state-only'}[args.obs_mode], args.max_steps),
+                       'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
+                       'sharding': 'contiguous env ranges per rank, no data-path collective'},
+            'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
+                         'launch_ms_min_max': [prof['ms_render_kernel_min'], prof['ms_render_kernel_max']],
+                         'events': 'hipEventRecord on the launch stream around every kernel, %d launches' % prof['steps']},
+            'kernels_ms': {'step': prof['ms_step_kernel'], 'reset': prof['ms_reset_kernel'], 'render': prof['ms_render_kernel'],
+                           'ms_per_step_with_events': elapsed_prof / K * 1e3},
+            'episodes_finished': episodes,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -13,7 +14,9 @@
 #include "cw_layout.h"
 
 extern "C" {
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st, hipEvent_t *ev);
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st,
+                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
+void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
@@ -64,6 +67,8 @@ struct cw_engine {
     std::vector<CwMenuDev> menus;
     int n = 0, S = 0, ncell = 0, K = 0;
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
+    hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int prof_cap = 0, prof_n = 0;
 };
 
@@ -213,6 +218,11 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.pool_k = e->K;
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
     P.frame_bytes = 48u * (uint32_t)e->ncell;
+    {   // experiment knobs; the defaults are the measured best
+        auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
+        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
+        cwk_set_tuning(geti("CW_TUNE_RENDER_BLOCKS_PER_CU", 4), geti("CW_TUNE_LIST_BLOCKS", 256), geti("CW_TUNE_OVERLAP", 1));
+    }
 
     int rc = CW_OK;
 #define ALLOC(field, count)                                     \
@@ -257,8 +267,15 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (hipMemcpy(P.hdr, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(CW_ERR_HIP, "cw_create: header upload failed");
     }
+    if (rc == CW_OK && (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess))
+        rc = fail(CW_ERR_HIP, "cw_create: side stream / event creation failed");
     if (rc != CW_OK) {
         for (void *p : e->allocs) (void)hipFree(p);
+        if (e->side) (void)hipStreamDestroy(e->side);
+        if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+        if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         delete e;
         return rc;
     }
@@ -280,6 +297,9 @@ int cw_destroy(cw_engine *e)
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
     prof_free(e);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (void *p : e->allocs) (void)hipFree(p);
     delete e;
     return CW_OK;
@@ -353,7 +373,8 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream, ev));
+    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
+                            e->ev_fork, e->ev_join, ev));
     if (ev) e->prof_n++;
     e->parity ^= 1;
     return CW_OK;
@@ -402,7 +423,7 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
-        HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + 5]));
+        for (int k = 0; k < 6; k++) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
         double acc[3] = {0, 0, 0};
         float rmax = 0.f, rmin = 1e30f;
         for (int i = 0; i < n; i++)

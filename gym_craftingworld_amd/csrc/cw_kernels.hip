@@ -285,31 +285,42 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
 }
 
 // ------------------------------------------------------------------------------------ reset
+// One WAVEFRONT per finished env.  reset() is an inherently serial walk down the env's MT19937
+// stream (a rejection-sampled Fisher-Yates of S*S cells, then imagine_obs), so a lane-per-env
+// kernel leaves every global-memory latency of that stream on the critical path -- measured 127 us
+// per reset alone and 350 us beside the render kernel's HBM traffic.  Here the wave stages the
+// env's 624-word state in LDS with coalesced loads, regenerates it 64 words per parallel step
+// (CwMtWave::gen), and runs the serial consumer on WAVE-UNIFORM values: each raw draw is a
+// v_readlane of the chunk register, the bookkeeping compiles to scalar (SALU) code, and the 9
+// token positions live in lanes 0..8 of one VGPR.  No global access is left inside
+// the chain, so the reset costs the same whether or not the chip is busy writing frames.
+
 // Fisher-Yates of arange(ncell) (RandomState.shuffle, ray.py:610-612) tracking only the 9 tokens
 // that matter: values 0..7 = objects, 8 = agent (diag rows, ray.py:605-608).  All tokens start
-// at positions 0..8; position i > 8 holds a non-token until its own swap and is final after
-// it, so the loop keeps a 9-nibble map "which token sits at low position q" in registers and
-// writes a token's final cell once, to this lane's LDS column.  Every lane consumes exactly one
-// raw MT word per round (rejected draws just do not advance i), so the wavefront stays in
-// lockstep -- no per-lane inner rejection loops.  new_cell[k] = old_row[perm[k]] means token v
-// ends in the cell whose perm entry is v.
-__device__ __forceinline__ void shuffle_tokens(CwMt &mt, int n, uint16_t *tok_col /* [9] stride CW_WAVE */)
+// at positions 0..8; position i > 8 holds a non-token until its own swap and is final after it,
+// so a 9-nibble map "which token sits at low position q" is all the state the loop needs.
+// new_cell[k] = old_row[perm[k]] means token v ends in the cell whose perm entry is v.
+// Returns a VGPR whose lane v (0..8) holds token v's final cell.
+__device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
 {
+    const uint32_t lane = mt.lane;
     unsigned long long low = 0x876543210ull;        // nibble q = token at low position q (15 = none)
+    uint32_t v_tok = 0;
     int i = n - 1;
     while (i >= 1) {
-        const uint32_t mask = 0xFFFFFFFFu >> __clz(i);
+        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz((uint32_t)i);
         const uint32_t v = mt.next() & mask;
         if (v <= (uint32_t)i) {                      // accepted: swap(perm[i], perm[v])
             const uint32_t b = (v <= 8u) ? (uint32_t)((low >> (4u * v)) & 15ull) : 15u;
             const uint32_t a = (i <= 8) ? (uint32_t)((low >> (4u * i)) & 15ull) : 15u;
-            if (b != 15u) tok_col[b * CW_WAVE] = (uint16_t)i;   // position i is final from now on
+            if (b != 15u) v_tok = (lane == b) ? (uint32_t)i : v_tok;   // "v_writelane": position i is final now
             if (v <= 8u) low = (low & ~(15ull << (4u * v))) | ((unsigned long long)a << (4u * v));
             i--;
         }
     }
     const uint32_t t0 = (uint32_t)(low & 15ull);
-    if (t0 != 15u) tok_col[t0 * CW_WAVE] = 0;
+    if (t0 != 15u) v_tok = (lane == t0) ? 0u : v_tok;
+    return v_tok;
 }
 
 // k-th (row-major) cell not in the occupied set {present slots} (+ extra cell if extra >= 0)
@@ -353,223 +364,272 @@ __device__ __forceinline__ uint32_t count_code(const uint32_t fp[8], const uint3
 #define CW_SET_SLOT(arr, idx, val)                                         \
     _Pragma("unroll") for (int _k = 0; _k < 8; _k++) arr[_k] = (_k == (idx)) ? (val) : arr[_k];
 
-__global__ __launch_bounds__(CW_WAVE) void cw_reset_kernel(CwParams P, int parity, int all_envs)
+#define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
+
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int parity, int all_envs)
 {
-    __shared__ uint16_t s_tok[9 * CW_WAVE];
-    const int t = blockIdx.x * CW_WAVE + threadIdx.x;
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
+    const int n_waves = gridDim.x * CW_RESET_WAVES;
     const int count = all_envs ? P.n_envs : P.done_count[parity];
-    if (t >= count) return;
-    const int env = all_envs ? t : P.done_list[t];
-    const int lane = threadIdx.x;
-    uint16_t *tok_col = s_tok + lane;
+    // few, latency-critical waves sharing CUs with the render kernel's 24 store-bound waves: win arbitration
+    if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
+    for (int job = wave; job < count; job += n_waves) {
+        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.done_list[job]);
+        const uint32_t h_old_x = __builtin_amdgcn_readfirstlane(P.hdr[env].x);
+        const uint32_t h_old_z = __builtin_amdgcn_readfirstlane(P.hdr[env].z);
+        const uint32_t menu_id = h_old_x >> 24;
+        const CwMenuDev M = P.menus[menu_id];
 
-    const uint4 h_old = P.hdr[env];
-    const uint32_t menu_id = h_old.x >> 24;
-    const CwMenuDev M = P.menus[menu_id];
+        CwMtWave mt;
+        mt.load(s_mt[wave_in_block], P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
 
-    CwMt mt;
-    mt.open(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env]);
+        // task draw, ray.py:169-174
+        const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
+        unsigned long long perm = 0xFEDCBA9876543210ull;             // task_idx = arange(n_selected)
+        for (int i = M.n_selected - 1; i >= 1; i--) {                 // RandomState.shuffle
+            const uint32_t j = mt.interval((uint32_t)i);
+            const unsigned long long ni = (perm >> (4 * i)) & 15ull, nj = (perm >> (4 * j)) & 15ull;
+            perm = (perm & ~(15ull << (4 * i))) | (nj << (4 * i));
+            perm = (perm & ~(15ull << (4 * j))) | (ni << (4 * j));
+        }
+        uint32_t desired = 0;
+        for (uint32_t q = 0; q < ntasks; q++) {
+            const uint32_t idx = (uint32_t)((perm >> (4 * q)) & 15ull);
+            desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
+        }
 
-    // task draw, ray.py:169-174
-    const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
-    unsigned long long perm = 0xFEDCBA9876543210ull;             // task_idx = arange(n_selected)
-    for (int i = M.n_selected - 1; i >= 1; i--) {                 // RandomState.shuffle
-        const uint32_t j = mt.interval((uint32_t)i);
-        const unsigned long long ni = (perm >> (4 * i)) & 15ull, nj = (perm >> (4 * j)) & 15ull;
-        perm = (perm & ~(15ull << (4 * i))) | (nj << (4 * i));
-        perm = (perm & ~(15ull << (4 * j))) | (ni << (4 * j));
-    }
-    uint32_t desired = 0;
-    for (uint32_t q = 0; q < ntasks; q++) {
-        const uint32_t idx = (uint32_t)((perm >> (4 * q)) & 15ull);
-        desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
-    }
+        // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
+        uint32_t fp[8], fc[8];
+        uint32_t agent;
+        if (P.pool_k == 0) {
+            const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
+#pragma unroll
+            for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readlane(v_tok, k);
+            agent = __builtin_amdgcn_readlane(v_tok, 8);
+        } else {
+            const uint32_t pk = mt.randint((uint32_t)P.pool_k);
+            const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
+#pragma unroll
+            for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readfirstlane((uint32_t)pp[k]);
+            agent = __builtin_amdgcn_readfirstlane((uint32_t)pp[8]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) fc[k] = k + 1;
+        const uint4 init_packed = pack_pos(fp);
+        const uint32_t init_agent = agent;
 
-    // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
-    uint32_t fp[8], fc[8];
-    uint32_t agent;
-    if (P.pool_k == 0) {
-        shuffle_tokens(mt, P.ncell, tok_col);
+        // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
+        if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
+            CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
+        }
+        if (desired & (1u << T_EATBREAD)) {                           // :232-237
+            const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
+            const int sl = nth_with_code(fp, fc, BREAD, which);
+            CW_SET_SLOT(fc, sl, (uint32_t)EMPTY);
+            CW_SET_SLOT(fp, sl, CW_POS_GONE);
+        }
+        if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
+            CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
+        }
+        if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
+            uint32_t present = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) fp[k] = tok_col[k * CW_WAVE];
-        agent = tok_col[8 * CW_WAVE];
-    } else {
-        const uint32_t pk = mt.randint((uint32_t)P.pool_k);
-        const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
+            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+            const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
+            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
+            const int sl = nth_with_code(fp, fc, STICKS, which_stick);
+            const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
+            CW_SET_SLOT(fp, sl, to);
+        }
+        if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
+            const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
+            const int sl = nth_with_code(fp, fc, STICKS, which);
+            CW_SET_SLOT(fc, sl, (uint32_t)HOUSE);
+        }
+        if (desired & (1u << T_CHOPROCK)) {                           // :265-268
+            CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
+            CW_SET_SLOT(fp, 3, CW_POS_GONE);
+        }
+        if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
+            const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
+            const int sl = nth_with_code(fp, fc, HOUSE, which);
 #pragma unroll
-        for (int k = 0; k < 8; k++) fp[k] = pp[k];
-        agent = pp[8];
-    }
+            for (int k = 0; k < 8; k++) agent = (k == sl) ? fp[k] : agent;
+        }
+        if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
+            uint32_t present = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) fc[k] = k + 1;
-    const uint4 init_packed = pack_pos(fp);
-    const uint32_t init_agent = agent;
+            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+            const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+            CW_SET_SLOT(fp, 1, to);
+        }
+        if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
+            uint32_t present = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+            const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+            CW_SET_SLOT(fp, 2, to);
+        }
 
-    // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
-    if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
-        CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
-    }
-    if (desired & (1u << T_EATBREAD)) {                           // :232-237
-        const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
-        const int s = nth_with_code(fp, fc, BREAD, which);
-        CW_SET_SLOT(fc, s, (uint32_t)EMPTY);
-        CW_SET_SLOT(fp, s, CW_POS_GONE);
-    }
-    if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
-        CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
-    }
-    if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
-        uint32_t present = 0;
+        // commit: the MT state goes back coalesced, the records are written by one lane
+        mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
+        if (lane == 0) {
+            uint32_t goal_codes = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-        const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
-        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
-        const int s = nth_with_code(fp, fc, STICKS, which_stick);
-        const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
-        CW_SET_SLOT(fp, s, to);
+            for (int k = 0; k < 8; k++) goal_codes |= fc[k] << (4 * k);
+            P.goal_pos[env] = pack_pos(fp);
+            P.goal_codes[env] = goal_codes;
+            P.goal_agent[env] = (uint16_t)agent;
+            P.init_pos[env] = init_packed;
+            P.init_agent[env] = (uint16_t)init_agent;
+            P.pos[env] = init_packed;
+            const uint32_t ar = __umulhi(init_agent, P.div_magic);
+            const uint32_t ac = init_agent - ar * P.size;
+            uint4 h;
+            h.x = ar | (ac << 8) | (menu_id << 24);                       // hold = 0
+            h.y = desired << 16;                                          // achieved = 0, ray.py:176
+            h.z = (CW_FLAG_RESET | (M.reward_subset ? CW_FLAG_SUBSET : 0u)) << 16;   // step_num = 0, :203
+            h.w = CW_CODES_INITIAL;
+            P.hdr[env] = h;
+            if ((h_old_z & 0xFFFFu) != 0) P.ep_no[env] += 1;             // :200-201
+        }
     }
-    if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
-        const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
-        const int s = nth_with_code(fp, fc, STICKS, which);
-        CW_SET_SLOT(fc, s, (uint32_t)HOUSE);
-    }
-    if (desired & (1u << T_CHOPROCK)) {                           // :265-268
-        CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
-        CW_SET_SLOT(fp, 3, CW_POS_GONE);
-    }
-    if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
-        const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
-        const int s = nth_with_code(fp, fc, HOUSE, which);
-#pragma unroll
-        for (int k = 0; k < 8; k++) agent = (k == s) ? fp[k] : agent;
-    }
-    if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-        CW_SET_SLOT(fp, 1, to);
-    }
-    if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-        CW_SET_SLOT(fp, 2, to);
-    }
-
-    // commit
-    P.mt_idx[env] = mt.k;
-    uint32_t goal_codes = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) goal_codes |= fc[k] << (4 * k);
-    P.goal_pos[env] = pack_pos(fp);
-    P.goal_codes[env] = goal_codes;
-    P.goal_agent[env] = (uint16_t)agent;
-    P.init_pos[env] = init_packed;
-    P.init_agent[env] = (uint16_t)init_agent;
-    P.pos[env] = init_packed;
-    const uint32_t ar = __umulhi(init_agent, P.div_magic);
-    const uint32_t ac = init_agent - ar * P.size;
-    uint4 h;
-    h.x = ar | (ac << 8) | (menu_id << 24);                       // hold = 0
-    h.y = desired << 16;                                          // achieved = 0, ray.py:176
-    h.z = (CW_FLAG_RESET | (M.reward_subset ? CW_FLAG_SUBSET : 0u)) << 16;   // step_num = 0, :203
-    h.w = CW_CODES_INITIAL;
-    P.hdr[env] = h;
-    if ((h_old.z & 0xFFFFu) != 0) P.ep_no[env] += 1;             // :200-201
 }
 
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
-__global__ __launch_bounds__(CW_WAVE) void cw_pool_kernel(CwParams P)
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwParams P)
 {
-    __shared__ uint16_t s_tok[9 * CW_WAVE];
-    const int env = blockIdx.x * CW_WAVE + threadIdx.x;
-    if (env >= P.n_envs) return;
-    uint16_t *tok_col = s_tok + threadIdx.x;
-    CwMt mt;
-    mt.open(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env]);
-    for (int k = 0; k < P.pool_k; k++) {
-        shuffle_tokens(mt, P.ncell, tok_col);
-        uint16_t *pp = P.pool + ((size_t)env * P.pool_k + k) * 9;
-#pragma unroll
-        for (int q = 0; q < 9; q++) pp[q] = tok_col[q * CW_WAVE];
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int n_waves = gridDim.x * CW_RESET_WAVES;
+    for (int env = blockIdx.x * CW_RESET_WAVES + wave_in_block; env < P.n_envs; env += n_waves) {
+        CwMtWave mt;
+        mt.load(s_mt[wave_in_block], P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
+        for (int k = 0; k < P.pool_k; k++) {
+            const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
+            uint16_t *pp = P.pool + ((size_t)env * P.pool_k + k) * 9;
+            if (lane < 9) pp[lane] = (uint16_t)v_tok;
+        }
+        mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
     }
-    P.mt_idx[env] = mt.k;
 }
 
 // ------------------------------------------------------------------------------------ render
-// One wavefront paints one frame.  The frame is an array of 4S*S "items" of 12 bytes (one cell's
-// 4 pixels on one pixel row); item `it` sits at byte 12*it, so lane l of a wave storing item
-// base+l writes 12 B and the 64 lanes together 768 contiguous bytes per store instruction.
-// The slot positions/colours are wave-uniform (SGPRs); a cell's colour is an 8-compare chain.
+// One wavefront paints one frame, 64 cells per iteration: lane = one cell (row-major), whose colour
+// is an 8-compare chain against the wave-uniform slot positions (SGPRs), computed ONCE and stored
+// to the cell's 4 pixel rows as 4 x 12 B (global_store_dwordx3).  Lanes of one grid row are
+// contiguous in memory on every pixel row, so each store instruction writes ceil(64/S)+1 contiguous
+// runs; the 4 stores of an iteration complete each other's partial cache lines back to back.
+// Plain stores: nontemporal ones measured 25 % slower in this shape (tools/microbench).
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
-                                             int S, uint32_t div_magic, const uint32_t sp[8],
+                                             int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
                                              const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
                                              int lane)
 {
-    const uint32_t n_items = 4u * S * S;
-    for (uint32_t it = lane; it < n_items; it += CW_WAVE) {
-        const uint32_t y = __umulhi(it, div_magic);      // pixel row
-        const uint32_t c = it - y * S;                   // cell column
-        const uint32_t cell = (y >> 2) * S + c;
+    const uint32_t row_bytes = 12u * S;
+    for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
+        const uint32_t r = __umulhi(cell, div_magic);
+        const uint32_t c = cell - r * S;
         uint32_t col = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? rgb[k] : col;
-        u32x3 d = cell_row_dwords(col);
-        const uint32_t sub = y & 3u;
-        if (cell == agent_cell && (sub == 1u || sub == 2u))
-            d = overlay_dwords(d, (sub == 2u) ? hold_rgb : 0x00FFFFFFu);
-        __builtin_nontemporal_store(d, (u32x3_a4 *)(dst0 + (size_t)it * 12u));
-        if (dst1) __builtin_nontemporal_store(d, (u32x3_a4 *)(dst1 + (size_t)it * 12u));
+        const u32x3 d = cell_row_dwords(col);
+        const bool ag = (cell == agent_cell);
+        const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
+        const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
+        const size_t off = (size_t)(4u * r) * row_bytes + 12u * c;
+        uint8_t *q = dst0 + off;
+        *(u32x3_a4 *)(q) = d;
+        *(u32x3_a4 *)(q + row_bytes) = d1;
+        *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
+        *(u32x3_a4 *)(q + 3 * row_bytes) = d;
+        if (dst1) {
+            uint8_t *q1 = dst1 + off;
+            *(u32x3_a4 *)(q1) = d;
+            *(u32x3_a4 *)(q1 + row_bytes) = d1;
+            *(u32x3_a4 *)(q1 + 2 * row_bytes) = d2;
+            *(u32x3_a4 *)(q1 + 3 * row_bytes) = d;
+        }
     }
 }
 
-// mode 0: every env -> P.obs; envs flagged RESET additionally -> init_img (same pixels) and
-//         desired_img (goal state).                     (FULL pixel mode, after step+reset)
-// mode 1: envs in the done list only -> obs, init_img, desired_img   (DIRTY pixel mode)
-// mode 2: every env -> ext_out only                      (cw_render into a caller buffer)
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int parity, uint8_t *ext_out)
+// mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
+// mode 1: envs in the done list -> obs, init_img, desired_img                    (after auto-reset)
+// mode 2: every env -> ext_out only                                               (cw_render)
+// mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
+//         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
+struct CwEnvRec { uint4 h, pp; };
+
+template <int MODE>
+__device__ __forceinline__ void render_jobs(const CwParams &P, int parity, int skip_done, uint8_t *ext_out)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
-    const int n_jobs = (mode == 1) ? P.done_count[parity] : P.n_envs;
+    const int n_jobs = (MODE == 1) ? P.done_count[parity] : P.n_envs;
+    if (wave >= n_jobs) return;
+    // software pipeline: the next job's records are loaded while the current frame is stored
+    int env = __builtin_amdgcn_readfirstlane((MODE == 1) ? P.done_list[wave] : wave);
+    CwEnvRec rec{P.hdr[env], P.pos[env]};
     for (int job = wave; job < n_jobs; job += n_waves) {
-        const int env = __builtin_amdgcn_readfirstlane((mode == 1) ? P.done_list[job] : job);
-        const uint4 h = P.hdr[env];
-        const uint4 pp = P.pos[env];
+        const int cur_env = env;
+        const CwEnvRec cur = rec;
+        const int nj = job + n_waves;
+        if (nj < n_jobs) {
+            env = __builtin_amdgcn_readfirstlane((MODE == 1) ? P.done_list[nj] : nj);
+            rec.h = P.hdr[env];
+            rec.pp = P.pos[env];
+        }
+        if (MODE == 3 && skip_done && P.done[cur_env]) continue;
         uint32_t sp[8], rgb[8];
-        unpack_pos(pp, sp);
+        unpack_pos(cur.pp, sp);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             sp[k] = __builtin_amdgcn_readfirstlane(sp[k]);
-            rgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((h.w >> (4 * k)) & 15u)];
+            rgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((cur.h.w >> (4 * k)) & 15u)];
         }
-        const uint32_t hx = __builtin_amdgcn_readfirstlane(h.x);
+        const uint32_t hx = __builtin_amdgcn_readfirstlane(cur.h.x);
         const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
         const uint32_t hold = (hx >> 16) & 0xFFu;
         const uint32_t hold_rgb = hold ? CW_RGB24[hold] : 0x00FFFFFFu;
-        const bool was_reset = (mode == 1) || ((__builtin_amdgcn_readfirstlane(h.z) >> 16) & CW_FLAG_RESET);
-        const size_t off = (size_t)env * P.frame_bytes;
-        uint8_t *d0 = (mode == 2) ? ext_out + off : P.obs + off;
-        uint8_t *d1 = (mode != 2 && was_reset) ? P.init_img + off : nullptr;
-        render_frame(d0, d1, P.size, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
-        if (mode != 2 && was_reset) {                            // desired_goal = render(final_state), ray.py:299
+        constexpr bool three = (MODE == 0) || (MODE == 1);
+        const size_t off = (size_t)cur_env * P.frame_bytes;
+        uint8_t *d0 = (MODE == 2) ? ext_out + off : P.obs + off;
+        uint8_t *d1 = three ? P.init_img + off : nullptr;
+        render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
+        if (three) {                                             // desired_goal = render(final_state), ray.py:299
             uint32_t gp[8], grgb[8];
-            unpack_pos(P.goal_pos[env], gp);
-            const uint32_t gc = P.goal_codes[env];
+            unpack_pos(P.goal_pos[cur_env], gp);
+            const uint32_t gc = P.goal_codes[cur_env];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 gp[k] = __builtin_amdgcn_readfirstlane(gp[k]);
                 grgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((gc >> (4 * k)) & 15u)];
             }
-            const uint32_t ga = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[env]);
-            render_frame(P.desired_img + off, nullptr, P.size, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
+            const uint32_t ga = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[cur_env]);
+            render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
         }
     }
+}
+
+// the per-step full-frame render (mode 3) and cw_render (mode 2): the roofline kernel
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int parity, int skip_done, uint8_t *ext_out)
+{
+    if (mode == 3) render_jobs<3>(P, parity, skip_done, ext_out);
+    else render_jobs<2>(P, parity, skip_done, ext_out);
+}
+// the three frames (obs, init_obs, desired_goal) of freshly reset envs: all envs (mode 0, cw_reset)
+// or the done list (mode 1, auto-reset)
+__global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode, int parity)
+{
+    if (mode == 0) render_jobs<0>(P, parity, 0, nullptr);
+    else render_jobs<1>(P, parity, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -618,33 +678,71 @@ __global__ void cw_iota_kernel(int32_t *p, int n)
 }
 
 // ------------------------------------------------------------------------------------ launchers
+static int g_render_blocks_per_cu = 4, g_list_blocks = 256, g_overlap = 1;
+
 static inline int cw_render_grid(int jobs)
 {
-    // 4 waves per block; enough blocks to fill 256 CUs several times over, grid-stride beyond
+    // 4 waves per block, persistent grid-stride; 4 blocks per CU saturate the HBM write path
+    // (tools/microbench) and leave wave slots for the reset kernel running beside it
     int blocks = (jobs + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * g_render_blocks_per_cu) blocks = 256 * g_render_blocks_per_cu;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+static inline int cw_reset_grid(int jobs)
+{
+    // persistent: one wave per env in flight, 2 workgroups (8 waves) per CU at most
+    int blocks = (jobs + CW_RESET_WAVES - 1) / CW_RESET_WAVES;
+    if (blocks > 256 * 2) blocks = 256 * 2;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
 
 extern "C" {
 
+// tuning knobs for experiments (CW_TUNE_* environment variables, read once in cw_create)
+void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap)
+{
+    if (render_blocks_per_cu > 0) g_render_blocks_per_cu = render_blocks_per_cu;
+    if (list_blocks > 0) g_list_blocks = list_blocks;
+    g_overlap = overlap;
+}
+
+// One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
+// while the side stream resets the done envs and paints their three frames; both join back into
+// the caller's stream, so the caller sees ordinary stream order.
 hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity,
-                           int obs_mode, int auto_reset, hipStream_t st, hipEvent_t *ev /* 6 or null */)
+                           int obs_mode, int auto_reset, hipStream_t st, hipStream_t side,
+                           hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev /* 6 or null */)
 {
     const int n = P->n_envs;
+    const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        parity, obs_mode == 2 ? 1 : 0);
-    if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
-    if (auto_reset)
-        hipLaunchKernelGGL(cw_reset_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P, parity, 0);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    if (obs_mode == 1 && auto_reset && g_overlap) {
+        (void)hipEventRecord(ev_fork, st);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        if (ev) (void)hipEventRecord(ev[2], side);
+        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, parity, 0);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1, parity);
+        if (ev) (void)hipEventRecord(ev[3], side);
+        (void)hipEventRecord(ev_join, side);
+        if (ev) (void)hipEventRecord(ev[4], st);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, parity, 1, (uint8_t *)nullptr);
+        if (ev) (void)hipEventRecord(ev[5], st);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+        return hipGetLastError();
+    }
+    if (ev) (void)hipEventRecord(ev[2], st);
+    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, parity, 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
-    if (obs_mode == 1)
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, parity, (uint8_t *)nullptr);
-    else if (obs_mode == 2 && auto_reset)
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n) < 1024 ? cw_render_grid(n) : 1024), dim3(256), 0, st, *P, 1,
-                           parity, (uint8_t *)nullptr);
+    if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, parity, 0, (uint8_t *)nullptr);
+    if ((obs_mode == 2 || obs_mode == 1) && auto_reset)
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1, parity);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -652,22 +750,22 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st)
 {
     const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_reset_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P, 0, 1);
-    if (obs_mode != 0)   // every env carries the RESET flag now: mode 0 writes all three frames
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, 0, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1);
+    if (obs_mode != 0)
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, 0);
     return hipGetLastError();
 }
 
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
 {
     const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_pool_kernel, dim3((n + CW_WAVE - 1) / CW_WAVE), dim3(CW_WAVE), 0, st, *P);
+    hipLaunchKernelGGL(cw_pool_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P);
     return hipGetLastError();
 }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, out);
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, 0, out);
     return hipGetLastError();
 }
 

@@ -77,4 +77,5 @@ struct CwParams {
     int32_t pool_k;          // fixed_init_state
     uint32_t div_magic;      // floor(2^32 / S) + 1 : x / S == mulhi(x, magic) for x < 2^18
     uint32_t frame_bytes;    // 48 * S * S
+    int32_t tune_reset_prio; // 1: reset waves raise their priority (s_setprio 3)
 };

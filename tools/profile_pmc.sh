@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box only: HBM traffic of the bench's kernels from the PMC counters, collected as
+# MI355X_MICROARCH.md prescribes: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one
+# pass), no tracing domains besides --kernel-trace, plus a calibration pass on a kernel with a
+# known byte count in the same store shape (12 B per lane): tools/microbench/store_variants.
+set -e -o pipefail
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+rm -rf $OUT; mkdir -p $OUT
+for C in WRITE_SIZE FETCH_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/bench_$C -- python bench.py --no-cpu-baseline --steps 60 --warmup 5 > $OUT/bench_$C.json 2> $OUT/bench_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/calib_$C -- ./tools/microbench/store_variants > $OUT/calib_$C.txt 2> $OUT/calib_$C.err
+done
+python tools/summarize_pmc.py $OUT > $OUT/summary.json
+cat $OUT/summary.json
