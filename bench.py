@@ -91,11 +91,15 @@ def main():
         dist.init_process_group('nccl', device_id=dev)     # RCCL; used for the timing barrier/max only
 
     from gym_craftingworld_amd import CraftingWorldVecEnv
+    from gym_craftingworld_amd.sharding import max_over_ranks, shard_range
 
-    N, K, W = args.envs_per_gpu, args.steps, args.warmup
-    # shard: rank g owns envs [g*N, (g+1)*N) of the global batch; env e's stream is RandomState(e)
+    K, W = args.steps, args.warmup
+    # weak scaling: the global batch is envs_per_gpu * world envs; rank g owns the contiguous range
+    # [lo, hi) and env e's stream is numpy RandomState(e) whatever rank owns it
+    lo, hi = shard_range(rank, world, args.envs_per_gpu * world)
+    N = hi - lo
     env = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=args.obs_mode,
-                              device=dev, seed=rank * N)
+                              device=dev, seed=lo)
     env.reset()
     # synthetic actions: uniform in [0,6), pre-generated on device, one row per step (not part of the env)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -117,10 +121,7 @@ def main():
     run(K, W)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, device=dev)
 
     # second, identical K-step region with the library's HIP events around each kernel
     env.profile_begin(K)
