@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcraftingworld.so')
+LIB_PATH = os.environ.get('CW_LIB_PATH') or os.path.join(_HERE, 'libcraftingworld.so')   # CW_LIB_PATH: experiment builds
 
 CW_ABI_VERSION = 1
 CW_MT_N = 624

@@ -564,57 +564,110 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
 // mode 2: every env -> ext_out only                                               (cw_render)
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
 //         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
-struct CwEnvRec { uint4 h, pp; };
+// Per-env records are wave-uniform, so they are fetched with SCALAR loads (s_load_dwordx4 through
+// the constant cache, lgkmcnt domain; cload below).  This matters: a vector load in the frame loop
+// makes hipcc wait vmcnt(0) before the next frame -- loads and stores retire in one in-order counter
+// -- which drains all 28 outstanding frame stores of the wave once per frame (measured 0.320 ms vs
+// 0.274 ms per launch).  With scalar loads the wave never waits on its stores.  The records of the
+// next CW_REC_AHEAD frames are requested before the current frame is stored: they were written by the
+// step kernel a moment ago, so they miss to HBM under the render's own write storm.
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 
+template <typename T>
+__device__ __forceinline__ T cload(const T *p)
+{
+    return *(const __attribute__((address_space(4))) T *)(p);
+}
+
+struct CwEnvRec {
+    u32x4s h, pp;
+    uint32_t done_word;
+    int env;
+};
+template <int MODE>
+__device__ __forceinline__ CwEnvRec rec_load(const CwParams &P, int job, int n_jobs, bool want_done)
+{
+    CwEnvRec r;
+    r.env = -1;
+    if (job < n_jobs) {
+        const int env = (MODE == 1) ? cload(P.done_list + job) : job;
+        r.env = env;
+        r.h = cload((const u32x4s *)(P.hdr + env));
+        r.pp = cload((const u32x4s *)(P.pos + env));
+        r.done_word = want_done ? cload((const uint32_t *)(P.done + (env & ~3))) : 0u;
+    }
+    return r;
+}
+__device__ __forceinline__ void unpack_pos_s(const u32x4s &v, uint32_t sp[8])
+{
+    sp[0] = v.x & 0xFFFFu; sp[1] = v.x >> 16;
+    sp[2] = v.y & 0xFFFFu; sp[3] = v.y >> 16;
+    sp[4] = v.z & 0xFFFFu; sp[5] = v.z >> 16;
+    sp[6] = v.w & 0xFFFFu; sp[7] = v.w >> 16;
+}
+
+#ifndef CW_REC_AHEAD
+#define CW_REC_AHEAD 1   // deeper look-ahead (2, 4) measured no better in-step: profiles/r01_render_sweeps.txt
+#endif
+
+template <int MODE>
+__device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cur, bool want_done, uint8_t *ext_out, int lane)
+{
+    if (cur.env < 0) return;
+    const int cur_env = cur.env;
+    if (want_done && ((cur.done_word >> (8 * (cur_env & 3))) & 0xFFu)) return;
+    uint32_t sp[8], rgb[8];
+    unpack_pos_s(cur.pp, sp);
+#pragma unroll
+    for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((cur.h.w >> (4 * k)) & 15u);   // SALU select chains
+    const uint32_t hx = cur.h.x;
+    const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
+    const uint32_t hold = (hx >> 16) & 0xFFu;
+    const uint32_t hold_rgb = hold ? rgb_of_code(hold) : 0x00FFFFFFu;
+    constexpr bool three = (MODE == 0) || (MODE == 1);
+    const size_t off = (size_t)cur_env * P.frame_bytes;
+    uint8_t *d0 = (MODE == 2) ? ext_out + off : P.obs + off;
+    uint8_t *d1 = three ? P.init_img + off : nullptr;
+    render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
+    if (three) {                                             // desired_goal = render(final_state), ray.py:299
+        uint32_t gp[8], grgb[8];
+        const u32x4s gpp = cload((const u32x4s *)(P.goal_pos + cur_env));
+        unpack_pos_s(gpp, gp);
+        const uint32_t gc = cload(P.goal_codes + cur_env);
+        const uint32_t gaw = cload((const uint32_t *)((const uint8_t *)P.goal_agent + ((2 * cur_env) & ~3)));
+        const uint32_t ga = (gaw >> (16 * (cur_env & 1))) & 0xFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) grgb[k] = rgb_of_code((gc >> (4 * k)) & 15u);
+        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
+    }
+}
+
+// mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
+// mode 1: envs in the done list -> obs, init_img, desired_img                    (after auto-reset)
+// mode 2: every env -> ext_out only                                               (cw_render)
+// mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
+//         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
 template <int MODE>
 __device__ __forceinline__ void render_jobs(const CwParams &P, int parity, int skip_done, uint8_t *ext_out)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
-    const int n_jobs = (MODE == 1) ? P.done_count[parity] : P.n_envs;
+    const int n_jobs = (MODE == 1) ? cload(P.done_count + parity) : P.n_envs;
     if (wave >= n_jobs) return;
-    // software pipeline: the next job's records are loaded while the current frame is stored
-    int env = __builtin_amdgcn_readfirstlane((MODE == 1) ? P.done_list[wave] : wave);
-    CwEnvRec rec{P.hdr[env], P.pos[env]};
-    for (int job = wave; job < n_jobs; job += n_waves) {
-        const int cur_env = env;
-        const CwEnvRec cur = rec;
-        const int nj = job + n_waves;
-        if (nj < n_jobs) {
-            env = __builtin_amdgcn_readfirstlane((MODE == 1) ? P.done_list[nj] : nj);
-            rec.h = P.hdr[env];
-            rec.pp = P.pos[env];
-        }
-        if (MODE == 3 && skip_done && P.done[cur_env]) continue;
-        uint32_t sp[8], rgb[8];
-        unpack_pos(cur.pp, sp);
+    const bool want_done = (MODE == 3) && skip_done;
+    // software pipeline on the scalar unit, CW_REC_AHEAD frames deep
+    CwEnvRec cur[CW_REC_AHEAD], nxt[CW_REC_AHEAD];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            sp[k] = __builtin_amdgcn_readfirstlane(sp[k]);
-            rgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((cur.h.w >> (4 * k)) & 15u)];
-        }
-        const uint32_t hx = __builtin_amdgcn_readfirstlane(cur.h.x);
-        const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
-        const uint32_t hold = (hx >> 16) & 0xFFu;
-        const uint32_t hold_rgb = hold ? CW_RGB24[hold] : 0x00FFFFFFu;
-        constexpr bool three = (MODE == 0) || (MODE == 1);
-        const size_t off = (size_t)cur_env * P.frame_bytes;
-        uint8_t *d0 = (MODE == 2) ? ext_out + off : P.obs + off;
-        uint8_t *d1 = three ? P.init_img + off : nullptr;
-        render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
-        if (three) {                                             // desired_goal = render(final_state), ray.py:299
-            uint32_t gp[8], grgb[8];
-            unpack_pos(P.goal_pos[cur_env], gp);
-            const uint32_t gc = P.goal_codes[cur_env];
+    for (int k = 0; k < CW_REC_AHEAD; k++) nxt[k] = rec_load<MODE>(P, wave + k * n_waves, n_jobs, want_done);
+    for (int base = wave; base < n_jobs; base += CW_REC_AHEAD * n_waves) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                gp[k] = __builtin_amdgcn_readfirstlane(gp[k]);
-                grgb[k] = CW_RGB24[__builtin_amdgcn_readfirstlane((gc >> (4 * k)) & 15u)];
-            }
-            const uint32_t ga = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[cur_env]);
-            render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
-        }
+        for (int k = 0; k < CW_REC_AHEAD; k++) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k < CW_REC_AHEAD; k++)
+            nxt[k] = rec_load<MODE>(P, base + (CW_REC_AHEAD + k) * n_waves, n_jobs, want_done);
+#pragma unroll
+        for (int k = 0; k < CW_REC_AHEAD; k++) render_one<MODE>(P, cur[k], want_done, ext_out, lane);
     }
 }
 
@@ -678,14 +731,17 @@ __global__ void cw_iota_kernel(int32_t *p, int n)
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static int g_render_blocks_per_cu = 4, g_list_blocks = 256, g_overlap = 1;
+static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0;
 
 static inline int cw_render_grid(int jobs)
 {
-    // 4 waves per block, persistent grid-stride; 4 blocks per CU saturate the HBM write path
-    // (tools/microbench) and leave wave slots for the reset kernel running beside it
+    // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
+    // write path saturates with few store streams and gets slower with more of them in flight
+    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/r01_render_sweeps.txt); it also
+    // leaves the wave slots for the reset kernel running beside it
     int blocks = (jobs + 3) / 4;
     if (blocks > 256 * g_render_blocks_per_cu) blocks = 256 * g_render_blocks_per_cu;
+    if (g_render_blocks_abs > 0 && blocks > g_render_blocks_abs) blocks = g_render_blocks_abs;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -702,8 +758,9 @@ static inline int cw_reset_grid(int jobs)
 extern "C" {
 
 // tuning knobs for experiments (CW_TUNE_* environment variables, read once in cw_create)
-void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap)
+void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs)
 {
+    g_render_blocks_abs = render_blocks_abs;
     if (render_blocks_per_cu > 0) g_render_blocks_per_cu = render_blocks_per_cu;
     if (list_blocks > 0) g_list_blocks = list_blocks;
     g_overlap = overlap;
