@@ -307,6 +307,44 @@ __device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
     unsigned long long low = 0x876543210ull;        // nibble q = token at low position q (15 = none)
     uint32_t v_tok = 0;
     int i = n - 1;
+
+    // ---- lane-parallel phase, 64 raw draws per pass, while every i in the pass stays > 8.
+    // Draw l of a chunk is accepted iff (d_l & mask(i_l)) <= i_l with i_l = i - #accepted before l:
+    // a prefix dependency that is resolved by iterating from "everything accepted" to the fixed point
+    // (lane 0 is exact after one pass, and a draw's fate only flips if its value sits within a few
+    // counts of i_l, so two or three passes settle all 64).  The sequential semantics are reproduced
+    // exactly; only the rare accepted draws that hit a low position (v <= 8, a token) are then
+    // replayed in lane order on the scalar unit.
+    while (i >= 72) {
+        if (mt.used == 64) mt.gen();
+        const uint32_t d = mt.v_out;
+        const bool valid = (int)lane >= mt.used;     // earlier lanes of this chunk were consumed before
+        unsigned long long acc = __ballot(valid);
+        uint32_t i_l = 0, v_l = 0;
+        for (int pass = 0; pass < 66; pass++) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)acc, 0u));
+            i_l = (uint32_t)i - before;
+            v_l = d & (0xFFFFFFFFu >> __builtin_clz(i_l));
+            const unsigned long long acc2 = __ballot(valid && v_l <= i_l);
+            if (acc2 == acc) break;
+            acc = acc2;
+        }
+        unsigned long long ev = __ballot(valid && v_l <= i_l && v_l <= 8u);
+        while (ev) {                                 // token events, in draw order
+            const int l = __builtin_ctzll(ev);
+            ev &= ev - 1;
+            const uint32_t vv = __builtin_amdgcn_readlane(v_l, l);
+            const uint32_t il = __builtin_amdgcn_readlane(i_l, l);
+            const uint32_t b = (uint32_t)((low >> (4u * vv)) & 15ull);
+            if (b != 15u) v_tok = (lane == b) ? il : v_tok;          // token b is final at position il (> 8)
+            low |= 15ull << (4u * vv);                               // the non-token from il lands on vv
+        }
+        i -= __popcll(acc);
+        mt.used = 64;
+    }
+
+    // ---- serial tail (and everything when the grid is tiny)
     while (i >= 1) {
         const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz((uint32_t)i);
         const uint32_t v = mt.next() & mask;
