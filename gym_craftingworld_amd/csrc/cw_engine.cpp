@@ -14,7 +14,7 @@
 #include "cw_layout.h"
 
 extern "C" {
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity, int obs_mode, int auto_reset, hipStream_t st,
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
@@ -59,7 +59,6 @@ struct DeviceGuard {
 struct cw_engine {
     int device = 0;
     int obs_mode = 0;
-    int parity = 0;
     int auto_reset = 1;
     bool has_reset = false;
     CwParams P{};
@@ -169,6 +168,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         return fail(CW_ERR_INVALID, "cw_create: fixed_init_state must be in 0..64");
     if (cfg->obs_mode < CW_OBS_STATE || cfg->obs_mode > CW_OBS_PIXELS_DIRTY) return fail(CW_ERR_INVALID, "cw_create: bad obs_mode");
     if (cfg->n_menus < 1 || cfg->n_menus > CW_MAX_MENUS || !cfg->menus) return fail(CW_ERR_INVALID, "cw_create: n_menus must be in 1..%d", CW_MAX_MENUS);
+    if ((double)cfg->num_envs * 48.0 * cfg->size * cfg->size > 1.0e12)
+        return fail(CW_ERR_INVALID, "cw_create: num_envs x frame size exceeds 1 TB");
 
     std::vector<CwMenuDev> menus(cfg->n_menus);
     for (int m = 0; m < cfg->n_menus; m++) {
@@ -374,10 +375,9 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->parity, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
+    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
                             e->ev_fork, e->ev_join, ev));
     if (ev) e->prof_n++;
-    e->parity ^= 1;
     return CW_OK;
 }
 

@@ -3,10 +3,12 @@
 //   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward,
 //                     done, wave-ballot compaction of the done list; in DIRTY pixel mode also
 //                     render_edit() (ray.py:522-557) of the <=2 changed cells.
-//   cw_reset_kernel   one lane per finished env: reset() of ray.py:156-218 = task draw, legacy
-//                     Fisher-Yates placement on the env's MT19937 stream, imagine_obs().
-//   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520, 12 B per lane per
-//                     store so that each wave store instruction covers 768 contiguous bytes.
+//   cw_reset_kernel   one WAVEFRONT per finished env: reset() of ray.py:156-218 = task draw, legacy
+//                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS,
+//                     lane-parallel rejection sampling), imagine_obs().
+//   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520; a lane paints one cell's
+//                     4 pixel rows with 4 x 12-byte stores; records arrive by scalar loads.
+//   cw_render_reset_kernel  the three frames (obs, init_obs, desired_goal) of freshly reset envs.
 //   cw_export_*       dense grid / one-hot views of the slot state.
 //
 // All integer; no MFMA (nothing here is a contraction: the reference's tensordot with a one-hot
@@ -24,19 +26,6 @@ enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6
 // TASK_LIST bit order, ray.py:40-41
 enum { T_MAKEBREAD = 0, T_EATBREAD = 1, T_BUILDHOUSE = 2, T_CHOPTREE = 3, T_CHOPROCK = 4,
        T_GOTOHOUSE = 5, T_MOVEAXE = 6, T_MOVEHAMMER = 7, T_MOVESTICKS = 8 };
-
-// COLORS_N (ray.py:28-30) as R | G<<8 | B<<16, index = cell code
-__constant__ uint32_t CW_RGB24[9] = {
-    0x000000u,
-    110u | (69u << 8) | (39u << 16),    // sticks
-    255u | (105u << 8) | (180u << 16),  // axe
-    100u | (100u << 8) | (200u << 16),  // hammer
-    100u | (100u << 8) | (100u << 16),  // rock
-    0u | (128u << 8) | (0u << 16),      // tree
-    205u | (133u << 8) | (63u << 16),   // bread
-    197u | (91u << 8) | (97u << 16),    // house
-    240u | (230u << 8) | (140u << 16),  // wheat
-};
 
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
@@ -66,7 +55,8 @@ __device__ __forceinline__ uint32_t code_of(uint32_t codes, int idx)
 }
 __device__ __forceinline__ uint32_t rgb_of_code(uint32_t code)
 {
-    // 9-entry table as a select chain (per-lane index; avoids a divergent constant-memory load)
+    // COLORS_N (ray.py:28-30) as R | G<<8 | B<<16, index = cell code: a select chain, VALU for a
+    // per-lane code and SALU (s_cmp/s_cselect) for a wave-uniform one
     uint32_t c = 0;
     c = code == 1 ? (110u | (69u << 8) | (39u << 16)) : c;
     c = code == 2 ? (255u | (105u << 8) | (180u << 16)) : c;
@@ -120,11 +110,10 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
 
 // ------------------------------------------------------------------------------------ step
 __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype,
-                                                      int parity, int paint_dirty)
+                                                      int compact, int paint_dirty)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
-        P.done_count[parity ^ 1] = 0;   // the other parity's counter is idle during this step
         atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
     }
     const bool live = i < P.n_envs;
@@ -270,16 +259,31 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         int base = 0;
         if (lane == 0) {
             if (m_done) {
-                base = atomicAdd(&P.done_count[parity], __popcll(m_done));
+                if (compact) base = atomicAdd(&P.done_count[0], __popcll(m_done));
                 atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
             }
             if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
             if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
         }
         base = __shfl(base, 0);
-        if (done) {
+        if (done && compact) {
             const unsigned long long below = m_done & ((1ull << lane) - 1ull);
             P.done_list[base + __popcll(below)] = i;
+        }
+    }
+}
+
+// The done counter is zeroed for the next step by the LAST workgroup of the last kernel that reads
+// it (a ticket in done_count[1]) -- no host-side parity and no memset node, so one cw_step is a
+// fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is.
+__device__ __forceinline__ void release_done_list(const CwParams &P)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(&P.done_count[1], 1);
+        if (t == (int)gridDim.x - 1) {
+            P.done_count[0] = 0;
+            P.done_count[1] = 0;
         }
     }
 }
@@ -308,17 +312,19 @@ __device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
     uint32_t v_tok = 0;
     int i = n - 1;
 
-    // ---- lane-parallel phase, 64 raw draws per pass, while every i in the pass stays > 8.
+    // ---- lane-parallel phase: up to 64 raw draws per round, as long as every i stays > 8.
     // Draw l of a chunk is accepted iff (d_l & mask(i_l)) <= i_l with i_l = i - #accepted before l:
     // a prefix dependency that is resolved by iterating from "everything accepted" to the fixed point
     // (lane 0 is exact after one pass, and a draw's fate only flips if its value sits within a few
     // counts of i_l, so two or three passes settle all 64).  The sequential semantics are reproduced
     // exactly; only the rare accepted draws that hit a low position (v <= 8, a token) are then
-    // replayed in lane order on the scalar unit.
-    while (i >= 72) {
+    // replayed in lane order on the scalar unit.  A round takes at most i-8 draws, so even if all of
+    // them are accepted no i_l drops to 8; what is left of the chunk stays for the next round.
+    while (i >= 10) {
         if (mt.used == 64) mt.gen();
+        const int take = min(64 - mt.used, i - 8);
         const uint32_t d = mt.v_out;
-        const bool valid = (int)lane >= mt.used;     // earlier lanes of this chunk were consumed before
+        const bool valid = (int)lane >= mt.used && (int)lane < mt.used + take;
         unsigned long long acc = __ballot(valid);
         uint32_t i_l = 0, v_l = 0;
         for (int pass = 0; pass < 66; pass++) {
@@ -341,10 +347,10 @@ __device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
             low |= 15ull << (4u * vv);                               // the non-token from il lands on vv
         }
         i -= __popcll(acc);
-        mt.used = 64;
+        mt.used += take;
     }
 
-    // ---- serial tail (and everything when the grid is tiny)
+    // ---- serial tail: the last <= 9 positions, where both ends of a swap can hold tokens
     while (i >= 1) {
         const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz((uint32_t)i);
         const uint32_t v = mt.next() & mask;
@@ -404,14 +410,14 @@ __device__ __forceinline__ uint32_t count_code(const uint32_t fp[8], const uint3
 
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
 
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int parity, int all_envs)
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
-    const int count = all_envs ? P.n_envs : P.done_count[parity];
+    const int count = all_envs ? P.n_envs : P.done_count[0];
     // few, latency-critical waves sharing CUs with the render kernel's 24 store-bound waves: win arbitration
     if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
     for (int job = wave; job < count; job += n_waves) {
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
             if ((h_old_z & 0xFFFFu) != 0) P.ep_no[env] += 1;             // :200-201
         }
     }
+    if (!all_envs && last_reader) release_done_list(P);
 }
 
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
@@ -686,13 +693,13 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
 //         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
 template <int MODE>
-__device__ __forceinline__ void render_jobs(const CwParams &P, int parity, int skip_done, uint8_t *ext_out)
+__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
-    const int n_jobs = (MODE == 1) ? cload(P.done_count + parity) : P.n_envs;
-    if (wave >= n_jobs) return;
+    const int n_jobs = (MODE == 1) ? cload(P.done_count) : P.n_envs;
+    if (wave >= n_jobs) return;   // (wave-uniform; the caller's release_done_list barrier comes after the call)
     const bool want_done = (MODE == 3) && skip_done;
     // software pipeline on the scalar unit, CW_REC_AHEAD frames deep
     CwEnvRec cur[CW_REC_AHEAD], nxt[CW_REC_AHEAD];
@@ -710,17 +717,21 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int parity, int s
 }
 
 // the per-step full-frame render (mode 3) and cw_render (mode 2): the roofline kernel
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int parity, int skip_done, uint8_t *ext_out)
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out)
 {
-    if (mode == 3) render_jobs<3>(P, parity, skip_done, ext_out);
-    else render_jobs<2>(P, parity, skip_done, ext_out);
+    if (mode == 3) render_jobs<3>(P, skip_done, ext_out);
+    else render_jobs<2>(P, skip_done, ext_out);
 }
 // the three frames (obs, init_obs, desired_goal) of freshly reset envs: all envs (mode 0, cw_reset)
 // or the done list (mode 1, auto-reset)
-__global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode, int parity)
+__global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
 {
-    if (mode == 0) render_jobs<0>(P, parity, 0, nullptr);
-    else render_jobs<1>(P, parity, 0, nullptr);
+    if (mode == 0) {
+        render_jobs<0>(P, 0, nullptr);
+    } else {
+        render_jobs<1>(P, 0, nullptr);
+        release_done_list(P);            // this launch is the done list's last reader
+    }
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -762,12 +773,6 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
     }
 }
 
-__global__ void cw_iota_kernel(int32_t *p, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
-}
-
 // ------------------------------------------------------------------------------------ launchers
 static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0;
 
@@ -807,37 +812,38 @@ void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int 
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
 // while the side stream resets the done envs and paints their three frames; both join back into
 // the caller's stream, so the caller sees ordinary stream order.
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int parity,
-                           int obs_mode, int auto_reset, hipStream_t st, hipStream_t side,
-                           hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev /* 6 or null */)
+hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset,
+                           hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                           hipEvent_t *ev /* 6 or null */)
 {
     const int n = P->n_envs;
     const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
+    const bool pixels = obs_mode != 0;   // pixel modes: the list render is the done list's last reader
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
-                       parity, obs_mode == 2 ? 1 : 0);
+                       auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev) (void)hipEventRecord(ev[1], st);
     if (obs_mode == 1 && auto_reset && g_overlap) {
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         if (ev) (void)hipEventRecord(ev[2], side);
-        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, parity, 0);
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1, parity);
+        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 0, 0);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1);
         if (ev) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, parity, 1, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, 1, (uint8_t *)nullptr);
         if (ev) (void)hipEventRecord(ev[5], st);
         (void)hipStreamWaitEvent(st, ev_join, 0);
         return hipGetLastError();
     }
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, parity, 0);
+    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, pixels ? 0 : 1, 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, parity, 0, (uint8_t *)nullptr);
-    if ((obs_mode == 2 || obs_mode == 1) && auto_reset)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1, parity);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, 0, (uint8_t *)nullptr);
+    if (pixels && auto_reset)
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -847,7 +853,7 @@ hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st)
     const int n = P->n_envs;
     hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1);
     if (obs_mode != 0)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0, 0);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0);
     return hipGetLastError();
 }
 
@@ -860,7 +866,7 @@ hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
 
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, 0, out);
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, out);
     return hipGetLastError();
 }
 

@@ -390,3 +390,46 @@ def test_single_env_facade_matches_golden():
     assert o['observation'].shape == (6, 6, 12) and o['observation'][:, :, 8].sum() == 1
     assert o['desired_goal'][:, :, 8].sum() == 1
     oh.close()
+
+
+@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty', 'state'])
+def test_step_captured_in_hip_graph(obs_mode):
+    """One cw_step is a fixed launch sequence (no host-side state in kernel arguments, fork/join of
+    the side stream included), so it can be captured into a HIP graph and replayed: the replayed
+    env must stay bit-identical to an eagerly stepped twin."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, T, kw = 2048, 90, dict(size=(7, 7), max_steps=25)
+    keys, pos = _np_states(N, 99)
+    envs = []
+    for _ in range(2):
+        e = CraftingWorldVecEnv(N, obs_mode=obs_mode, **kw)
+        e.set_rng_states(keys, pos)
+        e.reset()
+        envs.append(e)
+    eager, graphed = envs
+    acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.int32, generator=torch.Generator(device='cuda').manual_seed(4))
+    static_a = torch.zeros(N, dtype=torch.int32, device='cuda')
+    # step 0 eagerly on a side stream (torch's capture warm-up protocol), then capture one step
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        static_a.copy_(acts[0])
+        graphed.step_async(static_a)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_async(static_a)
+    # the capture itself did not execute: replay from step 1 on
+    eager.step(acts[0])
+    for t in range(1, T):
+        static_a.copy_(acts[t])
+        g.replay()
+        o, r, d, _ = eager.step(acts[t])
+        assert torch.equal(r, graphed.reward) and torch.equal(d, graphed.done), t
+    assert torch.equal(eager.hdr, graphed.hdr) and torch.equal(eager.slot_pos, graphed.slot_pos)
+    if obs_mode != 'state':
+        for k in ('observation', 'desired_goal', 'init_observation'):
+            assert torch.equal(eager._observation()[k], graphed._observation()[k]), k
+    assert int(eager.counters[1].item()) == int(graphed.counters[1].item()) > 0
+    for e in envs:
+        e.close()
