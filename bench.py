@@ -72,6 +72,8 @@ def main():
     ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--graph-steps', type=int, default=0,
+                    help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
     args = ap.parse_args()
 
     import torch
@@ -111,7 +113,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    G = args.graph_steps
+    graph = None
+    if G > 0:
+        if K % G or W % G or rows % G:
+            raise SystemExit('--graph-steps must divide --steps, --warmup and the action-row pool')
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                    # torch's capture warm-up protocol
+            for t in range(G):
+                env.step_async(actions[t])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):                    # G steps, each reading its own action row
+            for t in range(G):
+                env.step_async(actions[t])
+
     def run(k, t_off):
+        if graph is not None:
+            for _ in range(k // G):
+                graph.replay()
+            return
         for t in range(k):
             env.step_async(actions[(t_off + t) % rows])
 
@@ -123,7 +145,9 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device=dev)
 
-    # second, identical K-step region with the library's HIP events around each kernel
+    # second, identical K-step region with the library's HIP events around each kernel (eager launches:
+    # events cannot be re-recorded from inside a replayed graph)
+    graph = None
     env.profile_begin(K)
     barrier()
     t1 = time.perf_counter()
@@ -165,7 +189,8 @@ def main():
                                                                         'pixels_dirty': 'dirty-cell-repaint pixel',
                                                                         'state': 'state-only'}[args.obs_mode], args.max_steps),
                        'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
-                       'sharding': 'contiguous env ranges per rank, no data-path collective'},
+                       'sharding': 'contiguous env ranges per rank, no data-path collective',
+                       'launch': 'eager' if G == 0 else 'hip graph of %d steps' % G},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
