@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Live differential test (build container only): the REFERENCE itself vs the C oracle, step by
+step, on many seeds and configs -- a wider net than the committed fixtures.  Compares reward, done,
+achieved/desired vectors, one-hot state, observation / desired_goal / init_observation images and
+the MT19937 state after every reset.  Prints a summary; exits non-zero on the first mismatch.
+
+    python tools/diff_vs_reference.py [n_seeds]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from refharness import bits, codes_from_onehot, import_reference, make_ref_env, scripted_action  # noqa: E402
+from oracle import OracleEnv  # noqa: E402
+
+T = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe', 'MoveHammer', 'MoveSticks']
+CONFIGS = [
+    (dict(size=(21, 21)), 400),
+    (dict(size=(5, 5), max_steps=40), 600),
+    (dict(size=(8, 8), max_steps=60, reward_style='subset'), 500),
+    (dict(size=(6, 6), max_steps=30, stacking=False, selected_tasks=T[::-1]), 400),
+    (dict(size=(7, 7), max_steps=35, fixed_init_state=5, number_of_tasks=3), 400),
+    (dict(size=(4, 4), max_steps=20, selected_tasks=['MoveSticks', 'BuildHouse', 'GoToHouse', 'ChopTree', 'ChopRock']), 400),
+    (dict(size=(32, 32), max_steps=80), 200),
+    (dict(size=(12, 12), max_steps=100, reward_style='subset', selected_tasks=['EatBread', 'MakeBread'], number_of_tasks=1), 300),
+]
+
+
+def compare(env, ora, tag):
+    codes, agent, hold = codes_from_onehot(env.obs_one_hot)
+    s = ora.state()
+    assert np.array_equal(codes, s['grid']), (tag, 'grid')
+    assert agent == s['agent'] and hold == s['hold'], (tag, 'agent/hold')
+    assert bits(env.achieved_goal_vector) == s['achieved'] and bits(env.desired_goal_vector) == s['desired'], (tag, 'goals')
+    assert np.array_equal(env.obs_image.astype(np.uint8), s['obs']), (tag, 'obs image')
+    assert env.step_num == s['step_num'] and env.ep_no == s['ep_no'], (tag, 'counters')
+
+
+def main(n_seeds):
+    cls = import_reference()['ray']
+    total_steps = total_resets = successes = 0
+    t0 = time.time()
+    for ci, (kw, steps) in enumerate(CONFIGS):
+        for seed in range(n_seeds):
+            rng = np.random.RandomState(10_000 * ci + seed)
+            st = rng.get_state()
+            env = make_ref_env(cls, rng, **kw)
+            ora = OracleEnv(rng_state=(st[1].copy(), int(st[2])), **kw)
+            pol = np.random.RandomState(seed)
+
+            def do_reset():
+                o = env.reset()
+                oo = ora.reset()
+                s = ora.state()
+                assert np.array_equal(o['desired_goal'].astype(np.uint8), oo['desired_goal']), (ci, seed, 'desired_goal image')
+                assert np.array_equal(o['init_observation'].astype(np.uint8), oo['init_observation'])
+                icodes, iagent, _ = codes_from_onehot(env.INIT_OBS_VECTOR)
+                assert np.array_equal(icodes, s['init_grid'])
+                k, p = ora.get_rng()
+                rs = env.np_random.get_state()
+                assert p == rs[2] and np.array_equal(k, rs[1]), (ci, seed, 'rng state')
+                compare(env, ora, (ci, seed, 'reset'))
+
+            do_reset()
+            total_resets += 1
+            for t in range(steps):
+                a = int(pol.randint(6)) if (seed % 2 == 0 or pol.rand() < 0.2) else scripted_action(env, pol)
+                _, r, d, info = env.step(a)
+                _, r2, d2, info2 = ora.step(a)
+                assert (r, d) == (r2, d2), (ci, seed, t, 'reward/done', r, r2, d, d2)
+                compare(env, ora, (ci, seed, t))
+                successes += int(r == env.MAX_STEPS)
+                total_steps += 1
+                if d:
+                    do_reset()
+                    total_resets += 1
+    print('reference == oracle on %d steps, %d resets, %d successful episodes, %d configs x %d seeds (%.1f s)' % (
+        total_steps, total_resets, successes, len(CONFIGS), n_seeds, time.time() - t0))
+
+
+if __name__ == '__main__':
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 12)
