@@ -28,12 +28,13 @@ class cw_task_menu(C.Structure):
 class cw_config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('size', C.c_int32),
                 ('max_steps', C.c_int32), ('n_task_list', C.c_int32), ('fixed_init_state', C.c_int32),
-                ('obs_mode', C.c_int32), ('auto_reset', C.c_int32), ('n_menus', C.c_int32),
+                ('obs_mode', C.c_int32), ('auto_reset', C.c_int32), ('keep_terminal_obs', C.c_int32),
+                ('n_menus', C.c_int32),
                 ('menus', C.POINTER(cw_task_menu)), ('env_menu', C.POINTER(C.c_uint8))]
 
 
 class cw_buffer_table(C.Structure):
-    _fields_ = [('obs', C.c_void_p), ('desired_goal', C.c_void_p), ('init_obs', C.c_void_p),
+    _fields_ = [('obs', C.c_void_p), ('desired_goal', C.c_void_p), ('init_obs', C.c_void_p), ('terminal_obs', C.c_void_p),
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('achieved', C.c_void_p),
                 ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('hdr', C.c_void_p),
                 ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t)]

@@ -252,6 +252,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         ALLOC(obs, N * P.frame_bytes);
         ALLOC(desired_img, N * P.frame_bytes);
         ALLOC(init_img, N * P.frame_bytes);
+        if (cfg->keep_terminal_obs && cfg->auto_reset) ALLOC(terminal_img, N * P.frame_bytes);
     }
 #undef ALLOC
     CwMenuDev *dmenus = nullptr;
@@ -452,6 +453,7 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out)
     out->obs = P.obs;
     out->desired_goal = P.desired_img;
     out->init_obs = P.init_img;
+    out->terminal_obs = P.terminal_img;
     out->reward = P.reward;
     out->done = P.done;
     out->achieved = P.achieved_out;

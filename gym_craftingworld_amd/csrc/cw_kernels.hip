@@ -635,7 +635,7 @@ __device__ __forceinline__ CwEnvRec rec_load(const CwParams &P, int job, int n_j
     CwEnvRec r;
     r.env = -1;
     if (job < n_jobs) {
-        const int env = (MODE == 1) ? cload(P.done_list + job) : job;
+        const int env = (MODE == 1 || MODE == 4) ? cload(P.done_list + job) : job;
         r.env = env;
         r.h = cload((const u32x4s *)(P.hdr + env));
         r.pp = cload((const u32x4s *)(P.pos + env));
@@ -671,7 +671,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     const uint32_t hold_rgb = hold ? rgb_of_code(hold) : 0x00FFFFFFu;
     constexpr bool three = (MODE == 0) || (MODE == 1);
     const size_t off = (size_t)cur_env * P.frame_bytes;
-    uint8_t *d0 = (MODE == 2) ? ext_out + off : P.obs + off;
+    uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
     render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
     if (three) {                                             // desired_goal = render(final_state), ray.py:299
@@ -692,13 +692,14 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // mode 2: every env -> ext_out only                                               (cw_render)
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
 //         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
+// mode 4: envs in the done list, BEFORE their reset -> terminal_img only            (keep_terminal_obs)
 template <int MODE>
 __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
-    const int n_jobs = (MODE == 1) ? cload(P.done_count) : P.n_envs;
+    const int n_jobs = (MODE == 1 || MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform; the caller's release_done_list barrier comes after the call)
     const bool want_done = (MODE == 3) && skip_done;
     // software pipeline on the scalar unit, CW_REC_AHEAD frames deep
@@ -728,6 +729,8 @@ __global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mo
 {
     if (mode == 0) {
         render_jobs<0>(P, 0, nullptr);
+    } else if (mode == 4) {
+        render_jobs<4>(P, 0, nullptr);
     } else {
         render_jobs<1>(P, 0, nullptr);
         release_done_list(P);            // this launch is the done list's last reader
@@ -827,6 +830,7 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         if (ev) (void)hipEventRecord(ev[2], side);
+        if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 4);
         hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 0, 0);
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1);
         if (ev) (void)hipEventRecord(ev[3], side);
@@ -838,6 +842,7 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
         return hipGetLastError();
     }
     if (ev) (void)hipEventRecord(ev[2], st);
+    if (auto_reset && P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 4);
     if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, pixels ? 0 : 1, 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here

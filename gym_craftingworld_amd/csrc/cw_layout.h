@@ -63,6 +63,7 @@ struct CwParams {
     uint8_t *obs;            // [N][P][P][3] or null
     uint8_t *desired_img;
     uint8_t *init_img;
+    uint8_t *terminal_img;   // or null
     // done-list compaction: done_count[0] = entries, [1] = release ticket (cw_kernels.hip)
     int32_t *done_list;      // [N]
     int32_t *done_count;     // [2]

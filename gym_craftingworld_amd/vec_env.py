@@ -52,7 +52,9 @@ class CraftingWorldVecEnv:
     'pixels_dirty' persistent frame with <=2 repainted cells per step, the reference's own
     render_edit strategy | 'state' no pixel buffers), device, seed, seed_style, auto_reset,
     task_menus + env_menu (heterogeneous ordered task lists: env i uses task_menus[env_menu[i]],
-    each menu a dict with any of selected_tasks / number_of_tasks / stacking / reward_style).
+    each menu a dict with any of selected_tasks / number_of_tasks / stacking / reward_style),
+    keep_terminal_obs (pixel modes: info['terminal_observation'] holds the last frame of every episode
+    that ended this step, as gym.vector does, at the cost of one extra frame write per finished env).
     """
 
     metadata = {'render.modes': ['Non']}
@@ -60,7 +62,8 @@ class CraftingWorldVecEnv:
     def __init__(self, num_envs, size=(21, 21), fixed_init_state=0, max_steps=300, store_gif=False,
                  render_save_rate=1, task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None,
                  stacking=True, reward_style=None, obs_mode='pixels', device=None, seed=None,
-                 seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None):
+                 seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None,
+                 keep_terminal_obs=False):
         if store_gif:
             raise NotImplementedError('the GIF episode recorder (ray.py:565-597) is host-side debug I/O, out of scope')
         w, h = size
@@ -106,6 +109,7 @@ class CraftingWorldVecEnv:
         cfg.fixed_init_state = self.fixed_init_state
         cfg.obs_mode = _OBS_MODES[obs_mode]
         cfg.auto_reset = 1 if self.auto_reset else 0
+        cfg.keep_terminal_obs = 1 if (keep_terminal_obs and obs_mode != 'state') else 0
         cfg.n_menus = len(menus)
         cfg.menus = self._menus
         cfg.env_menu = env_menu.ctypes.data_as(C.POINTER(C.c_uint8)) if env_menu is not None else None
@@ -121,6 +125,7 @@ class CraftingWorldVecEnv:
         self._obs = v(tab.obs, (N, P, P, 3), torch.uint8)
         self._desired_img = v(tab.desired_goal, (N, P, P, 3), torch.uint8)
         self._init_img = v(tab.init_obs, (N, P, P, 3), torch.uint8)
+        self.terminal_observation = v(tab.terminal_obs, (N, P, P, 3), torch.uint8)   # None unless keep_terminal_obs
         self.reward = v(tab.reward, (N,), torch.int32)
         self._done_u8 = v(tab.done, (N,), torch.uint8)
         self.done = self._done_u8.view(torch.bool)
@@ -232,6 +237,8 @@ class CraftingWorldVecEnv:
         self._pending = False
         info = {'task_success': self.achieved_mask, 'desired_goal': self.desired_mask,
                 'achieved_goal': self.achieved_mask, 'episode_length': self.episode_length}
+        if self.terminal_observation is not None:
+            info['terminal_observation'] = self.terminal_observation     # rows valid where done
         return self._observation(), self.reward, self.done, info
 
     def step(self, actions):

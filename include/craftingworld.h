@@ -71,6 +71,8 @@ typedef struct cw_config {
     int32_t obs_mode;           /* CW_OBS_* */
     int32_t auto_reset;         /* 1: cw_step resets finished envs itself (gym.vector semantics);
                                  * 0: finished envs keep stepping until cw_reset (single gym.Env semantics, ray.py:367) */
+    int32_t keep_terminal_obs;  /* 1 (pixel modes + auto_reset): before a finished env is reset, its last frame is
+                                 * painted into cw_buffer_table.terminal_obs (gym.vector's info["terminal_observation"]) */
     int32_t n_menus;            /* 1..CW_MAX_MENUS */
     const cw_task_menu *menus;  /* host array [n_menus] */
     const uint8_t *env_menu;    /* host array [num_envs] of menu ids, or NULL (= all envs use menu 0) */
@@ -85,6 +87,7 @@ typedef struct cw_buffer_table {
     uint8_t *obs;            /* [N][P][P][3]  observation == achieved_goal image (ray.py:194-196) */
     uint8_t *desired_goal;   /* [N][P][P][3]  imagine_obs() image, rewritten at reset (ray.py:191) */
     uint8_t *init_obs;       /* [N][P][P][3]  INIT_OBS, rewritten at reset (ray.py:193)            */
+    uint8_t *terminal_obs;   /* [N][P][P][3]  last frame of the episode that just ended, valid where done==1 (NULL unless keep_terminal_obs) */
     int32_t *reward;         /* [N]  -1 or max_steps (ray.py:361-363)                              */
     uint8_t *done;           /* [N]  0/1 (ray.py:367); done envs have already been auto-reset      */
     uint16_t *achieved;      /* [N]  achieved_goal_vector as a bit mask AFTER the step, BEFORE auto-reset */

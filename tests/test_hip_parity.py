@@ -433,3 +433,36 @@ def test_step_captured_in_hip_graph(obs_mode):
     assert int(eager.counters[1].item()) == int(graphed.counters[1].item()) > 0
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty'])
+def test_terminal_observation_vs_oracle(obs_mode):
+    """keep_terminal_obs: where done, info['terminal_observation'] is the oracle's frame BEFORE its
+    reset, and obs is the first frame of the next episode (gym.vector auto-reset semantics)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, kw = 160, 70, dict(size=(5, 5), max_steps=12)
+    keys, pos = _np_states(N, 555)
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, keep_terminal_obs=True, **kw)
+    env.set_rng_states(keys, pos)
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), **kw)
+    env.reset()
+    ora.reset()
+    acts = np.random.RandomState(8).randint(0, 6, size=(T, N)).astype(np.int32)
+    dacts = torch.as_tensor(acts, device=env.device)
+    seen = 0
+    for t in range(T):
+        obs, rew, done, info = env.step(dacts[t])
+        term = info['terminal_observation'].cpu().numpy()
+        cur = obs['observation'].cpu().numpy()
+        d = done.cpu().numpy()
+        for i, e in enumerate(ora.envs):
+            o, r, dd, _ = e.step(int(acts[t, i]))
+            assert dd == d[i]
+            if dd:
+                assert np.array_equal(term[i], o['observation']), (t, i)
+                e.reset()
+                seen += 1
+            assert np.array_equal(cur[i], e.state()['obs']), (t, i)
+    assert seen > N
+    env.close()
