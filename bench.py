@@ -172,11 +172,14 @@ def main():
             alg_bytes = float(N) * 48.0
             dominant, ms = 'cw_step_kernel', prof['ms_step_kernel']
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
+        # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc) and args.obs_mode == 'pixels' and N == 65536 and S == 21:
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+        if pmcs and args.obs_mode == 'pixels' and N == 65536 and S == 21:
             try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                traffic = json.load(open(pmcs[-1])).get('hbm_bytes_per_launch')
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {

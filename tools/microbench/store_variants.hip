@@ -147,6 +147,36 @@ __global__ __launch_bounds__(256) void frame_cellrow_x3(uint8_t *dst, int n_fram
     }
 }
 
+// G2: like G but pixel rows padded to 256 B (frame pitch 84*256 = 21504 B = 168 whole lines) and the
+// 4 pad bytes written too, so every 128-B line is written whole by one store instruction
+__global__ __launch_bounds__(256) void frame_cellrow_padded(uint8_t *dst, int n_frames, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int rr = lane / 21, c = lane - rr * 21;
+    for (int f = wave; f < n_frames; f += n_waves) {
+        uint8_t *base = dst + (size_t)f * 21504;
+        uint4 p = pos[f];
+        uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+        if (lane < 63)
+            for (int r0 = 0; r0 < 21; r0 += 3) {
+                const uint32_t r = r0 + rr;
+                const uint32_t cell = r * 21 + c;
+                uint32_t col = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+                u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+                uint8_t *q = base + (size_t)(4 * r) * 256 + 12 * c;
+#pragma unroll
+                for (int dy = 0; dy < 4; dy++) {
+                    *(u32x3_a4 *)(q + dy * 256) = d;
+                    if (c == 20) *(uint32_t *)(q + dy * 256 + 12) = 0;
+                }
+            }
+    }
+}
+
 template <typename F>
 static void bench(const char *name, size_t bytes, F launch)
 {
@@ -167,8 +197,9 @@ int main()
     const int N = 65536; const uint32_t FB = 21168;
     const size_t bytes = (size_t)N * FB;
     uint8_t *buf; uint4 *pos;
+    uint8_t *buf2; CHECK(hipMalloc(&buf2, (size_t)N * 21504));
     CHECK(hipMalloc(&buf, bytes)); CHECK(hipMalloc(&pos, N * 16)); CHECK(hipMemset(pos, 7, N * 16));
-    for (int blocks : {1024, 2048, 4096, 16384}) {
+    for (int blocks : {128, 256, 512, 1024, 4096}) {
         printf("-- grid %d blocks x 256\n", blocks);
         bench("fill x4 plain", bytes, [&] { hipLaunchKernelGGL(fill_x4<0>, dim3(blocks), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
         bench("fill x4 nontemporal", bytes, [&] { hipLaunchKernelGGL(fill_x4<1>, dim3(blocks), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
@@ -182,6 +213,7 @@ int main()
         bench("E block-per-frame x3, render ALU", bytes, [&] { hipLaunchKernelGGL(frame_block_x3<1>, dim3(blocks), dim3(256), 0, 0, buf, N, FB, pos); });
         bench("F flat items x3, render ALU", bytes, [&] { hipLaunchKernelGGL(flat_x3, dim3(blocks), dim3(256), 0, 0, buf, N, pos); });
         bench("G cell-row x3 (4 stores/cell)", bytes, [&] { hipLaunchKernelGGL(frame_cellrow_x3, dim3(blocks), dim3(256), 0, 0, buf, N, FB, pos); });
+        bench("G2 cell-row, rows padded to 256 B", (size_t)N * 21504, [&] { hipLaunchKernelGGL(frame_cellrow_padded, dim3(blocks), dim3(256), 0, 0, buf2, N, pos); });
         bench("frame x4 plain", bytes, [&] { hipLaunchKernelGGL(frame_x4<0>, dim3(blocks), dim3(256), 0, 0, buf, N, FB); });
         bench("frame x4 nt", bytes, [&] { hipLaunchKernelGGL(frame_x4<1>, dim3(blocks), dim3(256), 0, 0, buf, N, FB); });
     }
