@@ -466,3 +466,36 @@ def test_terminal_observation_vs_oracle(obs_mode):
             assert np.array_equal(cur[i], e.state()['obs']), (t, i)
     assert seen > N
     env.close()
+
+
+def test_multi_device_facade_and_gymnasium_adapter():
+    """One process driving several engines (here: two shards on the one visible GPU) equals the
+    single batch; the gymnasium adaptor splits done into terminated (success) / truncated (time-out)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from gym_craftingworld_amd.adapters import GymnasiumVecAdapter, MultiDeviceVecEnv
+    N, T, kw = 300, 60, dict(size=(5, 5), max_steps=15, obs_mode='pixels_dirty')
+    keys, pos = _np_states(N, 2222)
+    acts = torch.as_tensor(np.random.RandomState(1).randint(0, 6, size=(T, N)).astype(np.int32), device='cuda')
+    single = CraftingWorldVecEnv(N, **kw)
+    single.set_rng_states(keys, pos)
+    multi = MultiDeviceVecEnv(N, ['cuda:0', 'cuda:0'], **kw)
+    multi.set_rng_states(keys, pos)
+    assert multi.ranges == [(0, 150), (150, 300)]
+    gs = GymnasiumVecAdapter(single)
+    obs, info = gs.reset()
+    multi.reset()
+    n_term = n_trunc = 0
+    for t in range(T):
+        o, r, term, trunc, info = gs.step(acts[t])
+        outs = multi.step(acts[t])
+        multi.synchronize()
+        assert torch.equal(r, torch.cat([x[1] for x in outs]))
+        assert torch.equal(term | trunc, torch.cat([x[2] for x in outs]))
+        assert torch.equal(o['observation'], torch.cat([x[0]['observation'] for x in outs]))
+        assert not bool((term & trunc).any())
+        assert bool((r[term] == 15).all()) and bool((r[trunc] == -1).all())
+        n_term += int(term.sum().item())
+        n_trunc += int(trunc.sum().item())
+    assert n_trunc > 0 and n_term > 0
+    gs.close()
+    multi.close()
