@@ -16,7 +16,7 @@
 extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
-void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs);
+void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
@@ -223,7 +223,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
         cwk_set_tuning(geti("CW_TUNE_RENDER_BLOCKS_PER_CU", 1), geti("CW_TUNE_LIST_BLOCKS", 256), geti("CW_TUNE_OVERLAP", 1),
-                        geti("CW_TUNE_RENDER_BLOCKS", 0));
+                        geti("CW_TUNE_RENDER_BLOCKS", 0), geti("CW_TUNE_RENDER_THREADS", 256));
     }
 
     int rc = CW_OK;

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0;
+static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0, g_render_threads = 256;
 
 static inline int cw_render_grid(int jobs)
 {
@@ -785,7 +785,8 @@ static inline int cw_render_grid(int jobs)
     // write path saturates with few store streams and gets slower with more of them in flight
     // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/r01_render_sweeps.txt); it also
     // leaves the wave slots for the reset kernel running beside it
-    int blocks = (jobs + 3) / 4;
+    const int wpb = g_render_threads / CW_WAVE;
+    int blocks = (jobs + wpb - 1) / wpb;
     if (blocks > 256 * g_render_blocks_per_cu) blocks = 256 * g_render_blocks_per_cu;
     if (g_render_blocks_abs > 0 && blocks > g_render_blocks_abs) blocks = g_render_blocks_abs;
     if (blocks < 1) blocks = 1;
@@ -804,9 +805,10 @@ static inline int cw_reset_grid(int jobs)
 extern "C" {
 
 // tuning knobs for experiments (CW_TUNE_* environment variables, read once in cw_create)
-void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs)
+void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads)
 {
     g_render_blocks_abs = render_blocks_abs;
+    if (render_threads == 64 || render_threads == 128 || render_threads == 256) g_render_threads = render_threads;
     if (render_blocks_per_cu > 0) g_render_blocks_per_cu = render_blocks_per_cu;
     if (list_blocks > 0) g_list_blocks = list_blocks;
     g_overlap = overlap;
@@ -836,7 +838,7 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
         if (ev) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, 1, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(g_render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr);
         if (ev) (void)hipEventRecord(ev[5], st);
         (void)hipStreamWaitEvent(st, ev_join, 0);
         return hipGetLastError();
@@ -846,7 +848,7 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
     if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, pixels ? 0 : 1, 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 3, 0, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(g_render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr);
     if (pixels && auto_reset)
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1);
     if (ev) (void)hipEventRecord(ev[5], st);
@@ -871,7 +873,7 @@ hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
 
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(256), 0, st, *P, 2, 0, out);
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(g_render_threads), 0, st, *P, 2, 0, out);
     return hipGetLastError();
 }
 
