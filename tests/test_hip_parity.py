@@ -97,6 +97,10 @@ CASES = [
     dict(N=128, T=200, kw=dict(size=(6, 6), max_steps=30, reward_style='subset', stacking=False)),
     dict(N=96, T=150, kw=dict(size=(7, 7), max_steps=25, fixed_init_state=4)),
     dict(N=100, T=100, kw=dict(size=(4, 4), max_steps=15, selected_tasks=['GoToHouse', 'EatBread', 'MoveAxe'], number_of_tasks=2)),
+    dict(N=65, T=45, kw=dict(size=(64, 64), max_steps=20)),        # one wave-iteration = exactly one grid row
+    dict(N=3, T=25, kw=dict(size=(255, 255), max_steps=12)),       # the largest grid the u8/u16 layout admits
+    dict(N=33, T=60, kw=dict(size=(13, 13), max_steps=25, task_list=TASKS + ['Extra1', 'Extra2'],
+                             selected_tasks=['Extra2', 'ChopTree', 'MoveHammer'])),   # len(task_list) = 11
 ]
 
 
