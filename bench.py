@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-other-modes', action='store_true', help='skip the short dirty-cell / state-only side measurements')
     ap.add_argument('--graph-steps', type=int, default=0,
                     help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
     args = ap.parse_args()
@@ -157,6 +158,27 @@ def main():
     prof = env.profile_end()
     episodes = int(env.counters[1].item())
 
+    # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
+    # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
+    # step (the reference's own render_edit strategy), state-only has no frames at all.
+    other = {}
+    if rank == 0 and not args.no_other_modes and args.obs_mode == 'pixels':
+        env.close()
+        for mode in ('pixels_dirty', 'state'):
+            e2 = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo)
+            e2.reset()
+            k2 = 2 * args.max_steps
+            for t in range(20):
+                e2.step_async(actions[t % rows])
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter()
+            for t in range(k2):
+                e2.step_async(actions[(20 + t) % rows])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - tt
+            other[mode] = {'value': N * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1}
+            e2.close()
+
     if rank == 0:
         total_steps = float(N) * world * K
         value = total_steps / elapsed
@@ -202,11 +224,13 @@ def main():
             'kernels_ms': {'step': prof['ms_step_kernel'], 'reset': prof['ms_reset_kernel'], 'render': prof['ms_render_kernel'],
                            'ms_per_step_with_events': elapsed_prof / K * 1e3},
             'episodes_finished': episodes,
+            'other_obs_modes_1gpu': other,
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)
         print(json.dumps(out))
-    env.close()
+    if not other:
+        env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
