@@ -19,6 +19,7 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
 void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
+hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st);
 }
@@ -379,6 +380,18 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
                             e->ev_fork, e->ev_join, ev));
     if (ev) e->prof_n++;
+    return CW_OK;
+}
+
+int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *rewards, uint8_t *dones, cw_stream_t stream)
+{
+    if (!e || !actions) return fail(CW_ERR_INVALID, "cw_rollout: null argument");
+    if (n_steps < 1) return fail(CW_ERR_INVALID, "cw_rollout: n_steps must be >= 1");
+    if (e->obs_mode != CW_OBS_STATE || !e->auto_reset)
+        return fail(CW_ERR_INVALID, "cw_rollout needs obs_mode CW_OBS_STATE and auto_reset (frames are not painted by the persistent kernel)");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_rollout called before cw_reset");
+    DeviceGuard guard(e->device);
+    HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
 

@@ -109,6 +109,133 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
 }
 
 // ------------------------------------------------------------------------------------ step
+// One env's step() on registers (ray.py:301-378).  Shared by cw_step_kernel (one launch per step)
+// and cw_rollout_kernel (T steps in one persistent launch).
+struct CwStepOut {
+    int reward;
+    bool done, success, invalid, changed;
+    uint32_t dirty0, dirty1;       // cells to repaint (render_edit): dirty1 = 0xFFFFFFFF if only one
+    uint32_t step_num, achieved, desired;
+};
+
+template <typename InitPosFn>
+__device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint32_t sp[8], int a, InitPosFn load_init_pos)
+{
+    CwStepOut o;
+    const int S = P.size;
+    int ar = h.x & 0xFF, ac = (h.x >> 8) & 0xFF;
+    uint32_t hold = (h.x >> 16) & 0xFF;
+    uint32_t achieved = h.y & 0xFFFFu;
+    const uint32_t desired = h.y >> 16;
+    const uint32_t step_num = (h.z & 0xFFFFu) + 1u;               // ray.py:309
+    const uint32_t flags = (h.z >> 16) & ~CW_FLAG_RESET;
+    uint32_t codes = h.w;
+
+    o.invalid = (unsigned)a > 5u;
+    bool changed = false;
+    const uint32_t cell = ar * S + ac;
+    const int idx_here = slot_at(sp, cell);
+    const uint32_t code_here = code_of(codes, idx_here);
+    o.dirty0 = cell;
+    o.dirty1 = 0xFFFFFFFFu;
+
+    if (a == 4) {                                             // pickup, ray.py:314-327
+        if (code_here >= STICKS && code_here <= HAMMER && hold == 0) {
+            hold = code_here;
+#pragma unroll
+            for (int k = 0; k < 8; k++) sp[k] = (k == idx_here) ? CW_POS_HELD : sp[k];
+            changed = true;
+        }
+    } else if (a == 5) {                                      // drop, ray.py:329-341
+        if (hold != 0 && idx_here < 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sp[k] = (sp[k] == CW_POS_HELD) ? cell : sp[k];
+            hold = 0;
+            changed = true;
+        }
+    } else if (!o.invalid) {                                  // __move_agent, ray.py:380-440
+        const int dr = (a == 0) ? -1 : (a == 2) ? 1 : 0;      // ACTIONS = up,right,down,left, :130-131
+        const int dc = (a == 1) ? 1 : (a == 3) ? -1 : 0;
+        const int nr = min(max(ar + dr, 0), S - 1);           // Coord.__add__, coord.py:22-25
+        const int nc = min(max(ac + dc, 0), S - 1);
+        uint32_t old_obj = 0;                                 // None
+        uint32_t cur_code = code_here;
+        if (nr != ar || nc != ac) {                           // :395-396
+            const uint32_t ncell = nr * S + nc;
+            const int idx_t = slot_at(sp, ncell);
+            const uint32_t t = code_of(codes, idx_t);
+            const bool cant = (t == ROCK && hold != 3) || (t == TREE && hold != 2);  // :401-405
+            if (!cant) {
+                changed = true;
+                o.dirty1 = ncell;
+                ar = nr; ac = nc;
+                old_obj = t;                                  // :411 (None when empty, :417-419)
+                uint32_t nw = t;
+                if (t == ROCK || t == BREAD) nw = EMPTY;      // :423-425
+                else if (t == TREE) nw = STICKS;              // :426-428
+                else if (t == STICKS && hold == 3) nw = HOUSE; // :429-432
+                else if (t == WHEAT && hold == 2) nw = BREAD;  // :433-438
+                if (nw != t) {
+                    codes = (codes & ~(15u << (4 * idx_t))) | (nw << (4 * idx_t));
+                    if (nw == EMPTY) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) sp[k] = (k == idx_t) ? CW_POS_GONE : sp[k];
+                    }
+                }
+                cur_code = nw;
+            }
+        }
+        // eval_task_edit, ray.py:646-703 -- runs after every move action, failed ones included
+        const uint32_t pcell = ar * S + ac;
+        if (old_obj == BREAD) achieved |= 1u << T_EATBREAD;            // :657-659
+        else if (old_obj == ROCK) achieved |= 1u << T_CHOPROCK;        // :660-662
+        else if (old_obj == TREE) achieved |= 1u << T_CHOPTREE;        // :663-665
+        achieved = (cur_code == HOUSE) ? (achieved | (1u << T_GOTOHOUSE))
+                                       : (achieved & ~(1u << T_GOTOHOUSE));  // :668
+        if (hold != 0) {
+            const uint4 ip = load_init_pos();
+            const uint32_t ip_sticks = ip.x & 0xFFFFu, ip_axe = ip.x >> 16;
+            const uint32_t ip_hammer = ip.y & 0xFFFFu, ip_tree = ip.z & 0xFFFFu;
+            if (hold == 1) {                                           // :672-684
+                const bool home = (pcell == ip_sticks) ||
+                                  (pcell == ip_tree && (achieved & (1u << T_CHOPTREE)));
+                achieved = home ? (achieved & ~(1u << T_MOVESTICKS)) : (achieved | (1u << T_MOVESTICKS));
+            } else if (hold == 2) {                                    // :685-693
+                if (old_obj == WHEAT) achieved |= 1u << T_MAKEBREAD;
+                achieved = (pcell == ip_axe) ? (achieved & ~(1u << T_MOVEAXE)) : (achieved | (1u << T_MOVEAXE));
+            } else {                                                   // :694-702
+                if (old_obj == STICKS) achieved |= 1u << T_BUILDHOUSE;
+                achieved = (pcell == ip_hammer) ? (achieved & ~(1u << T_MOVEHAMMER)) : (achieved | (1u << T_MOVEHAMMER));
+            }
+        }
+    }
+
+    // reward, ray.py:348-363 + 747-767
+    int reward = -1;
+    if (changed) {
+        const uint32_t am = achieved & P.task_mask, dm = desired & P.task_mask;
+        bool hit;
+        if (flags & CW_FLAG_SUBSET)  // np.max(desired - achieved) == 0
+            hit = ((dm & ~am) == 0) && (((~(dm ^ am)) & P.task_mask) != 0);
+        else                         // short_circuit_check == array_equal
+            hit = (am == dm);
+        reward = hit ? P.max_steps : -1;
+    }
+    o.reward = reward;
+    o.changed = changed;
+    o.success = (reward == P.max_steps);
+    o.done = (step_num >= (uint32_t)P.max_steps) || o.success;             // :367
+    o.step_num = step_num;
+    o.achieved = achieved;
+    o.desired = desired;
+
+    h.x = (uint32_t)ar | ((uint32_t)ac << 8) | (hold << 16) | (h.x & 0xFF000000u);
+    h.y = achieved | (desired << 16);
+    h.z = step_num | (flags << 16);
+    h.w = codes;
+    return o;
+}
+
 __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype,
                                                       int compact, int paint_dirty)
 {
@@ -127,126 +254,24 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         uint4 h = P.hdr[i];
         uint32_t sp[8];
         unpack_pos(P.pos[i], sp);
-        const int S = P.size;
-        int ar = h.x & 0xFF, ac = (h.x >> 8) & 0xFF;
-        uint32_t hold = (h.x >> 16) & 0xFF;
-        uint32_t achieved = h.y & 0xFFFFu;
-        const uint32_t desired = h.y >> 16;
-        uint32_t step_num = (h.z & 0xFFFFu) + 1u;                 // ray.py:309
-        const uint32_t flags = (h.z >> 16) & ~CW_FLAG_RESET;
-        uint32_t codes = h.w;
+        const CwStepOut o = step_env(P, h, sp, a, [&]() { return P.init_pos[i]; });
+        done = o.done; success = o.success; invalid = o.invalid;
 
-        invalid = (unsigned)a > 5u;
-        bool changed = false;
-        const uint32_t cell = ar * S + ac;
-        const int idx_here = slot_at(sp, cell);
-        const uint32_t code_here = code_of(codes, idx_here);
-        uint32_t dirty0 = cell, dirty1 = 0xFFFFFFFFu;
-
-        if (a == 4) {                                             // pickup, ray.py:314-327
-            if (code_here >= STICKS && code_here <= HAMMER && hold == 0) {
-                hold = code_here;
-#pragma unroll
-                for (int k = 0; k < 8; k++) sp[k] = (k == idx_here) ? CW_POS_HELD : sp[k];
-                changed = true;
-            }
-        } else if (a == 5) {                                      // drop, ray.py:329-341
-            if (hold != 0 && idx_here < 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) sp[k] = (sp[k] == CW_POS_HELD) ? cell : sp[k];
-                hold = 0;
-                changed = true;
-            }
-        } else if (!invalid) {                                    // __move_agent, ray.py:380-440
-            const int dr = (a == 0) ? -1 : (a == 2) ? 1 : 0;      // ACTIONS = up,right,down,left, :130-131
-            const int dc = (a == 1) ? 1 : (a == 3) ? -1 : 0;
-            const int nr = min(max(ar + dr, 0), S - 1);           // Coord.__add__, coord.py:22-25
-            const int nc = min(max(ac + dc, 0), S - 1);
-            uint32_t old_obj = 0;                                 // None
-            uint32_t cur_code = code_here;
-            if (nr != ar || nc != ac) {                           // :395-396
-                const uint32_t ncell = nr * S + nc;
-                const int idx_t = slot_at(sp, ncell);
-                const uint32_t t = code_of(codes, idx_t);
-                const bool cant = (t == ROCK && hold != 3) || (t == TREE && hold != 2);  // :401-405
-                if (!cant) {
-                    changed = true;
-                    dirty1 = ncell;
-                    ar = nr; ac = nc;
-                    old_obj = t;                                  // :411 (None when empty, :417-419)
-                    uint32_t nw = t;
-                    if (t == ROCK || t == BREAD) nw = EMPTY;      // :423-425
-                    else if (t == TREE) nw = STICKS;              // :426-428
-                    else if (t == STICKS && hold == 3) nw = HOUSE; // :429-432
-                    else if (t == WHEAT && hold == 2) nw = BREAD;  // :433-438
-                    if (nw != t) {
-                        codes = (codes & ~(15u << (4 * idx_t))) | (nw << (4 * idx_t));
-                        if (nw == EMPTY) {
-#pragma unroll
-                            for (int k = 0; k < 8; k++) sp[k] = (k == idx_t) ? CW_POS_GONE : sp[k];
-                        }
-                    }
-                    cur_code = nw;
-                }
-            }
-            // eval_task_edit, ray.py:646-703 -- runs after every move action, failed ones included
-            const uint32_t pcell = ar * S + ac;
-            if (old_obj == BREAD) achieved |= 1u << T_EATBREAD;            // :657-659
-            else if (old_obj == ROCK) achieved |= 1u << T_CHOPROCK;        // :660-662
-            else if (old_obj == TREE) achieved |= 1u << T_CHOPTREE;        // :663-665
-            achieved = (cur_code == HOUSE) ? (achieved | (1u << T_GOTOHOUSE))
-                                           : (achieved & ~(1u << T_GOTOHOUSE));  // :668
-            if (hold != 0) {
-                const uint4 ip = P.init_pos[i];
-                const uint32_t ip_sticks = ip.x & 0xFFFFu, ip_axe = ip.x >> 16;
-                const uint32_t ip_hammer = ip.y & 0xFFFFu, ip_tree = ip.z & 0xFFFFu;
-                if (hold == 1) {                                           // :672-684
-                    const bool home = (pcell == ip_sticks) ||
-                                      (pcell == ip_tree && (achieved & (1u << T_CHOPTREE)));
-                    achieved = home ? (achieved & ~(1u << T_MOVESTICKS)) : (achieved | (1u << T_MOVESTICKS));
-                } else if (hold == 2) {                                    // :685-693
-                    if (old_obj == WHEAT) achieved |= 1u << T_MAKEBREAD;
-                    achieved = (pcell == ip_axe) ? (achieved & ~(1u << T_MOVEAXE)) : (achieved | (1u << T_MOVEAXE));
-                } else {                                                   // :694-702
-                    if (old_obj == STICKS) achieved |= 1u << T_BUILDHOUSE;
-                    achieved = (pcell == ip_hammer) ? (achieved & ~(1u << T_MOVEHAMMER)) : (achieved | (1u << T_MOVEHAMMER));
-                }
-            }
-        }
-
-        // reward, ray.py:348-363 + 747-767
-        int reward = -1;
-        if (changed) {
-            const uint32_t am = achieved & P.task_mask, dm = desired & P.task_mask;
-            bool hit;
-            if (flags & CW_FLAG_SUBSET)  // np.max(desired - achieved) == 0
-                hit = ((dm & ~am) == 0) && (((~(dm ^ am)) & P.task_mask) != 0);
-            else                         // short_circuit_check == array_equal
-                hit = (am == dm);
-            reward = hit ? P.max_steps : -1;
-        }
-        success = (reward == P.max_steps);
-        done = (step_num >= (uint32_t)P.max_steps) || success;             // :367
-
-        // write back
-        h.x = (uint32_t)ar | ((uint32_t)ac << 8) | (hold << 16) | (h.x & 0xFF000000u);
-        h.y = achieved | (desired << 16);
-        h.z = step_num | (flags << 16);
-        h.w = codes;
         P.hdr[i] = h;
         P.pos[i] = pack_pos(sp);
-        P.reward[i] = reward;
+        P.reward[i] = o.reward;
         P.done[i] = done ? 1 : 0;
-        P.achieved_out[i] = (uint16_t)achieved;
-        P.desired_out[i] = (uint16_t)desired;
-        if (done) P.episode_length[i] = (int32_t)step_num;
+        P.achieved_out[i] = (uint16_t)o.achieved;
+        P.desired_out[i] = (uint16_t)o.desired;
+        if (done) P.episode_length[i] = (int32_t)o.step_num;
 
-        if (paint_dirty && changed) {                                      // render_edit, :358
+        if (paint_dirty && o.changed) {                                    // render_edit, :358
             uint8_t *frame = P.obs + (size_t)i * P.frame_bytes;
-            const uint32_t acell = ar * S + ac;
-            paint_cell(frame, S, dirty0, code_of(codes, slot_at(sp, dirty0)), dirty0 == acell, hold, P.div_magic);
-            if (dirty1 != 0xFFFFFFFFu)
-                paint_cell(frame, S, dirty1, code_of(codes, slot_at(sp, dirty1)), dirty1 == acell, hold, P.div_magic);
+            const uint32_t hold = (h.x >> 16) & 0xFFu;
+            const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+            paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+            if (o.dirty1 != 0xFFFFFFFFu)
+                paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
         }
     }
 
@@ -410,6 +435,149 @@ __device__ __forceinline__ uint32_t count_code(const uint32_t fp[8], const uint3
 
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
 
+// One env's reset() (ray.py:156-218) by one wavefront; every value in the result is wave-uniform.
+struct CwResetOut {
+    uint4 init_pos;          // sample_state placement of objects 0..7
+    uint32_t init_agent;
+    uint4 goal_pos;          // imagine_obs final state
+    uint32_t goal_codes, goal_agent;
+    uint32_t desired, subset;
+};
+
+__device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env, uint32_t menu_id, uint32_t *lds_mt, int lane)
+{
+    const CwMenuDev M = P.menus[menu_id];
+    CwMtWave mt;
+    mt.load(lds_mt, P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
+
+    // task draw, ray.py:169-174
+    const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
+    unsigned long long perm = 0xFEDCBA9876543210ull;             // task_idx = arange(n_selected)
+    for (int i = M.n_selected - 1; i >= 1; i--) {                 // RandomState.shuffle
+        const uint32_t j = mt.interval((uint32_t)i);
+        const unsigned long long ni = (perm >> (4 * i)) & 15ull, nj = (perm >> (4 * j)) & 15ull;
+        perm = (perm & ~(15ull << (4 * i))) | (nj << (4 * i));
+        perm = (perm & ~(15ull << (4 * j))) | (ni << (4 * j));
+    }
+    uint32_t desired = 0;
+    for (uint32_t q = 0; q < ntasks; q++) {
+        const uint32_t idx = (uint32_t)((perm >> (4 * q)) & 15ull);
+        desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
+    }
+
+    // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
+    uint32_t fp[8], fc[8];
+    uint32_t agent;
+    if (P.pool_k == 0) {
+        const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
+#pragma unroll
+        for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readlane(v_tok, k);
+        agent = __builtin_amdgcn_readlane(v_tok, 8);
+    } else {
+        const uint32_t pk = mt.randint((uint32_t)P.pool_k);
+        const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
+#pragma unroll
+        for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readfirstlane((uint32_t)pp[k]);
+        agent = __builtin_amdgcn_readfirstlane((uint32_t)pp[8]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) fc[k] = k + 1;
+    const uint4 init_packed = pack_pos(fp);
+    const uint32_t init_agent = agent;
+
+    // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
+    if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
+        CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
+    }
+    if (desired & (1u << T_EATBREAD)) {                           // :232-237
+        const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
+        const int sl = nth_with_code(fp, fc, BREAD, which);
+        CW_SET_SLOT(fc, sl, (uint32_t)EMPTY);
+        CW_SET_SLOT(fp, sl, CW_POS_GONE);
+    }
+    if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
+        CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
+    }
+    if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
+        const int sl = nth_with_code(fp, fc, STICKS, which_stick);
+        const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
+        CW_SET_SLOT(fp, sl, to);
+    }
+    if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
+        const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
+        const int sl = nth_with_code(fp, fc, STICKS, which);
+        CW_SET_SLOT(fc, sl, (uint32_t)HOUSE);
+    }
+    if (desired & (1u << T_CHOPROCK)) {                           // :265-268
+        CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
+        CW_SET_SLOT(fp, 3, CW_POS_GONE);
+    }
+    if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
+        const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
+        const int sl = nth_with_code(fp, fc, HOUSE, which);
+#pragma unroll
+        for (int k = 0; k < 8; k++) agent = (k == sl) ? fp[k] : agent;
+    }
+    if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+        CW_SET_SLOT(fp, 1, to);
+    }
+    if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
+        uint32_t present = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
+        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
+        CW_SET_SLOT(fp, 2, to);
+    }
+
+    mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);   // coalesced write-back
+    CwResetOut r;
+    uint32_t goal_codes = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) goal_codes |= fc[k] << (4 * k);
+    r.init_pos = init_packed;
+    r.init_agent = init_agent;
+    r.goal_pos = pack_pos(fp);
+    r.goal_codes = goal_codes;
+    r.goal_agent = agent;
+    r.desired = desired;
+    r.subset = M.reward_subset ? 1u : 0u;
+    return r;
+}
+
+// the header of a freshly reset env (hold = 0, achieved = 0 ray.py:176, step_num = 0 ray.py:203)
+__device__ __forceinline__ uint4 reset_header(const CwParams &P, const CwResetOut &r, uint32_t menu_id)
+{
+    const uint32_t ar = __umulhi(r.init_agent, P.div_magic);
+    const uint32_t ac = r.init_agent - ar * P.size;
+    uint4 h;
+    h.x = ar | (ac << 8) | (menu_id << 24);
+    h.y = r.desired << 16;
+    h.z = (CW_FLAG_RESET | (r.subset ? CW_FLAG_SUBSET : 0u)) << 16;
+    h.w = CW_CODES_INITIAL;
+    return h;
+}
+// the cold per-episode records (read only by the render kernels / get_state)
+__device__ __forceinline__ void store_episode_records(const CwParams &P, int env, const CwResetOut &r, bool count_episode)
+{
+    P.goal_pos[env] = r.goal_pos;
+    P.goal_codes[env] = r.goal_codes;
+    P.goal_agent[env] = (uint16_t)r.goal_agent;
+    P.init_pos[env] = r.init_pos;
+    P.init_agent[env] = (uint16_t)r.init_agent;
+    if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
+}
+
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
@@ -418,132 +586,91 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
     const int count = all_envs ? P.n_envs : P.done_count[0];
-    // few, latency-critical waves sharing CUs with the render kernel's 24 store-bound waves: win arbitration
+    // few, latency-critical waves sharing CUs with the render kernel's store-bound waves: win arbitration
     if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
     for (int job = wave; job < count; job += n_waves) {
         const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.done_list[job]);
         const uint32_t h_old_x = __builtin_amdgcn_readfirstlane(P.hdr[env].x);
         const uint32_t h_old_z = __builtin_amdgcn_readfirstlane(P.hdr[env].z);
         const uint32_t menu_id = h_old_x >> 24;
-        const CwMenuDev M = P.menus[menu_id];
-
-        CwMtWave mt;
-        mt.load(s_mt[wave_in_block], P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
-
-        // task draw, ray.py:169-174
-        const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
-        unsigned long long perm = 0xFEDCBA9876543210ull;             // task_idx = arange(n_selected)
-        for (int i = M.n_selected - 1; i >= 1; i--) {                 // RandomState.shuffle
-            const uint32_t j = mt.interval((uint32_t)i);
-            const unsigned long long ni = (perm >> (4 * i)) & 15ull, nj = (perm >> (4 * j)) & 15ull;
-            perm = (perm & ~(15ull << (4 * i))) | (nj << (4 * i));
-            perm = (perm & ~(15ull << (4 * j))) | (ni << (4 * j));
-        }
-        uint32_t desired = 0;
-        for (uint32_t q = 0; q < ntasks; q++) {
-            const uint32_t idx = (uint32_t)((perm >> (4 * q)) & 15ull);
-            desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
-        }
-
-        // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
-        uint32_t fp[8], fc[8];
-        uint32_t agent;
-        if (P.pool_k == 0) {
-            const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
-#pragma unroll
-            for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readlane(v_tok, k);
-            agent = __builtin_amdgcn_readlane(v_tok, 8);
-        } else {
-            const uint32_t pk = mt.randint((uint32_t)P.pool_k);
-            const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
-#pragma unroll
-            for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readfirstlane((uint32_t)pp[k]);
-            agent = __builtin_amdgcn_readfirstlane((uint32_t)pp[8]);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) fc[k] = k + 1;
-        const uint4 init_packed = pack_pos(fp);
-        const uint32_t init_agent = agent;
-
-        // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
-        if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
-            CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
-        }
-        if (desired & (1u << T_EATBREAD)) {                           // :232-237
-            const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
-            const int sl = nth_with_code(fp, fc, BREAD, which);
-            CW_SET_SLOT(fc, sl, (uint32_t)EMPTY);
-            CW_SET_SLOT(fp, sl, CW_POS_GONE);
-        }
-        if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
-            CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
-        }
-        if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
-            uint32_t present = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-            const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
-            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
-            const int sl = nth_with_code(fp, fc, STICKS, which_stick);
-            const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
-            CW_SET_SLOT(fp, sl, to);
-        }
-        if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
-            const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
-            const int sl = nth_with_code(fp, fc, STICKS, which);
-            CW_SET_SLOT(fc, sl, (uint32_t)HOUSE);
-        }
-        if (desired & (1u << T_CHOPROCK)) {                           // :265-268
-            CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
-            CW_SET_SLOT(fp, 3, CW_POS_GONE);
-        }
-        if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
-            const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
-            const int sl = nth_with_code(fp, fc, HOUSE, which);
-#pragma unroll
-            for (int k = 0; k < 8; k++) agent = (k == sl) ? fp[k] : agent;
-        }
-        if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
-            uint32_t present = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-            const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-            CW_SET_SLOT(fp, 1, to);
-        }
-        if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
-            uint32_t present = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-            const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-            const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-            CW_SET_SLOT(fp, 2, to);
-        }
-
-        // commit: the MT state goes back coalesced, the records are written by one lane
-        mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
+        const CwResetOut r = reset_env_wave(P, env, menu_id, s_mt[wave_in_block], lane);
         if (lane == 0) {
-            uint32_t goal_codes = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) goal_codes |= fc[k] << (4 * k);
-            P.goal_pos[env] = pack_pos(fp);
-            P.goal_codes[env] = goal_codes;
-            P.goal_agent[env] = (uint16_t)agent;
-            P.init_pos[env] = init_packed;
-            P.init_agent[env] = (uint16_t)init_agent;
-            P.pos[env] = init_packed;
-            const uint32_t ar = __umulhi(init_agent, P.div_magic);
-            const uint32_t ac = init_agent - ar * P.size;
-            uint4 h;
-            h.x = ar | (ac << 8) | (menu_id << 24);                       // hold = 0
-            h.y = desired << 16;                                          // achieved = 0, ray.py:176
-            h.z = (CW_FLAG_RESET | (M.reward_subset ? CW_FLAG_SUBSET : 0u)) << 16;   // step_num = 0, :203
-            h.w = CW_CODES_INITIAL;
-            P.hdr[env] = h;
-            if ((h_old_z & 0xFFFFu) != 0) P.ep_no[env] += 1;             // :200-201
+            store_episode_records(P, env, r, (h_old_z & 0xFFFFu) != 0);
+            P.pos[env] = r.init_pos;
+            P.hdr[env] = reset_header(P, r, menu_id);
         }
     }
     if (!all_envs && last_reader) release_done_list(P);
+}
+
+// T consecutive steps of every env in ONE persistent launch (state-only observation mode): each
+// wavefront owns 64 consecutive envs, keeps their state in registers, steps them lane-parallel and,
+// when the ballot shows finished envs, resets them one after the other with the whole wave
+// (reset_env_wave).  Envs never interact, so no wave ever waits for another: no kernel boundaries,
+// no done list, no launch latency between steps.  For scripted / random action streams
+// (actions[T][N] known up front); with a policy in the loop use cw_step.
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwParams P, const uint8_t *actions, int T,
+                                                                             int32_t *rewards, uint8_t *dones)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
+    const int env0 = wave * CW_WAVE;
+    if (env0 >= P.n_envs) return;
+    const int env = env0 + lane;
+    const bool live = env < P.n_envs;
+    const int e = live ? env : env0;                 // idle lanes shadow a valid env (their results are dropped)
+    uint4 h = P.hdr[e];
+    uint32_t sp[8];
+    unpack_pos(P.pos[e], sp);
+    uint4 ip = P.init_pos[e];
+    unsigned long long n_done = 0, n_succ = 0, n_inv = 0;
+    int reward = -1;
+    bool done = false;
+    uint32_t achieved = 0, desired = 0, step_num = 0;
+    for (int t = 0; t < T; t++) {
+        const int a = actions[(size_t)t * P.n_envs + e];
+        const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
+        reward = o.reward; done = o.done; achieved = o.achieved; desired = o.desired; step_num = o.step_num;
+        if (live) {
+            if (rewards) rewards[(size_t)t * P.n_envs + env] = o.reward;
+            if (dones) dones[(size_t)t * P.n_envs + env] = o.done ? 1 : 0;
+        }
+        unsigned long long m = __ballot(live && o.done);
+        n_done += __popcll(m);
+        n_succ += __popcll(__ballot(live && o.success));
+        n_inv += __popcll(__ballot(live && o.invalid));
+        if (m && t + 1 == T && live && o.done) P.episode_length[env] = (int32_t)o.step_num;
+        while (m) {                                  // auto-reset, one finished env at a time, whole wave
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int env_l = env0 + l;
+            const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
+            const CwResetOut r = reset_env_wave(P, env_l, menu_id, s_mt[wave_in_block], lane);
+            if (lane == 0) store_episode_records(P, env_l, r, true);   // step_num >= 1 here
+            if (lane == l) {
+                h = reset_header(P, r, menu_id);
+                unpack_pos(r.init_pos, sp);
+                ip = r.init_pos;
+            }
+        }
+    }
+    if (live) {
+        P.hdr[env] = h;
+        P.pos[env] = pack_pos(sp);
+        P.reward[env] = reward;                      // outputs of the last step, as cw_step leaves them
+        P.done[env] = done ? 1 : 0;
+        P.achieved_out[env] = (uint16_t)achieved;
+        P.desired_out[env] = (uint16_t)desired;
+        (void)step_num;
+    }
+    if (lane == 0) {
+        atomicAdd(&P.counters[0], (unsigned long long)min(CW_WAVE, P.n_envs - env0) * (unsigned long long)T);
+        if (n_done) atomicAdd(&P.counters[1], n_done);
+        if (n_succ) atomicAdd(&P.counters[2], n_succ);
+        if (n_inv) atomicAdd(&P.counters[3], n_inv);
+    }
 }
 
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
@@ -852,6 +979,14 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
     if (pixels && auto_reset)
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1);
     if (ev) (void)hipEventRecord(ev[5], st);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st)
+{
+    const int waves = (P->n_envs + CW_WAVE - 1) / CW_WAVE;
+    hipLaunchKernelGGL(cw_rollout_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
+                       *P, actions, T, rewards, dones);
     return hipGetLastError();
 }
 

@@ -248,6 +248,24 @@ class CraftingWorldVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
+    def rollout(self, actions, record=True):
+        """T consecutive steps (auto-reset included) in ONE persistent kernel launch, for action streams
+        known up front: actions uint8 [T, N] on the device.  Bit-identical to T calls of step().
+        State-only observation mode.  -> (rewards int32 [T,N], dones bool [T,N]) if record."""
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise ValueError('actions must have shape [T, num_envs]')
+        T = actions.shape[0]
+        rew = torch.empty((T, self.num_envs), dtype=torch.int32, device=self.device) if record else None
+        don = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device) if record else None
+        L.check(self._lib.cw_rollout(self._h, C.c_void_p(actions.data_ptr()), T,
+                                     C.c_void_p(rew.data_ptr()) if record else None,
+                                     C.c_void_p(don.data_ptr()) if record else None, self._stream()), 'cw_rollout')
+        self._actions_keepalive = actions
+        return (rew, don.view(torch.bool)) if record else None
+
     # ------------------------------------------------------------------ views / checkpoints
     def render(self, out=None):
         """render() of ray.py:442-520 for every env -> uint8 [N,4S,4S,3] (works in every obs_mode)."""

@@ -145,6 +145,15 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
  * reset kernel over the ballot-compacted done list, render kernel. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
 
+/* --- n_steps consecutive step()s (+ auto-reset) for every env in ONE persistent kernel launch --
+ * For scripted / random action streams known up front (BASELINE config 2 style): actions is a DEVICE
+ * array [n_steps][N] of uint8 action ids; rewards [n_steps][N] int32 and dones [n_steps][N] uint8 are
+ * DEVICE arrays or NULL.  The result (state, RNG streams, counters, the reward/done/achieved buffers of
+ * the last step) is bit-identical to n_steps calls of cw_step.  CW_OBS_STATE engines with auto_reset
+ * only: no frames are painted (use cw_render afterwards). */
+int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *rewards, uint8_t *dones,
+               cw_stream_t stream);
+
 /* render(state=None) for every env into a caller-supplied DEVICE buffer [N][P][P][3] (works in
  * every obs_mode; ray.py:442-520). */
 int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);

@@ -503,3 +503,50 @@ def test_multi_device_facade_and_gymnasium_adapter():
     assert n_trunc > 0 and n_term > 0
     gs.close()
     multi.close()
+
+
+@pytest.mark.parametrize('case', [dict(N=4096, T=140, kw=dict(size=(21, 21), max_steps=50)),
+                                  dict(N=1000, T=90, kw=dict(size=(5, 5), max_steps=12, reward_style='subset')),
+                                  dict(N=130, T=70, kw=dict(size=(6, 6), max_steps=10, fixed_init_state=3))],
+                         ids=lambda c: 'N%d_S%d' % (c['N'], c['kw']['size'][0]))
+def test_persistent_rollout_equals_stepping(case):
+    """cw_rollout (T steps in one persistent kernel) == T x cw_step: rewards and dones of every step,
+    final state, goal state, RNG streams and counters; and both equal the oracle on the first envs."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from gym_craftingworld_amd import _lib as L
+    from oracle import OracleBatch
+    N, T, kw = case['N'], case['T'], case['kw']
+    keys, pos = _np_states(N, 8080)
+    envs = []
+    for _ in range(2):
+        e = CraftingWorldVecEnv(N, obs_mode='state', **kw)
+        e.set_rng_states(keys, pos)
+        if kw.get('fixed_init_state'):
+            L.check(e._lib.cw_generate_fixed_states(e._h, e._stream()), 'pool')
+        e.reset()
+        envs.append(e)
+    stepped, rolled = envs
+    acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(21))
+    rew, don = rolled.rollout(acts)
+    rs, ds = [], []
+    for t in range(T):
+        _, r, d, _ = stepped.step(acts[t])
+        rs.append(r.clone())
+        ds.append(d.clone())
+    assert torch.equal(rew, torch.stack(rs)) and torch.equal(don, torch.stack(ds))
+    a, b = stepped.get_state(), rolled.get_state()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert torch.equal(stepped.counters, rolled.counters)
+    assert torch.equal(stepped.reward, rolled.reward) and torch.equal(stepped.done, rolled.done)
+    assert torch.equal(stepped.achieved_mask, rolled.achieved_mask)
+    ka, pa = stepped.get_rng_states()
+    kb, pb = rolled.get_rng_states()
+    assert np.array_equal(pa, pb) and np.array_equal(ka[:, 1:], kb[:, 1:])
+    M = min(N, 96)
+    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in range(M)], **kw)
+    ora.reset()
+    _, o_rew, o_don = ora.rollout(acts[:, :M].cpu().numpy().astype(np.int8), nthreads=4, record=True)
+    assert np.array_equal(rew[:, :M].cpu().numpy(), o_rew) and np.array_equal(don[:, :M].cpu().numpy(), o_don.astype(bool))
+    for e in envs:
+        e.close()
