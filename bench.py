@@ -72,6 +72,8 @@ def main():
     ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--rollout', action='store_true',
+                    help='state-only mode: run the K steps as ONE persistent-kernel launch (cw_rollout; actions known up front)')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the short dirty-cell / state-only side measurements')
     ap.add_argument('--graph-steps', type=int, default=0,
                     help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
@@ -130,7 +132,14 @@ def main():
             for t in range(G):
                 env.step_async(actions[t])
 
+    if args.rollout and args.obs_mode != 'state':
+        raise SystemExit('--rollout needs --obs-mode state')
+
     def run(k, t_off):
+        if args.rollout:
+            idx = (torch.arange(k, device=dev) + t_off) % rows
+            env.rollout(actions[idx] if k != rows or t_off else actions, record=False)
+            return
         if graph is not None:
             for _ in range(k // G):
                 graph.replay()
@@ -148,7 +157,10 @@ def main():
 
     # second, identical K-step region with the library's HIP events around each kernel (eager launches:
     # events cannot be re-recorded from inside a replayed graph)
+    launch_desc = ('one persistent kernel for all K steps (cw_rollout)' if args.rollout else
+                   ('eager' if G == 0 else 'hip graph of %d steps' % G))
     graph = None
+    args.rollout = False
     env.profile_begin(K)
     barrier()
     t1 = time.perf_counter()
@@ -215,7 +227,7 @@ def main():
                                                                         'state': 'state-only'}[args.obs_mode], args.max_steps),
                        'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
                        'sharding': 'contiguous env ranges per rank, no data-path collective',
-                       'launch': 'eager' if G == 0 else 'hip graph of %d steps' % G},
+                       'launch': launch_desc},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,

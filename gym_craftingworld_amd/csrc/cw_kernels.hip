@@ -610,16 +610,17 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
 // no done list, no launch latency between steps.  For scripted / random action streams
 // (actions[T][N] known up front); with a policy in the loop use cw_step.
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwParams P, const uint8_t *actions, int T,
-                                                                             int32_t *rewards, uint8_t *dones)
+                                                                             int32_t *rewards, uint8_t *dones, int epw)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
-    const int env0 = wave * CW_WAVE;
+    // epw = envs per wave (8..64): resets are serial within a wave, so small batches use more, narrower waves
+    const int env0 = wave * epw;
     if (env0 >= P.n_envs) return;
     const int env = env0 + lane;
-    const bool live = env < P.n_envs;
+    const bool live = lane < epw && env < P.n_envs;
     const int e = live ? env : env0;                 // idle lanes shadow a valid env (their results are dropped)
     uint4 h = P.hdr[e];
     uint32_t sp[8];
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
         (void)step_num;
     }
     if (lane == 0) {
-        atomicAdd(&P.counters[0], (unsigned long long)min(CW_WAVE, P.n_envs - env0) * (unsigned long long)T);
+        atomicAdd(&P.counters[0], (unsigned long long)min(epw, P.n_envs - env0) * (unsigned long long)T);
         if (n_done) atomicAdd(&P.counters[1], n_done);
         if (n_succ) atomicAdd(&P.counters[2], n_succ);
         if (n_inv) atomicAdd(&P.counters[3], n_inv);
@@ -984,9 +985,12 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
 
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st)
 {
-    const int waves = (P->n_envs + CW_WAVE - 1) / CW_WAVE;
+    // aim for ~4096 waves (4 per SIMD): envs per wave = 64 for large batches, down to 8 for small ones
+    int epw = 64;
+    while (epw > 8 && (P->n_envs + epw - 1) / epw < 4096) epw >>= 1;
+    const int waves = (P->n_envs + epw - 1) / epw;
     hipLaunchKernelGGL(cw_rollout_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
-                       *P, actions, T, rewards, dones);
+                       *P, actions, T, rewards, dones, epw);
     return hipGetLastError();
 }
 
