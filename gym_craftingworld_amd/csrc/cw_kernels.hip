@@ -9,6 +9,7 @@
 //   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520; a lane paints one cell's
 //                     4 pixel rows with 4 x 12-byte stores; records arrive by scalar loads.
 //   cw_render_reset_kernel  the three frames (obs, init_obs, desired_goal) of freshly reset envs.
+//   cw_rollout_kernel persistent: T steps of every env in one launch (state-only mode).
 //   cw_export_*       dense grid / one-hot views of the slot state.
 //
 // All integer; no MFMA (nothing here is a contraction: the reference's tensordot with a one-hot

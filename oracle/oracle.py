@@ -41,6 +41,8 @@ class _View(C.Structure):
 
 def build_oracle(force=False):
     """Compile oracle/libcw_oracle.so with gcc if missing or stale (no GPU, no reference needed)."""
+    if os.environ.get('CW_ORACLE_SO'):            # e.g. the ASAN/UBSAN build from `make -C oracle asan`
+        return os.environ['CW_ORACLE_SO']
     so = os.path.join(_HERE, 'libcw_oracle.so')
     srcs = [os.path.join(_HERE, f) for f in ('cw_oracle.c', 'cw_oracle.h')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

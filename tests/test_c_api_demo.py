@@ -1,0 +1,54 @@
+"""The C ABI used from plain C (examples/c_api_demo.c: no Python, no torch): build it with gcc,
+run it on the GPU, and check every number it prints against the CPU oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    exe = os.path.join(ROOT, 'examples', 'c_api_demo')
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'gym_craftingworld_amd', 'csrc')], stdout=subprocess.DEVNULL)
+    subprocess.check_call(['gcc', '-O2', '-std=c99', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(ROOT, 'include'),
+                           '-I', '/opt/rocm/include', '-o', exe, os.path.join(ROOT, 'examples', 'c_api_demo.c'),
+                           '-L', os.path.join(ROOT, 'gym_craftingworld_amd'), '-lcraftingworld', '-L', '/opt/rocm/lib',
+                           '-lamdhip64', '-Wl,-rpath,' + os.path.join(ROOT, 'gym_craftingworld_amd'), '-Wl,-rpath,/opt/rocm/lib'])
+    return exe
+
+
+def test_c_demo_builds_as_plain_c():
+    assert os.path.exists(_build())
+
+
+@pytest.mark.gpu
+def test_c_demo_matches_oracle():
+    from oracle import OracleBatch
+    out = subprocess.check_output([_build()], timeout=300).decode()
+    m = re.search(r'env_steps (\d+) episodes (\d+) successes (\d+) reward_sum_sampled (-?\d+) frame17_fnv ([0-9a-f]{8})', out)
+    assert m, out
+    N, T = 1024, 600
+    states = [np.random.RandomState(5000 + i).get_state() for i in range(N)]
+    ora = OracleBatch(N, rng_states=[(s[1], s[2]) for s in states], size=(21, 21), max_steps=300)
+    ora.reset()
+    s = np.uint32(12345)
+    acts = np.empty(T * N, dtype=np.int8)
+    x = 12345
+    for i in range(T * N):                       # the demo's LCG
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        acts[i] = (x >> 8) % 6
+    acts = acts.reshape(T, N)
+    total, rew, don = ora.rollout(acts, nthreads=8, record=True)
+    sampled = sum(int(rew[t].sum()) for t in range(T) if t % 100 == 99 or t == T - 1)
+    frame = ora.envs[17].state()['obs'].reshape(-1)
+    fnv = 2166136261
+    for b in frame.tolist():
+        fnv = ((fnv ^ b) * 16777619) & 0xFFFFFFFF
+    assert int(m.group(1)) == N * T
+    assert int(m.group(2)) == int(don.sum())
+    assert int(m.group(3)) == int((rew == 300).sum())
+    assert int(m.group(4)) == sampled
+    assert m.group(5) == '%08x' % fnv
