@@ -72,6 +72,10 @@ def main():
     ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl (= RCCL) in production; gloo only to rehearse the multi-rank flow')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='map every rank to cuda:0 (multi-rank control-flow rehearsal on a 1-GPU box; use with gloo)')
     ap.add_argument('--rollout', action='store_true',
                     help='state-only mode: run the K steps as ONE persistent-kernel launch (cw_rollout; actions known up front)')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the short dirty-cell / state-only side measurements')
@@ -89,11 +93,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)     # RCCL; used for the timing barrier/max only
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)     # RCCL; used for the timing barrier/max only
+        else:
+            dist.init_process_group('gloo')
 
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from gym_craftingworld_amd.sharding import max_over_ranks, shard_range
@@ -153,7 +162,7 @@ def main():
     run(K, W)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, device=dev)
+    elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == 'nccl' else 'cpu')
 
     # second, identical K-step region with the library's HIP events around each kernel (eager launches:
     # events cannot be re-recorded from inside a replayed graph)
