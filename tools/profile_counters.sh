@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU box only: where do cw_render_kernel's cycles go?  One --pmc pass per counter group (SQ: 8 slots,
+# TCC: 4 slots per pass), kernel-trace only beside it.
+set -e -o pipefail
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/counters
+rm -rf $OUT; mkdir -p $OUT
+i=0
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR" \
+         "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" \
+         "TCC_BUSY_sum TCC_TAG_STALL_sum TCC_WRITE_sum TCC_WRITEBACK_sum" \
+         "TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum TA_TA_BUSY_sum" \
+         "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python bench.py --no-cpu-baseline --no-other-modes --steps 60 --warmup 5 > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+done
+python - <<'PY'
+import csv, glob, os, collections, json
+out = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/counters'
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        if k.startswith('cw_'):
+            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+res = {k: {c: sorted(v)[len(v) // 2] for c, v in d.items()} for k, d in acc.items()}
+print(json.dumps(res, indent=1))
+PY
