@@ -550,3 +550,39 @@ def test_persistent_rollout_equals_stepping(case):
     assert np.array_equal(rew[:, :M].cpu().numpy(), o_rew) and np.array_equal(don[:, :M].cpu().numpy(), o_don.astype(bool))
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize('size,n_envs', [(21, 12288), (32, 4096), (9, 8192)])
+def test_reset_soak_vs_oracle(size, n_envs):
+    """Reset-heavy soak: max_steps=2 forces a reset of every env every other step, so the
+    lane-parallel rejection sampling, the token bookkeeping and imagine_obs are compared with the
+    oracle on >100 000 independent MT19937 streams/resets (placement, desired mask, goal state, agent,
+    final stream position)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    T = 16
+    kw = dict(size=(size, size), max_steps=2)
+    env = CraftingWorldVecEnv(n_envs, obs_mode='state', seed=77, **kw)
+    keys, pos = env.get_rng_states()
+    ora = OracleBatch(n_envs, rng_states=[(keys[i], int(pos[i])) for i in range(n_envs)], **kw)
+    env.reset()
+    ora.reset()
+    acts = np.random.RandomState(3).randint(0, 6, size=(T, n_envs)).astype(np.int8)
+    env.rollout(torch.as_tensor(acts.astype(np.uint8), device=env.device), record=False)   # persistent kernel: same reset code
+    total = ora.rollout(acts, nthreads=8)
+    assert total == T * n_envs
+    st = env.get_state()
+    k2, p2 = env.get_rng_states()
+    for i, s in enumerate(ora.states()):
+        assert np.array_equal(st['grid'][i], s['grid']), i
+        assert np.array_equal(st['init_grid'][i], s['init_grid']), i
+        assert np.array_equal(st['goal_grid'][i], s['goal_grid']), i
+        assert tuple(st['agent_rc'][i]) == s['agent'] and tuple(st['goal_agent_rc'][i]) == s['goal_agent'], i
+        assert st['desired'][i] == s['desired'] and st['ep_no'][i] == s['ep_no'], i
+    for i in range(0, n_envs, 97):
+        ok, op = ora.envs[i].get_rng()
+        assert p2[i] % 624 == op % 624, i
+        if op % 624:
+            assert np.array_equal(k2[i][1:], ok[1:]), i
+    assert int(env.counters[1].item()) == n_envs * (T // 2)
+    env.close()
