@@ -144,3 +144,43 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors='replace').read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, re.M), f
                 assert 'cw_oracle' not in txt and 'libcw_oracle' not in txt, f
+
+
+# ------------------------------------------------------------------ property tests (hypothesis)
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 2**32 - 1), burn=st.integers(0, 1400), draws=st.integers(1, 900))
+def test_mt_conversion_property(seed, burn, draws):
+    """For any numpy RandomState state: to engine form, consume `draws` words with the engine's
+    recurrence, export back -> numpy continues with the identical stream (and the raw words match)."""
+    from gym_craftingworld_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(seed)
+    if burn:
+        rs.randint(0, 2**32, size=burn, dtype=np.uint32)
+    state = rs.get_state()
+    s = state[1].astype(np.uint32).copy()
+    k = lib.cwh_mt_from_numpy(s.ctypes.data_as(C.c_void_p), int(state[2]))
+    ref = rs.randint(0, 2**32, size=draws, dtype=np.uint32)
+    got = np.empty(draws, dtype=np.uint32)
+    for i in range(draws):
+        got[i], k = _engine_next(s, k)
+    assert np.array_equal(ref, got)
+    key = np.empty(624, dtype=np.uint32)
+    lib.cwh_mt_to_numpy(s.ctypes.data_as(C.c_void_p), k, key.ctypes.data_as(C.c_void_p))
+    rs2 = np.random.RandomState()
+    rs2.set_state(('MT19937', key, k, 0, 0.0))
+    assert np.array_equal(rs.randint(0, 2**32, size=700, dtype=np.uint32), rs2.randint(0, 2**32, size=700, dtype=np.uint32))
+
+
+@settings(max_examples=200, deadline=None)
+@given(world=st.integers(1, 64), total=st.integers(1, 2**22))
+def test_shard_range_property(world, total):
+    from gym_craftingworld_amd.sharding import shard_range
+    r = [shard_range(g, world, total) for g in range(world)]
+    assert r[0][0] == 0 and r[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    sizes = [b - a for a, b in r]
+    assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
