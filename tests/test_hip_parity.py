@@ -586,3 +586,37 @@ def test_reset_soak_vs_oracle(size, n_envs):
             assert np.array_equal(k2[i][1:], ok[1:]), i
     assert int(env.counters[1].item()) == n_envs * (T // 2)
     env.close()
+
+
+def test_config4_shard_shape_mixed_menus_131072():
+    """BASELINE configs[3] as one rank sees it: 131 072 envs per GPU (1M over 8), env i using ordered
+    task menu i mod 8, full-frame pixels.  A strided sample of envs is replayed by the oracle."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T = 131072, 24
+    menus = [dict(selected_tasks=TASKS), dict(selected_tasks=TASKS[:3]), dict(selected_tasks=TASKS[3:], number_of_tasks=2),
+             dict(selected_tasks=['GoToHouse']), dict(selected_tasks=TASKS[::-1], stacking=False),
+             dict(selected_tasks=['MoveAxe', 'MoveHammer', 'MoveSticks'], reward_style='subset'),
+             dict(selected_tasks=['EatBread', 'MakeBread'], number_of_tasks=1), dict(selected_tasks=TASKS[1::2])]
+    env_menu = (np.arange(N) % len(menus)).astype(np.uint8)
+    kw = dict(size=(21, 21), max_steps=10)
+    env = CraftingWorldVecEnv(N, obs_mode='pixels', seed=4242, task_menus=menus, env_menu=env_menu, **kw)
+    keys, pos = env.get_rng_states()
+    sample = np.arange(0, N, 1021)[:128]
+    ora = OracleBatch(len(sample), rng_states=[(keys[i], int(pos[i])) for i in sample],
+                      per_env_kwargs=[menus[env_menu[i]] for i in sample], **kw)
+    env.reset()
+    ora.reset()
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    sidx = torch.as_tensor(sample, device='cuda')
+    for t in range(T):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.int32, generator=gen)
+        obs, rew, done, _ = env.step(a)
+        o_rew, o_done = ora.step(a[sidx].cpu().numpy())
+        assert np.array_equal(rew[sidx].cpu().numpy(), o_rew) and np.array_equal(done[sidx].cpu().numpy(), o_done), t
+    frames = obs['observation'][sidx].cpu().numpy()
+    goals = obs['desired_goal'][sidx].cpu().numpy()
+    for j, s in enumerate(ora.states()):
+        assert np.array_equal(frames[j], s['obs']) and np.array_equal(goals[j], s['desired_img']), sample[j]
+    assert int(env.counters[0].item()) == N * T and int(env.counters[1].item()) >= 2 * N
+    env.close()
