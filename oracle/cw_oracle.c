@@ -128,6 +128,44 @@ void cwo_get_rng(const cwo_env *e, uint32_t *key, int32_t *pos)
 }
 void cwo_seed_int(cwo_env *e, uint32_t seed) { mt_init_genrand(e, seed); }
 
+/* CPV_COLORS, craftingworld_altobs.py:26-27: pixel k of a cell's 3x3 tile is item k's flag colour
+ * (items: 8 objects, then the agent) */
+static const uint8_t CPV_COLORS[9][3] = {{45, 82, 160},  {255, 102, 102}, {204, 204, 0},  {211, 211, 211}, {34, 133, 34},
+                                         {0, 215, 255},  {153, 52, 255},  {10, 215, 100}, {0, 0, 255}};
+
+static size_t image_bytes(const cwo_config *c)
+{
+    const size_t s = (size_t)c->size;
+    return c->alt_obs ? (3 * s + 3) * (3 * s) * 3 : s * s * 48;
+}
+
+/* one cell's tile, altobs.py:527-543 / :625-634: pixel k = (item k present) + (k < 3 and held item k at this
+ * cell), times CPV_COLORS[k]; the reference keeps ints (up to 2 x colour), the uint8 view wraps modulo 256 */
+static void alt_tile(uint8_t *img, int size, int r, int c, int code, int agent_here, int hold)
+{
+    const int pw = size * 3;
+    for (int k = 0; k < 9; k++) {
+        int cnt = (k < 8) ? (code == k + 1) : agent_here;
+        if (agent_here && hold != 0 && k == hold - 1) cnt += 1;
+        uint8_t *p = img + ((size_t)(r * 3 + k / 3) * pw + (c * 3 + k % 3)) * 3;
+        for (int ch = 0; ch < 3; ch++) p[ch] = (uint8_t)(cnt * CPV_COLORS[k][ch]);
+    }
+}
+static void alt_hold_flag(uint8_t *img, int size, int hold)   /* altobs.py:557-559 / :640 */
+{
+    const int pw = size * 3;
+    for (int y = size * 3; y < size * 3 + 3; y++)
+        for (int x = 3; x < 6; x++) memset(img + ((size_t)y * pw + x) * 3, hold ? 255 : 0, 3);
+}
+
+void cwo_render_alt(int32_t size, const uint8_t *grid, int32_t ar, int32_t ac, int32_t hold, uint8_t *out)
+{
+    memset(out, 0, (size_t)(3 * size + 3) * (3 * size) * 3);
+    for (int r = 0; r < size; r++)
+        for (int c = 0; c < size; c++) alt_tile(out, size, r, c, grid[r * size + c], r == ar && c == ac, hold);
+    alt_hold_flag(out, size, hold);
+}
+
 /* ------------------------------------------------------------------ lifetime */
 cwo_env *cwo_new(const cwo_config *cfg)
 {
@@ -138,7 +176,7 @@ cwo_env *cwo_new(const cwo_config *cfg)
     e->cfg = *cfg;
     if (e->cfg.number_of_tasks > e->cfg.n_selected) e->cfg.number_of_tasks = e->cfg.n_selected;
     e->ncell = cfg->size * cfg->size;
-    size_t img = (size_t)e->ncell * 48;
+    size_t img = image_bytes(cfg);
     e->grid = (uint8_t *)calloc(e->ncell, 1);
     e->init_grid = (uint8_t *)calloc(e->ncell, 1);
     e->goal_grid = (uint8_t *)calloc(e->ncell, 1);
@@ -187,6 +225,12 @@ void cwo_render(int32_t size, const uint8_t *grid, int32_t ar, int32_t ac, int32
 /* render_edit, ray.py:522-557: repaint one cell of the persistent image in place */
 static void render_edit_cell(cwo_env *e, int r, int c)
 {
+    if (e->cfg.alt_obs) {                          /* altobs.py:625-640 */
+        const int here = (r == e->agent_r && c == e->agent_c);
+        alt_tile(e->obs, e->cfg.size, r, c, e->grid[r * e->cfg.size + c], here, e->hold);
+        if (here) alt_hold_flag(e->obs, e->cfg.size, e->hold);
+        return;
+    }
     const int size = e->cfg.size, pw = size * 4;
     const uint8_t *col = COLORS_N[e->grid[r * size + c]]; /* np.dot(onehot[:8], COLORS_M), :550 */
     for (int dy = 0; dy < 4; dy++)
@@ -307,7 +351,8 @@ static void imagine_obs(cwo_env *e)
     }
     e->goal_agent_r = agent / size;
     e->goal_agent_c = agent % size;
-    cwo_render(size, f, e->goal_agent_r, e->goal_agent_c, 0, e->desired_img); /* :299 */
+    if (e->cfg.alt_obs) cwo_render_alt(size, f, e->goal_agent_r, e->goal_agent_c, 0, e->desired_img);
+    else cwo_render(size, f, e->goal_agent_r, e->goal_agent_c, 0, e->desired_img); /* :299 */
 }
 
 /* ------------------------------------------------------------------ reset, ray.py:156-218 */
@@ -339,8 +384,9 @@ void cwo_reset(cwo_env *e)
     e->hold = 0;
     memcpy(e->init_grid, e->grid, n);                            /* :183 */
     imagine_obs(e);                                              /* :191 */
-    cwo_render(size, e->grid, e->agent_r, e->agent_c, 0, e->obs); /* :192 */
-    memcpy(e->init_img, e->obs, (size_t)n * 48);                 /* :193 */
+    if (c->alt_obs) cwo_render_alt(size, e->grid, e->agent_r, e->agent_c, 0, e->obs);
+    else cwo_render(size, e->grid, e->agent_r, e->agent_c, 0, e->obs); /* :192 */
+    memcpy(e->init_img, e->obs, image_bytes(c));                 /* :193 */
     if (e->step_num != 0) e->ep_no += 1;                         /* :200-201 */
     e->step_num = 0;                                             /* :203 */
 }
@@ -472,7 +518,8 @@ void cwo_set_state(cwo_env *e, const uint8_t *grid, const uint8_t *init_grid, in
     e->agent_r = agent_r; e->agent_c = agent_c; e->hold = hold;
     e->init_agent_r = -1; e->init_agent_c = -1; /* injected states carry no agent start cell */
     e->achieved = achieved; e->desired = desired; e->step_num = step_num;
-    cwo_render(e->cfg.size, e->grid, agent_r, agent_c, hold, e->obs);
+    if (e->cfg.alt_obs) cwo_render_alt(e->cfg.size, e->grid, agent_r, agent_c, hold, e->obs);
+    else cwo_render(e->cfg.size, e->grid, agent_r, agent_c, hold, e->obs);
 }
 
 int64_t cwo_batch_rollout(cwo_env **envs, int32_t n, const int8_t *actions, int32_t T,

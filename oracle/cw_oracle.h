@@ -40,6 +40,8 @@ typedef struct cwo_config {
     int32_t number_of_tasks;   /* already clamped to n_selected, ray.py:79-81 */
     int32_t fixed_init_state;  /* 0 = sample a fresh placement every reset, ray.py:116-118 */
     int32_t selected_bits[CWO_MAX_TASKS]; /* task_list.index(selected_tasks[i]), ray.py:174 */
+    int32_t alt_obs;           /* 1: CraftingWorldEnvAltObs rasteriser (craftingworld_altobs.py:489-642): 3x3 px per cell,
+                                * images are [(3*size+3)][3*size][3] */
 } cwo_config;
 
 typedef struct cwo_env cwo_env;
@@ -79,6 +81,10 @@ void cwo_get_view(const cwo_env *e, cwo_view *v);
 void cwo_set_state(cwo_env *e, const uint8_t *grid, const uint8_t *init_grid, int32_t agent_r,
                    int32_t agent_c, int32_t hold, uint32_t achieved, uint32_t desired,
                    int32_t step_num);
+/* craftingworld_altobs.py:489-595 render(state): out[(3s+3)*3s*3], values modulo 256 (the reference's int
+ * image reaches 2 x colour when the agent holds sticks on a sticks cell) */
+void cwo_render_alt(int32_t size, const uint8_t *grid, int32_t agent_r, int32_t agent_c, int32_t hold,
+                    uint8_t *out);
 /* ray.py:442-520 render(state): full frame from (grid, agent, hold) into out[4s*4s*3] */
 void cwo_render(int32_t size, const uint8_t *grid, int32_t agent_r, int32_t agent_c, int32_t hold,
                 uint8_t *out);

@@ -25,7 +25,7 @@ class _Config(C.Structure):
     _fields_ = [('size', C.c_int32), ('max_steps', C.c_int32), ('reward_subset', C.c_int32),
                 ('stacking', C.c_int32), ('n_task_list', C.c_int32), ('n_selected', C.c_int32),
                 ('number_of_tasks', C.c_int32), ('fixed_init_state', C.c_int32),
-                ('selected_bits', C.c_int32 * MAX_TASKS)]
+                ('selected_bits', C.c_int32 * MAX_TASKS), ('alt_obs', C.c_int32)]
 
 
 class _View(C.Structure):
@@ -86,8 +86,8 @@ def _bits_to_vec(bits, n):
 
 
 def make_config(size=(21, 21), fixed_init_state=0, max_steps=300, task_list=TASK_LIST,
-                selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True, reward_style=None):
-    """Reference ctor kwargs (ray.py:59-60) -> cwo_config."""
+                selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True, reward_style=None, alt_obs=False):
+    """Reference ctor kwargs (ray.py:59-60; alt_obs selects CraftingWorldEnvAltObs's rasteriser) -> cwo_config."""
     w, h = size
     if w != h:
         raise ValueError('non-square grids are a reference defect (SURVEY.md §8a) and are rejected')
@@ -101,6 +101,7 @@ def make_config(size=(21, 21), fixed_init_state=0, max_steps=300, task_list=TASK
     n = number_of_tasks if number_of_tasks is not None else len(selected_tasks)
     cfg.number_of_tasks = min(n, len(selected_tasks))    # ray.py:79-81
     cfg.fixed_init_state = fixed_init_state
+    cfg.alt_obs = 1 if alt_obs else 0
     for i, t in enumerate(selected_tasks):
         cfg.selected_bits[i] = list(task_list).index(t)  # ray.py:174
     return cfg
@@ -116,6 +117,8 @@ class OracleEnv:
         if not self._h:
             raise ValueError('cwo_new rejected the config')
         self.size = self.cfg.size
+        self.img_shape = ((3 * self.cfg.size + 3, 3 * self.cfg.size, 3) if self.cfg.alt_obs else
+                          (4 * self.cfg.size, 4 * self.cfg.size, 3))
         self.MAX_STEPS = self.cfg.max_steps
         self.n_task_list = self.cfg.n_task_list
         if rng_state is not None:
@@ -166,21 +169,21 @@ class OracleEnv:
     def state(self):
         """Copies of everything the parity tests compare."""
         v = self.view()
-        s, px = self.size, self.size * 4
+        s, ish = self.size, self.img_shape
         return dict(grid=self._arr(v.grid, (s, s)).copy(), init_grid=self._arr(v.init_grid, (s, s)).copy(),
                     goal_grid=self._arr(v.goal_grid, (s, s)).copy(),
                     agent=(v.agent_r, v.agent_c), hold=v.hold, goal_agent=(v.goal_agent_r, v.goal_agent_c),
                     achieved=v.achieved, desired=v.desired, step_num=v.step_num, ep_no=v.ep_no,
-                    obs=self._arr(v.obs, (px, px, 3)).copy(),
-                    desired_img=self._arr(v.desired_img, (px, px, 3)).copy(),
-                    init_img=self._arr(v.init_img, (px, px, 3)).copy())
+                    obs=self._arr(v.obs, ish).copy(),
+                    desired_img=self._arr(v.desired_img, ish).copy(),
+                    init_img=self._arr(v.init_img, ish).copy())
 
     def _obs_dict(self, v=None):
         v = v or self.view()
-        px = self.size * 4
-        o = self._arr(v.obs, (px, px, 3))
-        return {'observation': o, 'desired_goal': self._arr(v.desired_img, (px, px, 3)),
-                'achieved_goal': o, 'init_observation': self._arr(v.init_img, (px, px, 3))}
+        ish = self.img_shape
+        o = self._arr(v.obs, ish)
+        return {'observation': o, 'desired_goal': self._arr(v.desired_img, ish),
+                'achieved_goal': o, 'init_observation': self._arr(v.init_img, ish)}
 
     def reset(self):
         self._lib.cwo_reset(self._h)

@@ -12,7 +12,7 @@ from oracle import OracleEnv
 @pytest.mark.parametrize('name', fixture_names())
 def test_oracle_matches_reference_fixture(name):
     meta, kw, g = load(name)
-    env = OracleEnv(rng_state=(g['key0'], int(g['pos0'])), **kw)
+    env = OracleEnv(rng_state=(g['key0'], int(g['pos0'])), alt_obs=(meta['env'] == 'CraftingWorldEnvAltObs'), **kw)
     size = kw['size'][0]
     ri = 0
 

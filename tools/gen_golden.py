@@ -42,9 +42,16 @@ SCENARIOS = [
     ('ray32_scripted',    dict(size=(32, 32), max_steps=300),                    3232,  1500, 'scripted', 1),
     ('ray4_tiny',         dict(size=(4, 4), max_steps=30),                       404,   3000, 'random',   1),
 ]
+# CraftingWorldEnvAltObs (craftingworld_altobs.py): same dynamics, 3x3-px CPV rasteriser; images are stored
+# as uint8 views (the reference's int image reaches 2 x colour when the agent holds sticks on a sticks cell)
+ALT_SCENARIOS = [
+    ('alt21_scripted',    dict(size=(21, 21)),                                   2121,  1500, 'scripted', 2),
+    ('alt5_random',       dict(size=(5, 5), max_steps=40),                       55,    4000, 'random',   2),
+    ('alt8_scripted',     dict(size=(8, 8), max_steps=60, reward_style='subset'), 88,   3000, 'scripted', 1),
+]
 
 
-def capture(cls, kwargs, seed, steps, policy, keep_images):
+def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWorldEnvRay'):
     rng = np.random.RandomState(seed)
     st = rng.get_state()
     key0, pos0 = st[1].copy(), int(st[2])
@@ -107,7 +114,7 @@ def capture(cls, kwargs, seed, steps, policy, keep_images):
     out = dict(
         meta=np.frombuffer(json.dumps(dict(kwargs=kw, seed=seed, steps=steps, policy=policy,
                                            n_success=n_success, n_resets=len(R['desired']),
-                                           env='CraftingWorldEnvRay')).encode(), dtype=np.uint8),
+                                           env=env_name)).encode(), dtype=np.uint8),
         key0=key0.astype(np.uint32), pos0=np.int32(pos0),
         action=np.array(S['action'], np.int8), reward=np.array(S['reward'], np.int32),
         done=np.array(S['done'], np.uint8), achieved=np.array(S['achieved'], np.uint16),
@@ -131,8 +138,9 @@ def capture(cls, kwargs, seed, steps, policy, keep_images):
 def main():
     classes = import_reference()
     os.makedirs(OUT, exist_ok=True)
-    for name, kwargs, seed, steps, policy, keep in SCENARIOS:
-        out, n_success = capture(classes['ray'], kwargs, seed, steps, policy, keep)
+    todo = [(sc, 'ray', 'CraftingWorldEnvRay') for sc in SCENARIOS] + [(sc, 'altobs', 'CraftingWorldEnvAltObs') for sc in ALT_SCENARIOS]
+    for (name, kwargs, seed, steps, policy, keep), key, env_name in todo:
+        out, n_success = capture(classes[key], kwargs, seed, steps, policy, keep, env_name)
         path = os.path.join(OUT, name + '.npz')
         np.savez_compressed(path, **out)
         ach = np.bitwise_or.reduce(out['achieved']) if len(out['achieved']) else 0

@@ -21,8 +21,10 @@ def import_reference():
             sys.path.insert(0, p)
     import gym  # noqa: F401  (the stub)
     import gym_craftingworld  # noqa: F401  (registers the ids)
-    from gym_craftingworld.envs import CraftingWorldEnvRay, CraftingWorldEnvFlat, CraftingWorldEnvOneHot
-    return dict(ray=CraftingWorldEnvRay, flat=CraftingWorldEnvFlat, onehot=CraftingWorldEnvOneHot)
+    from gym_craftingworld.envs import (CraftingWorldEnvAltObs, CraftingWorldEnvFlat, CraftingWorldEnvOneHot,
+                                        CraftingWorldEnvRay)
+    return dict(ray=CraftingWorldEnvRay, flat=CraftingWorldEnvFlat, onehot=CraftingWorldEnvOneHot,
+                altobs=CraftingWorldEnvAltObs)
 
 
 def make_ref_env(cls, rng, **kwargs):
