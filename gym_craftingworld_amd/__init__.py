@@ -7,7 +7,7 @@ gym.vector.VectorEnv-shaped surface for N envs, hand-written HIP kernels underne
 built library; constructing an env needs both (there is no CPU fallback).
 """
 from .vec_env import ACTION_NAMES, OBJECTS, PICKUPABLE, TASK_LIST, CraftingWorldVecEnv  # noqa: F401
-from .env import CraftingWorldEnv, CraftingWorldEnvFlat, CraftingWorldEnvOneHot  # noqa: F401
+from .env import CraftingWorldEnv, CraftingWorldEnvAltObs, CraftingWorldEnvFlat, CraftingWorldEnvOneHot  # noqa: F401
 from ._lib import CraftingWorldError  # noqa: F401
 from .adapters import GymnasiumVecAdapter, MultiDeviceVecEnv  # noqa: F401
 

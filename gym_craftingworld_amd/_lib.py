@@ -18,6 +18,7 @@ CW_MAX_MENUS = 256
 CW_OK, CW_ERR_INVALID, CW_ERR_HIP, CW_ERR_STATE = 0, -1, -2, -3
 CW_OBS_STATE, CW_OBS_PIXELS_FULL, CW_OBS_PIXELS_DIRTY = 0, 1, 2
 CW_ACT_I32, CW_ACT_I64, CW_ACT_U8 = 0, 1, 2
+CW_RASTER_RAY, CW_RASTER_ALT = 0, 1
 
 
 class cw_task_menu(C.Structure):
@@ -29,7 +30,7 @@ class cw_config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('size', C.c_int32),
                 ('max_steps', C.c_int32), ('n_task_list', C.c_int32), ('fixed_init_state', C.c_int32),
                 ('obs_mode', C.c_int32), ('auto_reset', C.c_int32), ('keep_terminal_obs', C.c_int32),
-                ('n_menus', C.c_int32),
+                ('raster', C.c_int32), ('n_menus', C.c_int32),
                 ('menus', C.POINTER(cw_task_menu)), ('env_menu', C.POINTER(C.c_uint8))]
 
 

@@ -168,6 +168,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (cfg->fixed_init_state < 0 || cfg->fixed_init_state > 64)
         return fail(CW_ERR_INVALID, "cw_create: fixed_init_state must be in 0..64");
     if (cfg->obs_mode < CW_OBS_STATE || cfg->obs_mode > CW_OBS_PIXELS_DIRTY) return fail(CW_ERR_INVALID, "cw_create: bad obs_mode");
+    if (cfg->raster != CW_RASTER_RAY && cfg->raster != CW_RASTER_ALT) return fail(CW_ERR_INVALID, "cw_create: bad raster");
     if (cfg->n_menus < 1 || cfg->n_menus > CW_MAX_MENUS || !cfg->menus) return fail(CW_ERR_INVALID, "cw_create: n_menus must be in 1..%d", CW_MAX_MENUS);
     if ((double)cfg->num_envs * 48.0 * cfg->size * cfg->size > 1.0e12)
         return fail(CW_ERR_INVALID, "cw_create: num_envs x frame size exceeds 1 TB");
@@ -219,7 +220,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.task_mask = (1u << cfg->n_task_list) - 1u;
     P.pool_k = e->K;
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
-    P.frame_bytes = 48u * (uint32_t)e->ncell;
+    P.raster = cfg->raster;
+    P.frame_bytes = cfg->raster == CW_RASTER_ALT ? 27u * (uint32_t)e->S * (uint32_t)(e->S + 1) : 48u * (uint32_t)e->ncell;
     {   // experiment knobs; the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);

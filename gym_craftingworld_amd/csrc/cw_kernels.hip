@@ -109,6 +109,68 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
     }
 }
 
+// ------------------------------------------------------------------------------------ AltObs rasteriser
+// CraftingWorldEnvAltObs (craftingworld_altobs.py:489-642): 3x3 px per cell; pixel k of the tile carries
+// CPV_COLORS[k] (altobs.py:26-27) times the number of items k in the cell, items = 8 objects + agent, the
+// held object counted on its own object pixel at the agent cell (so sticks held over sticks give 2 x colour:
+// the reference's int image, here modulo 256).  Frame = [3S+3][3S][3] bytes; the last 3 pixel rows are a
+// strip whose pixels 1..1 (bytes 9..17 of each row) are white while something is held (altobs.py:557-559).
+// 27*S*(S+1) bytes is even but not a multiple of 4 and rows are 9S bytes, so tiles are written bytewise.
+__device__ __forceinline__ uint32_t cpv_color(int k)       // R | G<<8 | B<<16
+{
+    return k == 0 ? (45u | (82u << 8) | (160u << 16)) : k == 1 ? (255u | (102u << 8) | (102u << 16))
+         : k == 2 ? (204u | (204u << 8)) : k == 3 ? (211u | (211u << 8) | (211u << 16))
+         : k == 4 ? (34u | (133u << 8) | (34u << 16)) : k == 5 ? ((215u << 8) | (255u << 16))
+         : k == 6 ? (153u | (52u << 8) | (255u << 16)) : k == 7 ? (10u | (215u << 8) | (100u << 16)) : (255u << 16);
+}
+__device__ __forceinline__ void alt_paint_tile(uint8_t *frame, int S, uint32_t r, uint32_t c, uint32_t code,
+                                               bool agent_here, uint32_t hold)
+{
+    const uint32_t row_bytes = 9u * S;
+    uint8_t *p = frame + (size_t)(3u * r) * row_bytes + 9u * c;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t cnt = (k < 8) ? (code == (uint32_t)(k + 1) ? 1u : 0u) : (agent_here ? 1u : 0u);
+        if (k < 3) cnt += (agent_here && hold == (uint32_t)(k + 1)) ? 1u : 0u;
+        const uint32_t col = cpv_color(k);
+        uint8_t *q = p + (k / 3) * row_bytes + (k % 3) * 3;
+        q[0] = (uint8_t)(cnt * (col & 0xFFu));
+        q[1] = (uint8_t)(cnt * ((col >> 8) & 0xFFu));
+        q[2] = (uint8_t)(cnt * ((col >> 16) & 0xFFu));
+    }
+}
+// the "holding" strip: 3 rows x 9S bytes after the grid; `first`/`step` let one lane or a whole wave write it
+__device__ __forceinline__ void alt_paint_strip(uint8_t *frame, int S, uint32_t hold, uint32_t first, uint32_t step,
+                                                bool whole)
+{
+    const uint32_t row_bytes = 9u * S;
+    uint8_t *p = frame + (size_t)(3u * S) * row_bytes;
+    if (whole) {
+        for (uint32_t b = first; b < 3u * row_bytes; b += step) {
+            const uint32_t x = b % row_bytes;
+            p[b] = (hold != 0 && x >= 9u && x < 18u) ? 255 : 0;
+        }
+    } else {      // only the 27 flag bytes (the rest of the strip never changes)
+        for (uint32_t j = first; j < 27u; j += step) p[(j / 9u) * row_bytes + 9u + (j % 9u)] = hold ? 255 : 0;
+    }
+}
+__device__ __forceinline__ void render_frame_alt(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
+                                                 uint32_t div_magic, const uint32_t sp[8], uint32_t codes,
+                                                 uint32_t agent_cell, uint32_t hold, int lane)
+{
+    for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
+        const uint32_t r = __umulhi(cell, div_magic);
+        const uint32_t c = cell - r * S;
+        uint32_t code = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) code = (cell == sp[k]) ? ((codes >> (4 * k)) & 15u) : code;
+        alt_paint_tile(dst0, S, r, c, code, cell == agent_cell, hold);
+        if (dst1) alt_paint_tile(dst1, S, r, c, code, cell == agent_cell, hold);
+    }
+    alt_paint_strip(dst0, S, hold, lane, CW_WAVE, true);
+    if (dst1) alt_paint_strip(dst1, S, hold, lane, CW_WAVE, true);
+}
+
 // ------------------------------------------------------------------------------------ step
 // One env's step() on registers (ray.py:301-378).  Shared by cw_step_kernel (one launch per step)
 // and cw_rollout_kernel (T steps in one persistent launch).
@@ -270,9 +332,19 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
             uint8_t *frame = P.obs + (size_t)i * P.frame_bytes;
             const uint32_t hold = (h.x >> 16) & 0xFFu;
             const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
-            paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
-            if (o.dirty1 != 0xFFFFFFFFu)
-                paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+            if (P.raster == 1) {                                           // altobs.py:625-640
+                const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
+                alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
+                if (o.dirty1 != 0xFFFFFFFFu) {
+                    const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
+                    alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
+                }
+                alt_paint_strip(frame, P.size, hold, 0, 1, false);
+            } else {
+                paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+                if (o.dirty1 != 0xFFFFFFFFu)
+                    paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+            }
         }
     }
 
@@ -802,7 +874,8 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     const size_t off = (size_t)cur_env * P.frame_bytes;
     uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
-    render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
+    if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane);
+    else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
     if (three) {                                             // desired_goal = render(final_state), ray.py:299
         uint32_t gp[8], grgb[8];
         const u32x4s gpp = cload((const u32x4s *)(P.goal_pos + cur_env));
@@ -812,7 +885,8 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
         const uint32_t ga = (gaw >> (16 * (cur_env & 1))) & 0xFFFFu;
 #pragma unroll
         for (int k = 0; k < 8; k++) grgb[k] = rgb_of_code((gc >> (4 * k)) & 15u);
-        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
+        if (P.raster == 1) render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, gc, ga, 0u, lane);
+        else render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
     }
 }
 

@@ -77,6 +77,7 @@ struct CwParams {
     uint32_t task_mask;      // (1 << n_task_list) - 1
     int32_t pool_k;          // fixed_init_state
     uint32_t div_magic;      // floor(2^32 / S) + 1 : x / S == mulhi(x, magic) for x < 2^18
-    uint32_t frame_bytes;    // 48 * S * S
+    uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
+    int32_t raster;          // CW_RASTER_*
     int32_t tune_reset_prio; // 1: reset waves raise their priority (s_setprio 3)
 };

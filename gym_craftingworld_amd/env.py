@@ -22,6 +22,8 @@ class CraftingWorldEnv:
     _default_size = (21, 21)
     _default_max_steps = 300
 
+    _raster = 'ray'
+
     def __init__(self, size=None, fixed_init_state=0, max_steps=None, store_gif=False, render_save_rate=1,
                  task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True,
                  reward_style=None, device=None, reference_dtypes=False, seed=None):
@@ -31,7 +33,8 @@ class CraftingWorldEnv:
                                         store_gif=store_gif, render_save_rate=render_save_rate, task_list=task_list,
                                         selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
                                         stacking=stacking, reward_style=reward_style, obs_mode='pixels_dirty',
-                                        device=device, seed=seed, seed_style='gym', auto_reset=False)
+                                        device=device, seed=seed, seed_style='gym', auto_reset=False,
+                                        raster=self._raster)
         v = self._vec
         self.STATE_W, self.STATE_H = v.STATE_W, v.STATE_H
         self.MAX_STEPS = v.MAX_STEPS
@@ -39,8 +42,8 @@ class CraftingWorldEnv:
         self.number_of_tasks, self.stacking = v.number_of_tasks, stacking
         self.fixed_init_state = fixed_init_state
         self._dtype = np.int64 if reference_dtypes else np.uint8
-        P = 4 * v.size
-        img = lambda: Box(low=0, high=255, shape=(P, P, 3), dtype=self._dtype)  # noqa: E731
+        fs = v.frame_shape
+        img = lambda: Box(low=0, high=255, shape=fs, dtype=self._dtype)  # noqa: E731
         self.observation_space = Dict(dict(observation=img(), desired_goal=img(), achieved_goal=img(),
                                            init_observation=img()))                # ray.py:85-92
         self.observation_vector_space = v.observation_vector_space                # ray.py:94-110
@@ -48,9 +51,9 @@ class CraftingWorldEnv:
         self.ACTIONS = list(ACTION_NAMES)
         self.ep_no = 0
         self.step_num = 0
-        self.obs_image = np.zeros((P, P, 3), self._dtype)
-        self.desired_goal = np.zeros((P, P, 3), self._dtype)
-        self.INIT_OBS = np.zeros((P, P, 3), self._dtype)
+        self.obs_image = np.zeros(fs, self._dtype)
+        self.desired_goal = np.zeros(fs, self._dtype)
+        self.INIT_OBS = np.zeros(fs, self._dtype)
         self.observation = None
         self.desired_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)  # ray.py:112
         self.achieved_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)
@@ -197,3 +200,28 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
         _, r, d, info = super().step(action)
         self._oh[...] = self._vec.one_hot()[0].cpu().numpy()                     # onehot.py:369-371
         return self._oh_dict(), r, d, info
+
+
+class CraftingWorldEnvAltObs(CraftingWorldEnv):
+    """craftingworld_altobs.py:85-886 (exported by the reference, not registered): same dynamics, 3x3-px CPV
+    rasteriser with a "holding" strip, images ((W+1)*3, H*3, 3); stacked_obs=True returns the four images
+    stacked (4, ., ., 3) instead of the Dict (altobs.py:116-119, 258-261, 408-412).  Pixel values are the
+    reference's int image modulo 256 (it reaches 2 x colour when sticks are held over sticks)."""
+    _raster = 'alt'
+
+    def __init__(self, *a, stacked_obs=False, **kw):
+        super().__init__(*a, **kw)
+        self.stacked_obs = stacked_obs
+        if stacked_obs is True:
+            self.observation_space = Box(low=0, high=255, shape=(4,) + self._vec.frame_shape, dtype=self._dtype)
+
+    def _stack(self, o):
+        return np.stack([o['observation'], o['desired_goal'], o['achieved_goal'], o['init_observation']])
+
+    def reset(self, render_next=False):
+        o = super().reset()
+        return self._stack(o) if self.stacked_obs is True else o
+
+    def step(self, action):
+        o, r, d, info = super().step(action)
+        return (self._stack(o) if self.stacked_obs is True else o), r, d, info

@@ -53,6 +53,7 @@ class CraftingWorldVecEnv:
     render_edit strategy | 'state' no pixel buffers), device, seed, seed_style, auto_reset,
     task_menus + env_menu (heterogeneous ordered task lists: env i uses task_menus[env_menu[i]],
     each menu a dict with any of selected_tasks / number_of_tasks / stacking / reward_style),
+    raster ('ray' = CraftingWorldEnvRay's 4x4 colour tiles, 'alt' = CraftingWorldEnvAltObs's 3x3 CPV tiles),
     keep_terminal_obs (pixel modes: info['terminal_observation'] holds the last frame of every episode
     that ended this step, as gym.vector does, at the cost of one extra frame write per finished env).
     """
@@ -63,12 +64,14 @@ class CraftingWorldVecEnv:
                  render_save_rate=1, task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None,
                  stacking=True, reward_style=None, obs_mode='pixels', device=None, seed=None,
                  seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None,
-                 keep_terminal_obs=False):
+                 keep_terminal_obs=False, raster='ray'):
         if store_gif:
             raise NotImplementedError('the GIF episode recorder (ray.py:565-597) is host-side debug I/O, out of scope')
         w, h = size
         if w != h:
             raise ValueError('non-square grids raise IndexError in the reference (SURVEY.md §8a); rejected')
+        if raster not in ('ray', 'alt'):
+            raise ValueError("raster must be 'ray' (4x4 colour tiles) or 'alt' (CraftingWorldEnvAltObs 3x3 CPV tiles)")
         if obs_mode not in _OBS_MODES:
             raise ValueError('obs_mode must be one of %s' % sorted(_OBS_MODES))
         if not torch.cuda.is_available():
@@ -110,6 +113,8 @@ class CraftingWorldVecEnv:
         cfg.obs_mode = _OBS_MODES[obs_mode]
         cfg.auto_reset = 1 if self.auto_reset else 0
         cfg.keep_terminal_obs = 1 if (keep_terminal_obs and obs_mode != 'state') else 0
+        cfg.raster = L.CW_RASTER_ALT if raster == 'alt' else L.CW_RASTER_RAY
+        self.raster = raster
         cfg.n_menus = len(menus)
         cfg.menus = self._menus
         cfg.env_menu = env_menu.ctypes.data_as(C.POINTER(C.c_uint8)) if env_menu is not None else None
@@ -120,12 +125,16 @@ class CraftingWorldVecEnv:
         # zero-copy views of the engine's buffers
         tab = L.cw_buffer_table()
         L.check(self._lib.cw_buffers(self._h, C.byref(tab)), 'cw_buffers')
-        N, P, di = self.num_envs, 4 * self.size, self.device.index
+        N, di = self.num_envs, self.device.index
+        # frame geometry: ray.py:84 (4W,4H,3) / craftingworld_altobs.py:115 ((W+1)*3, H*3, 3)
+        self.frame_shape = (3 * self.size + 3, 3 * self.size, 3) if raster == 'alt' else (4 * self.size, 4 * self.size, 3)
+        fs = (N,) + self.frame_shape
+        assert tab.frame_bytes == fs[1] * fs[2] * fs[3]
         v = lambda p, shape, dt: tensor_view(p, shape, dt, di)  # noqa: E731
-        self._obs = v(tab.obs, (N, P, P, 3), torch.uint8)
-        self._desired_img = v(tab.desired_goal, (N, P, P, 3), torch.uint8)
-        self._init_img = v(tab.init_obs, (N, P, P, 3), torch.uint8)
-        self.terminal_observation = v(tab.terminal_obs, (N, P, P, 3), torch.uint8)   # None unless keep_terminal_obs
+        self._obs = v(tab.obs, fs, torch.uint8)
+        self._desired_img = v(tab.desired_goal, fs, torch.uint8)
+        self._init_img = v(tab.init_obs, fs, torch.uint8)
+        self.terminal_observation = v(tab.terminal_obs, fs, torch.uint8)   # None unless keep_terminal_obs
         self.reward = v(tab.reward, (N,), torch.int32)
         self._done_u8 = v(tab.done, (N,), torch.uint8)
         self.done = self._done_u8.view(torch.bool)
@@ -138,7 +147,7 @@ class CraftingWorldVecEnv:
         self.agent_rc = self.hdr[:, 0:2]
         self.hold = self.hdr[:, 2]
 
-        pix = (P, P, 3)
+        pix = self.frame_shape
         self.single_action_space = Discrete(len(ACTION_NAMES))       # ray.py:133
         self.action_space = MultiDiscrete([len(ACTION_NAMES)] * N)
         if obs_mode == 'state':
@@ -269,9 +278,8 @@ class CraftingWorldVecEnv:
     # ------------------------------------------------------------------ views / checkpoints
     def render(self, out=None):
         """render() of ray.py:442-520 for every env -> uint8 [N,4S,4S,3] (works in every obs_mode)."""
-        P = 4 * self.size
         if out is None:
-            out = torch.empty((self.num_envs, P, P, 3), dtype=torch.uint8, device=self.device)
+            out = torch.empty((self.num_envs,) + self.frame_shape, dtype=torch.uint8, device=self.device)
         L.check(self._lib.cw_render(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_render')
         return out
 

@@ -46,6 +46,14 @@ enum {
     CW_OBS_PIXELS_DIRTY = 2  /* render_edit(): persistent frame, <=2 changed cells repainted, ray.py:522-557 */
 };
 
+/* rasterisers (cw_config.raster) */
+enum {
+    CW_RASTER_RAY = 0,  /* CraftingWorldEnvRay: 4x4 px per cell in the object's colour, frames [4S][4S][3]   (ray.py:442-557) */
+    CW_RASTER_ALT = 1   /* CraftingWorldEnvAltObs: 3x3 px per cell, pixel k lit with CPV_COLORS[k] iff item k is in the
+                         * cell, + a 3-px strip with a "holding" flag: frames [3S+3][3S][3] (craftingworld_altobs.py:489-642);
+                         * values are the reference's int image modulo 256 */
+};
+
 /* action dtypes accepted by cw_step */
 enum { CW_ACT_I32 = 0, CW_ACT_I64 = 1, CW_ACT_U8 = 2 };
 
@@ -73,6 +81,7 @@ typedef struct cw_config {
                                  * 0: finished envs keep stepping until cw_reset (single gym.Env semantics, ray.py:367) */
     int32_t keep_terminal_obs;  /* 1 (pixel modes + auto_reset): before a finished env is reset, its last frame is
                                  * painted into cw_buffer_table.terminal_obs (gym.vector's info["terminal_observation"]) */
+    int32_t raster;             /* CW_RASTER_* (pixel modes) */
     int32_t n_menus;            /* 1..CW_MAX_MENUS */
     const cw_task_menu *menus;  /* host array [n_menus] */
     const uint8_t *env_menu;    /* host array [num_envs] of menu ids, or NULL (= all envs use menu 0) */
@@ -99,7 +108,7 @@ typedef struct cw_buffer_table {
                               *   bytes 12-15 the 8 object slots' codes, 4 bits each (slot k in bits 4k..4k+3)      */
     uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
     uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
-    size_t frame_bytes;      /* P*P*3 */
+    size_t frame_bytes;      /* P*P*3 (CW_RASTER_RAY) or (3S+3)*3S*3 (CW_RASTER_ALT) */
 } cw_buffer_table;
 
 /* Host-side dense snapshot for parity injection / checkpointing (cw_get_state, cw_set_state).

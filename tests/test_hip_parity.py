@@ -35,7 +35,7 @@ def _hdr_fields(hdr):
 def test_golden_fixture_replay(name, obs_mode):
     from gym_craftingworld_amd import CraftingWorldVecEnv
     meta, kw, g = load(name)
-    env = CraftingWorldVecEnv(1, obs_mode=obs_mode, seed=0, **kw)
+    env = CraftingWorldVecEnv(1, obs_mode=obs_mode, seed=0, raster='alt' if meta['env'] == 'CraftingWorldEnvAltObs' else 'ray', **kw)
     env.set_rng_states(g['key0'][None], np.array([g['pos0']]))
     if kw.get('fixed_init_state'):
         # the pool is drawn from the env RNG at construction (ray.py:116-118): redo it on the injected stream
@@ -619,4 +619,46 @@ def test_config4_shard_shape_mixed_menus_131072():
     for j, s in enumerate(ora.states()):
         assert np.array_equal(frames[j], s['obs']) and np.array_equal(goals[j], s['desired_img']), sample[j]
     assert int(env.counters[0].item()) == N * T and int(env.counters[1].item()) >= 2 * N
+    env.close()
+
+
+@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty'])
+def test_altobs_raster_vs_oracle(obs_mode):
+    """the AltObs rasteriser (3x3-px CPV tiles + holding strip) in both pixel modes
+    vs the oracle: all three frames, cw_render, terminal frames; includes sticks held over sticks (2 x colour)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, kw = 200, 90, dict(size=(6, 6), max_steps=30)
+    keys, pos = _np_states(N, 6060)
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, raster='alt', keep_terminal_obs=True, **kw)
+    env.set_rng_states(keys, pos)
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), alt_obs=True, **kw)
+    obs = env.reset()
+    ora.reset()
+    assert tuple(obs['observation'].shape) == (N, 21, 18, 3)
+    acts = np.random.RandomState(2).randint(0, 6, size=(T, N)).astype(np.int32)
+    dacts = torch.as_tensor(acts, device=env.device)
+    for t in range(T):
+        obs, rew, done, info = env.step(dacts[t])
+        term = info['terminal_observation'].cpu().numpy() if (t % 9 == 0) else None
+        d = done.cpu().numpy()
+        for i, e in enumerate(ora.envs):
+            o, r, dd, _ = e.step(int(acts[t, i]))
+            assert dd == d[i] and r == int(rew[i].item()) if t % 9 == 0 else dd == d[i]
+            if dd:
+                if term is not None:
+                    assert np.array_equal(term[i], o['observation']), (t, i)
+                e.reset()
+        if t % 9 == 0 or t == T - 1:
+            cur, des, ini, ren = (x.cpu().numpy() for x in (obs['observation'], obs['desired_goal'], obs['init_observation'], env.render()))
+            for i, s in enumerate(ora.states()):
+                assert np.array_equal(cur[i], s['obs']), (t, i)
+                assert np.array_equal(ren[i], s['obs']), (t, i)
+                assert np.array_equal(des[i], s['desired_img']) and np.array_equal(ini[i], s['init_img']), (t, i)
+    # the double-count corner: sticks in hand, standing on sticks -> blue channel 2*160 mod 256 = 64
+    grid = np.zeros((N, 6, 6), np.uint8)
+    grid[:, 2, 3] = 1
+    env.set_state(grid=grid, agent_rc=np.tile(np.array([[2, 3]], np.uint8), (N, 1)), hold=np.ones(N, np.uint8))
+    fr = env.render()[0].cpu().numpy()
+    assert fr[6, 9].tolist() == [90, 164, 64] and fr[8, 11].tolist() == [0, 0, 255] and fr[18:, 3:6].min() == 255
     env.close()
