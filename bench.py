@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--size', type=int, default=21)
     ap.add_argument('--max-steps', type=int, default=300)
     ap.add_argument('--obs-mode', default='pixels', choices=['pixels', 'pixels_dirty', 'state'])
+    ap.add_argument('--raster', default='ray', choices=['ray', 'alt'], help="'alt' = CraftingWorldEnvAltObs tiles (side measurement)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -113,7 +114,7 @@ def main():
     lo, hi = shard_range(rank, world, args.envs_per_gpu * world)
     N = hi - lo
     env = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=args.obs_mode,
-                              device=dev, seed=lo)
+                              device=dev, seed=lo, raster=args.raster)
     env.reset()
     # synthetic actions: uniform in [0,6), pre-generated on device, one row per step (not part of the env)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -183,7 +184,7 @@ def main():
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
     # step (the reference's own render_edit strategy), state-only has no frames at all.
     other = {}
-    if rank == 0 and not args.no_other_modes and args.obs_mode == 'pixels':
+    if rank == 0 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
         env.close()
         for mode in ('pixels_dirty', 'state'):
             e2 = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo)
@@ -204,7 +205,7 @@ def main():
         total_steps = float(N) * world * K
         value = total_steps / elapsed
         S = args.size
-        frame = 48 * S * S
+        frame = 48 * S * S if args.raster == 'ray' else 27 * S * (S + 1)
         if args.obs_mode == 'pixels':
             # A_pix = 48 + S*S (grid read) + frame write; the render kernel's share is
             # S*S + frame bytes per env, and one launch paints N envs (+2 more frames for each env reset that step)
