@@ -28,6 +28,12 @@ CONFIGS = [
     (dict(size=(32, 32), max_steps=80), 200),
     (dict(size=(12, 12), max_steps=100, reward_style='subset', selected_tasks=['EatBread', 'MakeBread'], number_of_tasks=1), 300),
 ]
+# the same through CraftingWorldEnvAltObs (3x3-px CPV rasteriser); images compared as uint8 views
+ALT_CONFIGS = [
+    (dict(size=(21, 21), max_steps=120), 300),
+    (dict(size=(5, 5), max_steps=30), 500),
+    (dict(size=(9, 9), max_steps=60, fixed_init_state=2, reward_style='subset'), 400),
+]
 
 
 def compare(env, ora, tag):
@@ -41,15 +47,16 @@ def compare(env, ora, tag):
 
 
 def main(n_seeds):
-    cls = import_reference()['ray']
+    classes = import_reference()
     total_steps = total_resets = successes = 0
     t0 = time.time()
-    for ci, (kw, steps) in enumerate(CONFIGS):
+    todo = [(classes['ray'], False, kw, steps) for kw, steps in CONFIGS] + [(classes['altobs'], True, kw, steps) for kw, steps in ALT_CONFIGS]
+    for ci, (cls, alt, kw, steps) in enumerate(todo):
         for seed in range(n_seeds):
             rng = np.random.RandomState(10_000 * ci + seed)
             st = rng.get_state()
             env = make_ref_env(cls, rng, **kw)
-            ora = OracleEnv(rng_state=(st[1].copy(), int(st[2])), **kw)
+            ora = OracleEnv(rng_state=(st[1].copy(), int(st[2])), alt_obs=alt, **kw)
             pol = np.random.RandomState(seed)
 
             def do_reset():
@@ -79,7 +86,7 @@ def main(n_seeds):
                     do_reset()
                     total_resets += 1
     print('reference == oracle on %d steps, %d resets, %d successful episodes, %d configs x %d seeds (%.1f s)' % (
-        total_steps, total_resets, successes, len(CONFIGS), n_seeds, time.time() - t0))
+        total_steps, total_resets, successes, len(todo), n_seeds, time.time() - t0))
 
 
 if __name__ == '__main__':
