@@ -17,6 +17,7 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads);
+int cwk_profile_side(int set);
 hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
@@ -227,6 +228,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
         cwk_set_tuning(geti("CW_TUNE_RENDER_BLOCKS_PER_CU", 1), geti("CW_TUNE_LIST_BLOCKS", 256), geti("CW_TUNE_OVERLAP", 1),
                         geti("CW_TUNE_RENDER_BLOCKS", 0), geti("CW_TUNE_RENDER_THREADS", 256));
+        cwk_profile_side(geti("CW_PROFILE_SIDE_STREAM", 0));
     }
 
     int rc = CW_OK;
@@ -440,11 +442,14 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
-        for (int k = 0; k < 6; k++) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
+        const bool side_recorded = cwk_profile_side(-1) || !(e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset);
+        for (int k = 0; k < 6; k++)
+            if (side_recorded || k >= 4) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
         double acc[3] = {0, 0, 0};
         float rmax = 0.f, rmin = 1e30f;
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 3; k++) {
+                if (k != 2 && !side_recorded) continue;      // overlapped full-pixel step: only the render kernel is bracketed
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[(size_t)i * 6 + 2 * k], e->prof_ev[(size_t)i * 6 + 2 * k + 1]));
                 acc[k] += ms;

@@ -981,6 +981,9 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
 
 // ------------------------------------------------------------------------------------ launchers
 static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0, g_render_threads = 256;
+static int g_profile_side = 0;   // 1: bracket every kernel (step, side-stream reset + list render, render); 0: in the
+                                 // overlapped full-pixel step only the dominant render kernel -- every event record
+                                 // costs a few us of pipeline bubble, and side-stream events perturb the overlap
 
 static inline int cw_render_grid(int jobs)
 {
@@ -1008,6 +1011,12 @@ static inline int cw_reset_grid(int jobs)
 extern "C" {
 
 // tuning knobs for experiments (CW_TUNE_* environment variables, read once in cw_create)
+int cwk_profile_side(int set)
+{
+    if (set >= 0) g_profile_side = set;
+    return g_profile_side;
+}
+
 void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads)
 {
     g_render_blocks_abs = render_blocks_abs;
@@ -1027,18 +1036,20 @@ hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype
     const int n = P->n_envs;
     const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
     const bool pixels = obs_mode != 0;   // pixel modes: the list render is the done list's last reader
-    if (ev) (void)hipEventRecord(ev[0], st);
+    const bool overlapped = (obs_mode == 1 && auto_reset && g_overlap);
+    const bool ev_all = ev && (g_profile_side || !overlapped);
+    if (ev_all) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
-    if (ev) (void)hipEventRecord(ev[1], st);
+    if (ev_all) (void)hipEventRecord(ev[1], st);
     if (obs_mode == 1 && auto_reset && g_overlap) {
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        if (ev) (void)hipEventRecord(ev[2], side);
+        if (ev && g_profile_side) (void)hipEventRecord(ev[2], side);
         if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 4);
         hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 0, 0);
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1);
-        if (ev) (void)hipEventRecord(ev[3], side);
+        if (ev && g_profile_side) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
         hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(g_render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr);

@@ -183,8 +183,10 @@ int cw_set_state(cw_engine *e, const cw_state_view *host);
  * events, returns average durations in milliseconds and stops recording. */
 typedef struct cw_profile {
     int32_t steps;           /* cw_step calls recorded */
-    float ms_step_kernel;    /* average per launch */
-    float ms_reset_kernel;
+    float ms_step_kernel;    /* average per launch (0 where not bracketed, see ms_reset_kernel) */
+    float ms_reset_kernel;   /* in the overlapped full-pixel step only the render kernel is bracketed unless
+                              * CW_PROFILE_SIDE_STREAM=1: every event record costs a pipeline bubble and side-stream
+                              * events perturb the overlap they measure */
     float ms_render_kernel;  /* 0 in CW_OBS_STATE */
     float ms_render_kernel_max;
     float ms_render_kernel_min;
