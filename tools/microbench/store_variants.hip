@@ -192,14 +192,19 @@ static void bench(const char *name, size_t bytes, F launch)
     printf("%-44s median %.3f ms  %.0f GB/s   (min %.3f ms %.0f GB/s)\n", name, ms[7], bytes / ms[7] / 1e6, ms[0], bytes / ms[0] / 1e6);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int alloc_mode = argc > 1 ? atoi(argv[1]) : 0;   // 0 hipMalloc, 1 uncached, 2 fine-grained
     const int N = 65536; const uint32_t FB = 21168;
     const size_t bytes = (size_t)N * FB;
     uint8_t *buf; uint4 *pos;
     uint8_t *buf2; CHECK(hipMalloc(&buf2, (size_t)N * 21504));
-    CHECK(hipMalloc(&buf, bytes)); CHECK(hipMalloc(&pos, N * 16)); CHECK(hipMemset(pos, 7, N * 16));
-    for (int blocks : {128, 256, 512, 1024, 4096}) {
+    if (alloc_mode == 1) CHECK(hipExtMallocWithFlags((void **)&buf, bytes, hipDeviceMallocUncached));
+    else if (alloc_mode == 2) CHECK(hipExtMallocWithFlags((void **)&buf, bytes, hipDeviceMallocFinegrained));
+    else CHECK(hipMalloc(&buf, bytes));
+    printf("alloc mode %d\n", alloc_mode);
+    CHECK(hipMalloc(&pos, N * 16)); CHECK(hipMemset(pos, 7, N * 16));
+    for (int blocks : {256, 1024}) {
         printf("-- grid %d blocks x 256\n", blocks);
         bench("fill x4 plain", bytes, [&] { hipLaunchKernelGGL(fill_x4<0>, dim3(blocks), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
         bench("fill x4 nontemporal", bytes, [&] { hipLaunchKernelGGL(fill_x4<1>, dim3(blocks), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
