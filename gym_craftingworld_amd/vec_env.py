@@ -340,6 +340,21 @@ class CraftingWorldVecEnv:
         L.check(self._lib.cw_profile_end(self._h, C.byref(p)), 'cw_profile_end')
         return {k: getattr(p, k) for k, _ in p._fields_}
 
+    def compute_reward_batch(self, achieved_mask, desired_mask, subset=None):
+        """Vectorised compute_reward_equal / compute_reward_subset (ray.py:757-767) on bit masks, for
+        HER-style relabelling on the device: int tensors of any shape -> int32 rewards (MAX_STEPS or -1).
+        subset=None uses menu 0's reward_style."""
+        full = (1 << len(self.task_list)) - 1
+        a = achieved_mask.to(torch.int32) & full
+        d = desired_mask.to(torch.int32) & full
+        if subset is None:
+            subset = bool(self._menus[0].reward_subset)
+        if subset:      # np.max(desired - achieved) == 0: nothing missing and at least one position equal
+            hit = ((d & ~a) == 0) & (((~(d ^ a)) & full) != 0)
+        else:
+            hit = a == d
+        return torch.where(hit, torch.full_like(a, self.MAX_STEPS), torch.full_like(a, -1))
+
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         """compute_reward_equal / compute_reward_subset of ray.py:757-767 on 0/1 goal vectors
         (host convenience for HER-style relabelling; the per-step reward comes from the kernel)."""
