@@ -679,3 +679,44 @@ def test_compute_reward_batch_matches_reference_rules():
             ref = np.where((av == dv).all(axis=1), 77, -1)               # ray.py:757-761
         assert np.array_equal(got, ref)
     env.close()
+
+
+def test_overlap_stress_desynchronised_resets():
+    """The full-pixel step forks: main stream paints non-done envs while the side stream resets done
+    envs and paints their three frames.  Short, de-synchronised episodes (max_steps=23, random phases
+    from successes) keep both streams busy on every step; full-frame and dirty-cell engines must stay
+    identical throughout, and the first envs equal to the oracle."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, M = 32768, 700, 96
+    kw = dict(size=(21, 21), max_steps=23)
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', seed=31, keep_terminal_obs=True, **kw)
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', seed=31, keep_terminal_obs=True, **kw)
+    keys, pos = full.get_rng_states()
+    # scatter the episode phases so that some envs finish on every step
+    phase = (np.arange(N) * 7 % 23).astype(np.int32)
+    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in range(M)], **kw)
+    full.reset(); dirty.reset(); ora.reset()
+    full.set_state(step_num=phase); dirty.set_state(step_num=phase)
+    for i, e in enumerate(ora.envs):
+        s = e.state()
+        e.set_state(s['grid'], s['init_grid'], s['agent'], s['hold'], s['achieved'], s['desired'], int(phase[i]))
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for t in range(T):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen)
+        of, rf, df, inf_f = full.step(a)
+        od, rd, dd, inf_d = dirty.step(a)
+        if t % 50 == 0 or t == T - 1:
+            assert torch.equal(rf, rd) and torch.equal(df, dd), t
+            for k in ('observation', 'desired_goal', 'init_observation'):
+                assert torch.equal(of[k], od[k]), (t, k)
+            m = df.nonzero().squeeze(1)
+            assert m.numel() > 0
+            assert torch.equal(inf_f['terminal_observation'][m], inf_d['terminal_observation'][m]), t
+        o_rew, o_done = ora.step(a[:M].cpu().numpy())
+        assert np.array_equal(rf[:M].cpu().numpy(), o_rew) and np.array_equal(df[:M].cpu().numpy(), o_done), t
+    for i, s in enumerate(ora.states()):
+        assert np.array_equal(of['observation'][i].cpu().numpy(), s['obs']), i
+        assert np.array_equal(of['desired_goal'][i].cpu().numpy(), s['desired_img']), i
+    assert torch.equal(full.hdr, dirty.hdr) and torch.equal(full.counters, dirty.counters)
+    full.close(); dirty.close()
