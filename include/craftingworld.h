@@ -104,7 +104,8 @@ typedef struct cw_buffer_table {
     int32_t *episode_length; /* [N]  step_num at done (valid where done==1)                        */
     uint8_t *hdr;            /* [N][16] packed per-env header of the CURRENT state (after auto-reset):
                               *   byte 0 agent row, 1 agent col, 2 hold (0 none,1 sticks,2 axe,3 hammer), 3 menu id,
-                              *   bytes 4-5 achieved mask (LE u16), 6-7 desired mask, 8-9 step_num, 10-11 flags,
+                              *   bytes 4-5 achieved mask (LE u16), 6-7 desired mask, 8-9 step_num, 10-11 flags (bit 0: no step
+                              *   taken yet in this episode, bit 1: subset reward rule),
                               *   bytes 12-15 the 8 object slots' codes, 4 bits each (slot k in bits 4k..4k+3)      */
     uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
     uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
