@@ -190,7 +190,8 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
     uint32_t hold = (h.x >> 16) & 0xFF;
     uint32_t achieved = h.y & 0xFFFFu;
     const uint32_t desired = h.y >> 16;
-    const uint32_t step_num = (h.z & 0xFFFFu) + 1u;               // ray.py:309
+    // ray.py:309; 16-bit field, saturating: a finished env stepped on without auto-reset stays done (max_steps <= 65535)
+    const uint32_t step_num = min((h.z & 0xFFFFu) + 1u, 0xFFFFu);
     const uint32_t flags = (h.z >> 16) & ~CW_FLAG_RESET;
     uint32_t codes = h.w;
 
