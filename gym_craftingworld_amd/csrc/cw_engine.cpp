@@ -14,14 +14,12 @@
 #include "cw_layout.h"
 
 extern "C" {
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
+hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
-void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads);
-int cwk_profile_side(int set);
-hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st);
+hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
-hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st);
+hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st);
 }
 
@@ -64,6 +62,7 @@ struct cw_engine {
     int auto_reset = 1;
     bool has_reset = false;
     CwParams P{};
+    CwTuning tune{};
     std::vector<void *> allocs;
     std::vector<CwMenuDev> menus;
     int n = 0, S = 0, ncell = 0, K = 0;
@@ -226,9 +225,16 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     {   // experiment knobs; the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
-        cwk_set_tuning(geti("CW_TUNE_RENDER_BLOCKS_PER_CU", 1), geti("CW_TUNE_LIST_BLOCKS", 256), geti("CW_TUNE_OVERLAP", 1),
-                        geti("CW_TUNE_RENDER_BLOCKS", 0), geti("CW_TUNE_RENDER_THREADS", 256));
-        cwk_profile_side(geti("CW_PROFILE_SIDE_STREAM", 0));
+        CwTuning &tn = e->tune;
+        tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
+        tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
+        const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
+        if (rt == 64 || rt == 128 || rt == 256) tn.render_threads = rt;
+        tn.list_blocks = geti("CW_TUNE_LIST_BLOCKS", tn.list_blocks);
+        tn.overlap = geti("CW_TUNE_OVERLAP", tn.overlap);
+        tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
+        if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
+        if (tn.list_blocks < 1) tn.list_blocks = 1;
     }
 
     int rc = CW_OK;
@@ -369,7 +375,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
 {
     if (!e) return fail(CW_ERR_INVALID, "cw_reset: null engine");
     DeviceGuard guard(e->device);
-    HIP_TRY(cwk_launch_reset_all(&e->P, e->obs_mode, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     e->has_reset = true;
     return CW_OK;
 }
@@ -381,7 +387,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    HIP_TRY(cwk_launch_step(&e->P, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
+    HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
                             e->ev_fork, e->ev_join, ev));
     if (ev) e->prof_n++;
     return CW_OK;
@@ -404,7 +410,7 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
     if (!e || !out_frames) return fail(CW_ERR_INVALID, "cw_render: null argument");
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_render called before cw_reset");
     DeviceGuard guard(e->device);
-    HIP_TRY(cwk_launch_render_ext(&e->P, out_frames, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
 
@@ -442,7 +448,7 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
-        const bool side_recorded = cwk_profile_side(-1) || !(e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset);
+        const bool side_recorded = e->tune.profile_side || !(e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && e->tune.overlap);
         for (int k = 0; k < 6; k++)
             if (side_recorded || k >= 4) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
         double acc[3] = {0, 0, 0};
@@ -604,7 +610,7 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     HIP_TRY(hipMemcpy(e->P.init_pos, ipos.data(), N * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->P.ep_no, epno.data(), N * 4, hipMemcpyHostToDevice));
     if (e->obs_mode != CW_OBS_STATE)   // the persistent frame must follow the injected state
-        HIP_TRY(cwk_launch_render_ext(&e->P, e->P.obs, nullptr));
+        HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }

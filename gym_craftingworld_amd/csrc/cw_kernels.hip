@@ -981,21 +981,16 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
 }
 
 // ------------------------------------------------------------------------------------ launchers
-static int g_render_blocks_per_cu = 1, g_list_blocks = 256, g_overlap = 1, g_render_blocks_abs = 0, g_render_threads = 256;
-static int g_profile_side = 0;   // 1: bracket every kernel (step, side-stream reset + list render, render); 0: in the
-                                 // overlapped full-pixel step only the dominant render kernel -- every event record
-                                 // costs a few us of pipeline bubble, and side-stream events perturb the overlap
-
-static inline int cw_render_grid(int jobs)
+static inline int cw_render_grid(const CwTuning &tn, int jobs)
 {
     // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
     // write path saturates with few store streams and gets slower with more of them in flight
     // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/r01_render_sweeps.txt); it also
     // leaves the wave slots for the reset kernel running beside it
-    const int wpb = g_render_threads / CW_WAVE;
+    const int wpb = tn.render_threads / CW_WAVE;
     int blocks = (jobs + wpb - 1) / wpb;
-    if (blocks > 256 * g_render_blocks_per_cu) blocks = 256 * g_render_blocks_per_cu;
-    if (g_render_blocks_abs > 0 && blocks > g_render_blocks_abs) blocks = g_render_blocks_abs;
+    if (blocks > 256 * tn.render_blocks_per_cu) blocks = 256 * tn.render_blocks_per_cu;
+    if (tn.render_blocks_abs > 0 && blocks > tn.render_blocks_abs) blocks = tn.render_blocks_abs;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -1011,61 +1006,46 @@ static inline int cw_reset_grid(int jobs)
 
 extern "C" {
 
-// tuning knobs for experiments (CW_TUNE_* environment variables, read once in cw_create)
-int cwk_profile_side(int set)
-{
-    if (set >= 0) g_profile_side = set;
-    return g_profile_side;
-}
-
-void cwk_set_tuning(int render_blocks_per_cu, int list_blocks, int overlap, int render_blocks_abs, int render_threads)
-{
-    g_render_blocks_abs = render_blocks_abs;
-    if (render_threads == 64 || render_threads == 128 || render_threads == 256) g_render_threads = render_threads;
-    if (render_blocks_per_cu > 0) g_render_blocks_per_cu = render_blocks_per_cu;
-    if (list_blocks > 0) g_list_blocks = list_blocks;
-    g_overlap = overlap;
-}
-
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
 // while the side stream resets the done envs and paints their three frames; both join back into
 // the caller's stream, so the caller sees ordinary stream order.
-hipError_t cwk_launch_step(const CwParams *P, const void *actions, int act_dtype, int obs_mode, int auto_reset,
-                           hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode,
+                           int auto_reset, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
                            hipEvent_t *ev /* 6 or null */)
 {
+    const CwTuning &tn = *T;
     const int n = P->n_envs;
     const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
     const bool pixels = obs_mode != 0;   // pixel modes: the list render is the done list's last reader
-    const bool overlapped = (obs_mode == 1 && auto_reset && g_overlap);
-    const bool ev_all = ev && (g_profile_side || !overlapped);
+    const bool overlapped = (obs_mode == 1 && auto_reset && tn.overlap);
+    const bool ev_all = ev && (tn.profile_side || !overlapped);
     if (ev_all) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev_all) (void)hipEventRecord(ev[1], st);
-    if (obs_mode == 1 && auto_reset && g_overlap) {
+    if (obs_mode == 1 && auto_reset && tn.overlap) {
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        if (ev && g_profile_side) (void)hipEventRecord(ev[2], side);
-        if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 4);
+        if (ev && tn.profile_side) (void)hipEventRecord(ev[2], side);
+        if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, side, *P, 4);
         hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 0, 0);
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, side, *P, 1);
-        if (ev && g_profile_side) (void)hipEventRecord(ev[3], side);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, side, *P, 1);
+        if (ev && tn.profile_side) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(g_render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr);
         if (ev) (void)hipEventRecord(ev[5], st);
         (void)hipStreamWaitEvent(st, ev_join, 0);
         return hipGetLastError();
     }
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (auto_reset && P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 4);
+    if (auto_reset && P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, st, *P, 4);
     if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, pixels ? 0 : 1, 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(n)), dim3(g_render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr);
     if (pixels && auto_reset)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(g_list_blocks), dim3(256), 0, st, *P, 1);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, st, *P, 1);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -1081,12 +1061,13 @@ hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, 
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_reset_all(const CwParams *P, int obs_mode, hipStream_t st)
+hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st)
 {
+    const CwTuning &tn = *T;
     const int n = P->n_envs;
     hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1);
     if (obs_mode != 0)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(n)), dim3(256), 0, st, *P, 0);
+        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(tn, n)), dim3(256), 0, st, *P, 0);
     return hipGetLastError();
 }
 
@@ -1097,9 +1078,10 @@ hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_render_ext(const CwParams *P, uint8_t *out, hipStream_t st)
+hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(P->n_envs)), dim3(g_render_threads), 0, st, *P, 2, 0, out);
+    const CwTuning &tn = *T;
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, P->n_envs)), dim3(tn.render_threads), 0, st, *P, 2, 0, out);
     return hipGetLastError();
 }
 

@@ -38,6 +38,17 @@ struct CwMenuDev {
     int32_t reward_subset;
 };
 
+// Host-side launch tuning of one engine (defaults = the measured best; the CW_TUNE_* /
+// CW_PROFILE_* environment variables read in cw_create override them for experiments).
+struct CwTuning {
+    int render_blocks_per_cu = 1;   // render workgroups per CU (persistent, grid-stride over frames)
+    int render_blocks_abs = 0;      // >0: absolute cap on render workgroups
+    int render_threads = 256;       // threads per render workgroup (64, 128, 256)
+    int list_blocks = 256;          // workgroups of the done-list render
+    int overlap = 1;                // full-pixel step: reset + list render on the side stream beside the main render
+    int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
+};
+
 // Everything the kernels need, passed by value.
 struct CwParams {
     // per-env state (SoA of 16-byte records unless noted)
