@@ -111,6 +111,40 @@ void cwh_mt_to_numpy(const uint32_t *s, int idx, uint32_t *key)
     }
 }
 
+// ------------------------------------------------------------------------------ DLPack producer
+// Non-owning DLManagedTensor over engine memory (DLPack ABI v0: the struct layout below is the
+// published one).  Produced and freed in C so that no Python callback is involved when a consumer
+// (torch) drops its last view -- possibly during interpreter shutdown.
+struct CwDLDevice { int32_t device_type, device_id; };
+struct CwDLDataType { uint8_t code, bits; uint16_t lanes; };
+struct CwDLTensor { void *data; CwDLDevice device; int32_t ndim; CwDLDataType dtype; int64_t *shape, *strides; uint64_t byte_offset; };
+struct CwDLManagedTensor { CwDLTensor dl_tensor; void *manager_ctx; void (*deleter)(CwDLManagedTensor *); };
+
+static void cw_dl_deleter(CwDLManagedTensor *m)
+{
+    if (!m) return;
+    free(m->dl_tensor.shape);
+    free(m);
+}
+
+// device_type 10 = kDLROCM; code 0 int / 1 uint; returns a malloc'ed DLManagedTensor* (or NULL)
+void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, const int64_t *shape)
+{
+    CwDLManagedTensor *m = (CwDLManagedTensor *)calloc(1, sizeof(CwDLManagedTensor));
+    int64_t *shp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ndim > 0 ? ndim : 1));
+    if (!m || !shp) { free(m); free(shp); return nullptr; }
+    for (int i = 0; i < ndim; i++) shp[i] = shape[i];
+    m->dl_tensor.data = data;
+    m->dl_tensor.device = CwDLDevice{10, device_id};
+    m->dl_tensor.ndim = ndim;
+    m->dl_tensor.dtype = CwDLDataType{(uint8_t)code, (uint8_t)bits, 1};
+    m->dl_tensor.shape = shp;
+    m->dl_tensor.strides = nullptr;
+    m->dl_tensor.byte_offset = 0;
+    m->deleter = cw_dl_deleter;
+    return m;
+}
+
 void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
 {
     s[0] = seed;

@@ -7,7 +7,10 @@ ids (ray.py:130-131), same rewards/done rule (ray.py:361-367), same four-image D
 (include/craftingworld.h); this file is host plumbing: config marshalling, torch views of the
 engine's device buffers, stream hand-off.  There is no CPU fallback.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 import torch
@@ -43,6 +46,18 @@ def _menu_struct(task_list, selected_tasks, number_of_tasks, stacking, reward_st
     for i, t in enumerate(selected_tasks):
         m.selected_bits[i] = tl.index(t)                                             # ValueError like ray.py:174
     return m
+
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():      # destroy engines before the HIP runtime is torn down at interpreter exit
+    for env in list(_LIVE):
+        try:
+            env.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class CraftingWorldVecEnv:
@@ -121,6 +136,7 @@ class CraftingWorldVecEnv:
         h_ = C.c_void_p()
         L.check(self._lib.cw_create(C.byref(cfg), self.device.index, C.byref(h_)), 'cw_create')
         self._h = h_
+        _LIVE.add(self)
 
         # zero-copy views of the engine's buffers
         tab = L.cw_buffer_table()
@@ -177,6 +193,8 @@ class CraftingWorldVecEnv:
             self._h = None
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001

@@ -720,3 +720,35 @@ def test_overlap_stress_desynchronised_resets():
         assert np.array_equal(of['desired_goal'][i].cpu().numpy(), s['desired_img']), i
     assert torch.equal(full.hdr, dirty.hdr) and torch.equal(full.counters, dirty.counters)
     full.close(); dirty.close()
+
+
+def test_episode_recorder_writes_gifs(tmp_path):
+    from PIL import Image
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from gym_craftingworld_amd.recorder import EpisodeRecorder
+    env = CraftingWorldVecEnv(8, size=(5, 5), max_steps=6, obs_mode='pixels', keep_terminal_obs=True, seed=3)
+    rec = EpisodeRecorder(env, env_index=2, out_dir=str(tmp_path), scale=2)
+    rec.after_reset(env.reset())
+    paths = []
+    for t in range(20):
+        obs, rew, done, info = env.step(torch.randint(0, 6, (8,), device='cuda'))
+        p = rec.after_step(obs, done, info)
+        if p:
+            paths.append(p)
+    assert len(paths) >= 3
+    im = Image.open(paths[0])
+    # reset frame + 6 steps (pillow merges identical consecutive frames); obs | desired_goal side by side
+    assert 2 <= im.n_frames <= 7 and im.size == (2 * 2 * 20, 2 * 20)
+    env.close()
+
+
+def test_process_exit_with_live_views_is_clean():
+    """A process that exits without close() while torch views of engine buffers are alive must end
+    normally (engines are destroyed at exit before the HIP runtime, DLPack deleters are C functions)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = subprocess.call([sys.executable, os.path.join(root, 'tools', 'microbench', 'exit_test.py')], cwd=root,
+                         stderr=subprocess.DEVNULL)
+    assert rc == 3
