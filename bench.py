@@ -57,6 +57,8 @@ def cpu_baseline(size, max_steps, seconds=12.0):
         total += batch.rollout(acts, nthreads=cores)
     dt = time.perf_counter() - t0
     return dict(value=total / dt, unit='env-steps/s', cores=cores, kind='port',
+                reference_note='the reference itself (pure Python) cannot travel to the GPU box; BASELINE.md §2 has it at '
+                               '64-78 k env-steps/s on one 2.1 GHz Xeon core (measured in the build container)',
                 sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset, dirty-cell repaint like the reference), '
                        '%.1f s on %d OpenMP threads' % (n, T0 * reps, size, size, max_steps, dt, cores))
 
