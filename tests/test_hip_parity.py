@@ -752,3 +752,45 @@ def test_process_exit_with_live_views_is_clean():
     rc = subprocess.call([sys.executable, os.path.join(root, 'tools', 'microbench', 'exit_test.py')], cwd=root,
                          stderr=subprocess.DEVNULL)
     assert rc == 3
+
+
+def test_error_behaviour_of_the_boundary():
+    """Status codes of the C ABI surface as Python exceptions: CW_ERR_INVALID -> ValueError, CW_ERR_STATE /
+    CW_ERR_HIP -> CraftingWorldError; reference-style errors for bad task names and action indices."""
+    import ctypes as C
+    import gym_craftingworld_amd as g
+    from gym_craftingworld_amd import _lib as L
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(4, size=(3, 3))                                   # < 12 cells: sample_state cannot place 9 items
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(4, max_steps=70000)
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(4, selected_tasks=['MakeBread', 'Fly'])           # list.index raises ValueError, ray.py:174
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(4, task_list=TASKS[:5], selected_tasks=TASKS[:2])  # eval_task_edit needs all 9 slots
+    with pytest.raises(ValueError):
+        g.CraftingWorldVecEnv(4, obs_mode='rgb')
+    with pytest.raises(NotImplementedError):
+        g.CraftingWorldVecEnv(4, store_gif=True)
+    env = g.CraftingWorldVecEnv(4, size=(5, 5), obs_mode='state')
+    with pytest.raises(g.CraftingWorldError):
+        env.step(torch.zeros(4, dtype=torch.int32, device='cuda'))              # step before reset
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(5, dtype=torch.int32, device='cuda'))
+    with pytest.raises(ValueError):
+        env.set_state(grid=np.full((4, 5, 5), 1, np.uint8))                     # 25 objects: not a reachable state
+    with pytest.raises(ValueError):
+        env.rollout(torch.zeros((3, 7), dtype=torch.uint8, device='cuda'))
+    lib = L.load()
+    assert lib.cw_step(None, None, 0, None) == L.CW_ERR_INVALID and b'null' in lib.cw_last_error()
+    pix = g.CraftingWorldVecEnv(4, size=(5, 5), obs_mode='pixels')
+    pix.reset()
+    with pytest.raises(ValueError):
+        pix.rollout(torch.zeros((3, 4), dtype=torch.uint8, device='cuda'))      # rollout is state-only
+    one = g.make('craftingworld-v3', size=(5, 5))
+    one.reset()
+    with pytest.raises(IndexError):
+        one.step(-1)
+    for e in (env, pix, one):
+        e.close()
