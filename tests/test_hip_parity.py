@@ -794,3 +794,63 @@ def test_error_behaviour_of_the_boundary():
         one.step(-1)
     for e in (env, pix, one):
         e.close()
+
+
+def test_systematic_transition_table():
+    """Every combination of (object in the target cell 0..8) x (object under the agent) x (hold) x (action)
+    x (where the init grid put sticks/axe/hammer/tree relative to the two cells) x (achieved bits) x
+    (agent interior / at the wall), one step each, HIP vs oracle -- the whole local transition table of
+    step(), eval_task_edit() and both reward rules, not a random sample of it."""
+    from itertools import product
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleEnv
+    S = 5
+    DR = [(-1, 0), (0, 1), (1, 0), (0, -1)]
+    cases = []
+    for tgt, under, hold, a, initv, achv, wall in product(range(9), (0, 1, 2, 3, 7, 8), range(4), range(6), range(4), range(3), (0, 1)):
+        if hold and under and sum(1 for x in (tgt, under) if x) + 1 > 8:
+            continue
+        ar, ac = (0, 0) if wall else (2, 2)
+        g = np.zeros((S, S), np.uint8)
+        g[ar, ac] = under
+        d = DR[a] if a < 4 else DR[1]
+        tr, tc = ar + d[0], ac + d[1]
+        if 0 <= tr < S and 0 <= tc < S:
+            g[tr, tc] = tgt
+        else:
+            tr, tc = ar, ac                      # clamped move: target == own cell
+        ig = np.zeros((S, S), np.uint8)          # one of each object; objects 1,2,3,5 placed per initv
+        spots = {0: [(4, 0), (4, 1), (4, 2), (4, 3)],                       # all elsewhere
+                 1: [(tr, tc), (4, 1), (4, 2), (4, 3)],                     # sticks started in the target cell
+                 2: [(4, 0), (tr, tc), (4, 2), (4, 3)] if hold != 3 else [(4, 0), (4, 1), (tr, tc), (4, 3)],   # held tool's origin
+                 3: [(4, 0), (4, 1), (4, 2), (tr, tc)]}[initv]              # tree started in the target cell
+        for code, (r, c) in zip((1, 2, 3, 5), spots):
+            ig[r, c] = code
+        for code, (r, c) in zip((4, 6, 7, 8), [(3, 4), (2, 4), (1, 4), (0, 4)]):
+            ig[r, c] = code
+        ach = (0, 1 << 3, 0x1FF)[achv]
+        cases.append((g, ig, (ar, ac), hold, a, ach))
+    N = len(cases)
+    for style in (None, 'subset'):
+        env = CraftingWorldVecEnv(N, size=(S, S), max_steps=9, obs_mode='pixels_dirty', reward_style=style, auto_reset=False)
+        env.reset()
+        rng = np.random.RandomState(1)
+        des = np.array([c[5] if rng.rand() < 0.3 else rng.randint(1, 512) for c in cases], np.uint16)
+        env.set_state(grid=np.stack([c[0] for c in cases]), init_grid=np.stack([c[1] for c in cases]),
+                      agent_rc=np.array([c[2] for c in cases], np.uint8), hold=np.array([c[3] for c in cases], np.uint8),
+                      achieved=np.array([c[5] for c in cases], np.uint16), desired=des, step_num=np.full(N, 3, np.int32))
+        obs, rew, done, _ = env.step(torch.as_tensor(np.array([c[4] for c in cases], np.int32), device=env.device))
+        st = env.get_state()
+        rew, done, frames = rew.cpu().numpy(), done.cpu().numpy(), obs['observation'].cpu().numpy()
+        o = OracleEnv(size=(S, S), max_steps=9, reward_style=style)
+        for i, (g, ig, ag, hold, a, ach) in enumerate(cases):
+            o.set_state(g, ig, ag, hold, ach, int(des[i]), 3)
+            _, r, d, _ = o.step(a)
+            s = o.state()
+            tag = (style, i, 'tgt/under/hold/a', int(g.max()), hold, a)
+            assert (r, d) == (rew[i], done[i]), tag
+            assert np.array_equal(st['grid'][i], s['grid']) and tuple(st['agent_rc'][i]) == s['agent'], tag
+            assert st['hold'][i] == s['hold'] and st['achieved'][i] == s['achieved'], (tag, bin(st['achieved'][i]), bin(s['achieved']))
+            assert np.array_equal(frames[i], s['obs']), tag
+        env.close()
+    assert N > 20000
