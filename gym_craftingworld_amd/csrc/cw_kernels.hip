@@ -5,10 +5,11 @@
 //                     render_edit() (ray.py:522-557) of the <=2 changed cells.
 //   cw_reset_kernel   one WAVEFRONT per finished env: reset() of ray.py:156-218 = task draw, legacy
 //                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS,
-//                     lane-parallel rejection sampling), imagine_obs().
+//                     lane-parallel rejection sampling), imagine_obs(); in the pixel modes the same
+//                     wave then paints the env's three frames (obs, init_obs, desired_goal).
 //   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520; a lane paints one cell's
 //                     4 pixel rows with 4 x 12-byte stores; records arrive by scalar loads.
-//   cw_render_reset_kernel  the three frames (obs, init_obs, desired_goal) of freshly reset envs.
+//   cw_render_reset_kernel  the three frames of every env after cw_reset; terminal frames of the done list.
 //   cw_rollout_kernel persistent: T steps of every env in one launch (state-only mode).
 //   cw_export_*       dense grid / one-hot views of the slot state.
 //
@@ -652,7 +653,33 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
     if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
 }
 
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs)
+__device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
+                                             uint32_t div_magic, const uint32_t sp[8], const uint32_t rgb[8],
+                                             uint32_t agent_cell, uint32_t hold_rgb, int lane);
+
+// the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the
+// wave that just reset it: no second kernel has to wait for the reset and re-read its records
+__device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, const CwResetOut &r, int lane)
+{
+    const size_t off = (size_t)env * P.frame_bytes;
+    uint32_t sp[8], gp[8], rgb[8], grgb[8];
+    unpack_pos(r.init_pos, sp);
+    unpack_pos(r.goal_pos, gp);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        rgb[k] = rgb_of_code((uint32_t)k + 1u);
+        grgb[k] = rgb_of_code((r.goal_codes >> (4 * k)) & 15u);
+    }
+    if (P.raster == 1) {
+        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane);
+        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane);
+    } else {
+        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
+        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
+    }
+}
+
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs, int paint)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -673,6 +700,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
             P.pos[env] = r.init_pos;
             P.hdr[env] = reset_header(P, r, menu_id);
         }
+        if (paint) paint_reset_frames(P, env, r, lane);
     }
     if (!all_envs && last_reader) release_done_list(P);
 }
@@ -807,10 +835,9 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
 }
 
 // mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
-// mode 1: envs in the done list -> obs, init_img, desired_img                    (after auto-reset)
 // mode 2: every env -> ext_out only                                               (cw_render)
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
-//         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
+//         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
 // Per-env records are wave-uniform, so they are fetched with SCALAR loads (s_load_dwordx4 through
 // the constant cache, lgkmcnt domain; cload below).  This matters: a vector load in the frame loop
 // makes hipcc wait vmcnt(0) before the next frame -- loads and stores retire in one in-order counter
@@ -837,7 +864,7 @@ __device__ __forceinline__ CwEnvRec rec_load(const CwParams &P, int job, int n_j
     CwEnvRec r;
     r.env = -1;
     if (job < n_jobs) {
-        const int env = (MODE == 1 || MODE == 4) ? cload(P.done_list + job) : job;
+        const int env = (MODE == 4) ? cload(P.done_list + job) : job;
         r.env = env;
         r.h = cload((const u32x4s *)(P.hdr + env));
         r.pp = cload((const u32x4s *)(P.pos + env));
@@ -871,7 +898,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
     const uint32_t hold = (hx >> 16) & 0xFFu;
     const uint32_t hold_rgb = hold ? rgb_of_code(hold) : 0x00FFFFFFu;
-    constexpr bool three = (MODE == 0) || (MODE == 1);
+    constexpr bool three = (MODE == 0);
     const size_t off = (size_t)cur_env * P.frame_bytes;
     uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
@@ -892,10 +919,9 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 }
 
 // mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
-// mode 1: envs in the done list -> obs, init_img, desired_img                    (after auto-reset)
 // mode 2: every env -> ext_out only                                               (cw_render)
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
-//         mode-1 launch that follows their reset on the side stream                (FULL pixel step)
+//         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
 // mode 4: envs in the done list, BEFORE their reset -> terminal_img only            (keep_terminal_obs)
 template <int MODE>
 __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out)
@@ -903,7 +929,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
-    const int n_jobs = (MODE == 1 || MODE == 4) ? cload(P.done_count) : P.n_envs;
+    const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform; the caller's release_done_list barrier comes after the call)
     const bool want_done = (MODE == 3) && skip_done;
     // software pipeline on the scalar unit, CW_REC_AHEAD frames deep
@@ -927,18 +953,12 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
     if (mode == 3) render_jobs<3>(P, skip_done, ext_out);
     else render_jobs<2>(P, skip_done, ext_out);
 }
-// the three frames (obs, init_obs, desired_goal) of freshly reset envs: all envs (mode 0, cw_reset)
-// or the done list (mode 1, auto-reset)
+// off the per-step path: the three frames of every env after cw_reset (mode 0), or the last frames of the
+// done list's envs before their reset (mode 4, keep_terminal_obs)
 __global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
 {
-    if (mode == 0) {
-        render_jobs<0>(P, 0, nullptr);
-    } else if (mode == 4) {
-        render_jobs<4>(P, 0, nullptr);
-    } else {
-        render_jobs<1>(P, 0, nullptr);
-        release_done_list(P);            // this launch is the done list's last reader
-    }
+    if (mode == 0) render_jobs<0>(P, 0, nullptr);
+    else render_jobs<4>(P, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1007,7 +1027,7 @@ static inline int cw_reset_grid(int jobs)
 extern "C" {
 
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
-// while the side stream resets the done envs and paints their three frames; both join back into
+// while the side stream resets the done envs, the resetting waves painting their three frames; both join back into
 // the caller's stream, so the caller sees ordinary stream order.
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode,
                            int auto_reset, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
@@ -1016,7 +1036,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     const CwTuning &tn = *T;
     const int n = P->n_envs;
     const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
-    const bool pixels = obs_mode != 0;   // pixel modes: the list render is the done list's last reader
+    const bool pixels = obs_mode != 0;
     const bool overlapped = (obs_mode == 1 && auto_reset && tn.overlap);
     const bool ev_all = ev && (tn.profile_side || !overlapped);
     if (ev_all) (void)hipEventRecord(ev[0], st);
@@ -1028,8 +1048,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         if (ev && tn.profile_side) (void)hipEventRecord(ev[2], side);
         if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, side, *P, 4);
-        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 0, 0);
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, side, *P, 1);
+        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 1, 0, 1);   // reset + its three frames
         if (ev && tn.profile_side) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
@@ -1040,12 +1059,11 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     }
     if (ev) (void)hipEventRecord(ev[2], st);
     if (auto_reset && P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, st, *P, 4);
-    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, pixels ? 0 : 1, 0);
+    // pixel modes: the resetting wave paints the env's three frames itself and is the done list's last reader
+    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, 1, 0, pixels ? 1 : 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
-    if (obs_mode == 1)   // no overlap: the reset is complete, every env (done ones included) is painted here
+    if (obs_mode == 1)   // no overlap: the reset is complete; finished envs are painted twice (rare path, tuning only)
         hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr);
-    if (pixels && auto_reset)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, st, *P, 1);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -1065,7 +1083,7 @@ hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mo
 {
     const CwTuning &tn = *T;
     const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1);
+    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1, 0);
     if (obs_mode != 0)
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(tn, n)), dim3(256), 0, st, *P, 0);
     return hipGetLastError();

@@ -44,8 +44,8 @@ struct CwTuning {
     int render_blocks_per_cu = 1;   // render workgroups per CU (persistent, grid-stride over frames)
     int render_blocks_abs = 0;      // >0: absolute cap on render workgroups
     int render_threads = 256;       // threads per render workgroup (64, 128, 256)
-    int list_blocks = 256;          // workgroups of the done-list render
-    int overlap = 1;                // full-pixel step: reset + list render on the side stream beside the main render
+    int list_blocks = 256;          // workgroups of the done-list (terminal-frame) render
+    int overlap = 1;                // full-pixel step: reset (+ its frames) on the side stream beside the main render
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
 };
 
