@@ -56,7 +56,17 @@ def cpu_baseline(size, max_steps, seconds=12.0):
     for _ in range(reps):
         total += batch.rollout(acts, nthreads=cores)
     dt = time.perf_counter() - t0
-    return dict(value=total / dt, unit='env-steps/s', cores=cores, kind='port',
+    calib = None
+    try:   # port vs the reference's own Python, both timed in the build container (tools/calibrate_cpu.py)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'cpu_calibration.json')) as f:
+            c = json.load(f)
+        calib = dict(port_over_reference_1core=c['port_over_reference'],
+                     reference_python_env_steps_per_s_core=c['reference_python_env_steps_per_s'],
+                     reference_equivalent_of_value=total / dt / c['port_over_reference'],
+                     note='ratio measured in the build container on one core, not on this host')
+    except (OSError, KeyError, ValueError):
+        pass
+    return dict(value=total / dt, unit='env-steps/s', cores=cores, kind='port', calibration=calib,
                 reference_note='the reference itself (pure Python) cannot travel to the GPU box; BASELINE.md §2 has it at '
                                '64-78 k env-steps/s on one 2.1 GHz Xeon core (measured in the build container)',
                 sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset, dirty-cell repaint like the reference), '

@@ -184,3 +184,20 @@ def test_shard_range_property(world, total):
     assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
     sizes = [b - a for a, b in r]
     assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
+
+
+def test_bench_cpu_baseline_leg_reports_port_and_calibration():
+    """bench.py's cpu_baseline object (task contract (4)): kind "port", the cores used, a described sample, and
+    the committed build-container calibration against the reference's own Python."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('cw_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(5, 20, seconds=0.2)
+    assert out['kind'] == 'port' and out['unit'] == 'env-steps/s' and out['cores'] >= 1 and out['value'] > 0
+    assert 'envs x' in out['sample']
+    c = out['calibration']
+    assert c is not None and 20 < c['port_over_reference_1core'] < 2000
+    assert abs(c['reference_equivalent_of_value'] * c['port_over_reference_1core'] - out['value']) < 1e-6 * out['value']
