@@ -226,7 +226,9 @@ def main():
             dominant, ms = 'cw_render_kernel', prof['ms_render_kernel']
         else:
             alg_bytes = float(N) * 48.0
-            dominant, ms = 'cw_step_kernel', prof['ms_step_kernel']
+            # state-only / dirty-cell: the whole auto-reset step is one launch (step + inline resets), latency-bound
+            fused = os.environ.get('CW_TUNE_FUSED_STEP', '1') != '0'
+            dominant, ms = ('cw_step_fused_kernel' if fused else 'cw_step_kernel'), prof['ms_step_kernel']
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
         # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)

@@ -266,6 +266,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (rt == 64 || rt == 128 || rt == 256) tn.render_threads = rt;
         tn.list_blocks = geti("CW_TUNE_LIST_BLOCKS", tn.list_blocks);
         tn.overlap = geti("CW_TUNE_OVERLAP", tn.overlap);
+        tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
         if (tn.list_blocks < 1) tn.list_blocks = 1;

@@ -23,6 +23,17 @@
 #include "cw_mt.h"
 
 #define CW_WAVE 64
+#define CW_BALLOT(p) __builtin_amdgcn_ballot_w64(p)   // the compare's own SGPR pair (__ballot goes through a select + compare)
+
+// -DCW_TRACE (make trace -> libcraftingworld_trace.so, tools/microbench only): 100 MHz wall-clock stamps of the reset's phases
+#ifdef CW_TRACE
+__device__ unsigned long long cw_trace_buf[1024 * 8];
+#define CW_STAMP(env, k) do { if (lane == 0) { cw_trace_buf[((env) & 1023) * 8 + (k)] = wall_clock64(); \
+                                               if ((k) == 0 || (k) == 5) cw_trace_buf[((env) & 1023) * 8 + 6 + ((k) ? 1 : 0)] = clock64(); } } while (0)
+extern "C" hipError_t cwk_trace_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cw_trace_buf), sizeof(cw_trace_buf)); }
+#else
+#define CW_STAMP(env, k) do { } while (0)
+#endif
 
 enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6, HOUSE = 7, WHEAT = 8 };
 // TASK_LIST bit order, ray.py:40-41
@@ -351,9 +362,9 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
     }
 
     // done-mask compaction with wavefront ballots (64-bit on CDNA)
-    const unsigned long long m_done = __ballot(done);
-    const unsigned long long m_succ = __ballot(success);
-    const unsigned long long m_inv = __ballot(invalid);
+    const unsigned long long m_done = CW_BALLOT(done);
+    const unsigned long long m_succ = CW_BALLOT(success);
+    const unsigned long long m_inv = CW_BALLOT(invalid);
     if (m_done | m_inv) {
         const int lane = threadIdx.x & (CW_WAVE - 1);
         int base = 0;
@@ -408,47 +419,54 @@ __device__ __forceinline__ void release_done_list(const CwParams &P)
 __device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
 {
     const uint32_t lane = mt.lane;
-    unsigned long long low = 0x876543210ull;        // nibble q = token at low position q (15 = none)
+    uint32_t hit = 0;                               // bit q: low position q has been swapped out (holds a non-token)
     uint32_t v_tok = 0;
     int i = n - 1;
 
     // ---- lane-parallel phase: up to 64 raw draws per round, as long as every i stays > 8.
     // Draw l of a chunk is accepted iff (d_l & mask(i_l)) <= i_l with i_l = i - #accepted before l:
-    // a prefix dependency that is resolved by iterating from "everything accepted" to the fixed point
-    // (lane 0 is exact after one pass, and a draw's fate only flips if its value sits within a few
-    // counts of i_l, so two or three passes settle all 64).  The sequential semantics are reproduced
-    // exactly; only the rare accepted draws that hit a low position (v <= 8, a token) are then
-    // replayed in lane order on the scalar unit.  A round takes at most i-8 draws, so even if all of
-    // them are accepted no i_l drops to 8; what is left of the chunk stays for the next round.
+    // a prefix dependency, resolved by iterating acc -> F(acc) to its fixed point.  F is strictly
+    // lower-triangular (lane l depends on lanes < l only), so the fixed point is unique, reached from any
+    // start, and lane l is exact after l+1 passes at the latest; starting from "accepted against the
+    // round's first i" a draw's fate only flips if its value sits within a few counts of i_l, so one or
+    // two passes settle all 64.  The sequential semantics are reproduced exactly; only the rare accepted
+    // draws that hit a low position (v <= 8) are then replayed in lane order on the scalar unit.  In this
+    // phase position i > 8 always holds a non-token, so low position q holds either its original token q
+    // or (after its first hit) a non-token: one bit per position is the whole state.  A round takes at
+    // most i-8 draws, so even if all of them are accepted no i_l drops to 8; the rest of the chunk stays
+    // for the next round.
     while (i >= 10) {
         if (mt.used == 64) mt.gen();
         const int take = min(64 - mt.used, i - 8);
         const uint32_t d = mt.v_out;
-        const bool valid = (int)lane >= mt.used && (int)lane < mt.used + take;
-        unsigned long long acc = __ballot(valid);
+        // lanes [used, used+take) hold this round's draws (take >= 1)
+        const unsigned long long valid = (~0ull >> (64 - take)) << mt.used;
+        unsigned long long acc = CW_BALLOT((d & (0xFFFFFFFFu >> __builtin_clz((uint32_t)i))) <= (uint32_t)i) & valid;
         uint32_t i_l = 0, v_l = 0;
-        for (int pass = 0; pass < 66; pass++) {
+        for (;;) {                                   // <= 64 passes (lane l is exact after l+1), typically 2
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)acc, 0u));
             i_l = (uint32_t)i - before;
             v_l = d & (0xFFFFFFFFu >> __builtin_clz(i_l));
-            const unsigned long long acc2 = __ballot(valid && v_l <= i_l);
+            const unsigned long long acc2 = CW_BALLOT(v_l <= i_l) & valid;
             if (acc2 == acc) break;
             acc = acc2;
         }
-        unsigned long long ev = __ballot(valid && v_l <= i_l && v_l <= 8u);
+        unsigned long long ev = CW_BALLOT(v_l <= 8u) & acc;
         while (ev) {                                 // token events, in draw order
             const int l = __builtin_ctzll(ev);
             ev &= ev - 1;
             const uint32_t vv = __builtin_amdgcn_readlane(v_l, l);
             const uint32_t il = __builtin_amdgcn_readlane(i_l, l);
-            const uint32_t b = (uint32_t)((low >> (4u * vv)) & 15ull);
-            if (b != 15u) v_tok = (lane == b) ? il : v_tok;          // token b is final at position il (> 8)
-            low |= 15ull << (4u * vv);                               // the non-token from il lands on vv
+            if (!((hit >> vv) & 1u)) v_tok = (lane == vv) ? il : v_tok;   // token vv is final at position il (> 8)
+            hit |= 1u << vv;                                            // the non-token from il lands on vv
         }
         i -= __popcll(acc);
         mt.used += take;
     }
+    unsigned long long low = 0;                     // nibble q = token at low position q (15 = none)
+#pragma unroll
+    for (int q = 0; q < 9; q++) low |= (unsigned long long)(((hit >> q) & 1u) ? 15u : (uint32_t)q) << (4 * q);
 
     // ---- serial tail: the last <= 9 positions, where both ends of a swap can hold tokens
     while (i >= 1) {
@@ -467,15 +485,16 @@ __device__ __forceinline__ uint32_t shuffle_tokens(CwMtWave &mt, int n)
     return v_tok;
 }
 
+// imagine_obs works on a copy of the 8 object slots held "lane = slot": lane k (< 8) of v_fp / v_fc is slot k's
+// cell / code (lanes >= 8: CW_POS_GONE / 0).  Sixteen wave-uniform values would otherwise sit in SGPRs and every
+// rank / count over them would be a chain of scalar compares; here a count is one ballot.
 // k-th (row-major) cell not in the occupied set {present slots} (+ extra cell if extra >= 0)
-__device__ __forceinline__ uint32_t kth_unoccupied(const uint32_t fp[8], int extra, uint32_t k)
+__device__ __forceinline__ uint32_t kth_unoccupied(uint32_t v_fp, int extra, uint32_t k)
 {
     uint32_t cand = k;
 #pragma unroll 1
     for (int it = 0; it < 10; it++) {
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int s = 0; s < 8; s++) cnt += (fp[s] <= cand) ? 1u : 0u;   // GONE = 0xFFFF never counts
+        uint32_t cnt = (uint32_t)__popcll(CW_BALLOT(v_fp <= cand));      // GONE / HELD (>= 0xFFFE) never count
         cnt += (extra >= 0 && (uint32_t)extra <= cand) ? 1u : 0u;
         const uint32_t nc = k + cnt;
         if (nc == cand) break;
@@ -483,30 +502,25 @@ __device__ __forceinline__ uint32_t kth_unoccupied(const uint32_t fp[8], int ext
     }
     return cand;
 }
-// among slots whose code == want (and present), the one with rank `which` in cell order
-__device__ __forceinline__ int nth_with_code(const uint32_t fp[8], const uint32_t fc[8], uint32_t want, uint32_t which)
+__device__ __forceinline__ uint32_t count_code(uint32_t v_fp, uint32_t v_fc, uint32_t want)
 {
-    int sel = -1;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const bool cand = (fc[k] == want) && (fp[k] < CW_POS_HELD);
-        uint32_t rank = 0;
-#pragma unroll
-        for (int m = 0; m < 8; m++)
-            rank += ((fc[m] == want) && (fp[m] < fp[k])) ? 1u : 0u;
-        sel = (cand && rank == which) ? k : sel;
+    return (uint32_t)__popcll(CW_BALLOT(v_fc == want && v_fp < CW_POS_HELD));
+}
+// among slots whose code == want (and present), the one with rank `which` in cell order (-1: none)
+__device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint32_t want, uint32_t which)
+{
+    const bool cand = (v_fc == want) && (v_fp < CW_POS_HELD);
+    unsigned long long m = CW_BALLOT(cand);
+    uint32_t rank = 0;                               // lane k: candidates in a cell before slot k's
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        rank += (__builtin_amdgcn_readlane(v_fp, l) < v_fp) ? 1u : 0u;
     }
-    return sel;
+    const unsigned long long sel = CW_BALLOT(cand && rank == which);
+    return sel ? __builtin_ctzll(sel) : -1;
 }
-__device__ __forceinline__ uint32_t count_code(const uint32_t fp[8], const uint32_t fc[8], uint32_t want)
-{
-    uint32_t n = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) n += ((fc[k] == want) && (fp[k] < CW_POS_HELD)) ? 1u : 0u;
-    return n;
-}
-#define CW_SET_SLOT(arr, idx, val)                                         \
-    _Pragma("unroll") for (int _k = 0; _k < 8; _k++) arr[_k] = (_k == (idx)) ? (val) : arr[_k];
+#define CW_SET_LANE(v, idx, val) v = ((int)lane == (idx)) ? (val) : v
 
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
 
@@ -519,11 +533,18 @@ struct CwResetOut {
     uint32_t desired, subset;
 };
 
-__device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env, uint32_t menu_id, uint32_t *lds_mt, int lane)
+// menu_fn() yields the env's task-menu id; it is called after the MT state's loads are in flight, so a caller that
+// still has to fetch the id (cw_reset_kernel: from the header) overlaps that fetch with them.
+template <typename MenuFn>
+__device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env, MenuFn menu_fn, uint32_t *lds_mt, int lane)
 {
+    CW_STAMP(env, 0);
+    const CwMtWave::Pending pend = CwMtWave::load_issue(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
+    const uint32_t menu_id = menu_fn();
     const CwMenuDev M = P.menus[menu_id];
     CwMtWave mt;
-    mt.load(lds_mt, P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
+    mt.load_commit(lds_mt, pend, lane);
+    CW_STAMP(env, 1);
 
     // task draw, ray.py:169-174
     const uint32_t ntasks = M.stacking ? mt.randint((uint32_t)M.number_of_tasks) + 1u : 1u;
@@ -540,82 +561,83 @@ __device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env,
         desired |= 1u << (uint32_t)((M.sel_bits >> (4 * idx)) & 15ull);
     }
 
-    // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644)
-    uint32_t fp[8], fc[8];
-    uint32_t agent;
+    CW_STAMP(env, 2);
+    // placement: sample_state (ray.py:599-628) or a pooled one (ray.py:630-644); lane v < 9 = token v's cell
+    uint32_t v_tok;
     if (P.pool_k == 0) {
-        const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
-#pragma unroll
-        for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readlane(v_tok, k);
-        agent = __builtin_amdgcn_readlane(v_tok, 8);
+        v_tok = shuffle_tokens(mt, P.ncell);
     } else {
         const uint32_t pk = mt.randint((uint32_t)P.pool_k);
         const uint16_t *pp = P.pool + ((size_t)env * P.pool_k + pk) * 9;
-#pragma unroll
-        for (int k = 0; k < 8; k++) fp[k] = __builtin_amdgcn_readfirstlane((uint32_t)pp[k]);
-        agent = __builtin_amdgcn_readfirstlane((uint32_t)pp[8]);
+        v_tok = lane < 9 ? (uint32_t)pp[lane] : 0u;
     }
+    uint32_t agent = __builtin_amdgcn_readlane(v_tok, 8);
+    uint32_t v_fp = lane < 8 ? v_tok : (uint32_t)CW_POS_GONE;    // tokens 0..7 are objects 0..7 = slots 0..7
+    uint32_t v_fc = lane < 8 ? (uint32_t)lane + 1u : 0u;
+    uint32_t ip[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) fc[k] = k + 1;
-    const uint4 init_packed = pack_pos(fp);
+    for (int k = 0; k < 8; k++) ip[k] = __builtin_amdgcn_readlane(v_tok, k);
+    const uint4 init_packed = pack_pos(ip);
     const uint32_t init_agent = agent;
+    CW_STAMP(env, 3);
 
-    // imagine_obs, ray.py:220-299, on the slot copy (fp, fc); same code order as the reference
+    // imagine_obs, ray.py:220-299, on the slot copy; same code order as the reference
     if (desired & (1u << T_MAKEBREAD)) {                          // :226-231 the wheat -> bread
-        CW_SET_SLOT(fc, 7, (uint32_t)BREAD);
+        CW_SET_LANE(v_fc, 7, (uint32_t)BREAD);
     }
     if (desired & (1u << T_EATBREAD)) {                           // :232-237
-        const uint32_t which = mt.randint(count_code(fp, fc, BREAD));
-        const int sl = nth_with_code(fp, fc, BREAD, which);
-        CW_SET_SLOT(fc, sl, (uint32_t)EMPTY);
-        CW_SET_SLOT(fp, sl, CW_POS_GONE);
+        const uint32_t which = mt.randint(count_code(v_fp, v_fc, BREAD));
+        const int sl = nth_with_code(v_fp, v_fc, BREAD, which);
+        CW_SET_LANE(v_fc, sl, (uint32_t)EMPTY);
+        CW_SET_LANE(v_fp, sl, (uint32_t)CW_POS_GONE);
     }
     if (desired & (1u << T_CHOPTREE)) {                           // :238-243 the tree -> sticks
-        CW_SET_SLOT(fc, 4, (uint32_t)STICKS);
+        CW_SET_LANE(v_fc, 4, (uint32_t)STICKS);
     }
     if (desired & (1u << T_MOVESTICKS)) {                         // :244-257
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
-        const uint32_t which_stick = mt.randint(count_code(fp, fc, STICKS));
+        const uint32_t present = (uint32_t)__popcll(CW_BALLOT(v_fp < CW_POS_HELD));
+        const uint32_t which_stick = mt.randint(count_code(v_fp, v_fc, STICKS));
         const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present - 1u);   // no object, no agent (:252)
-        const int sl = nth_with_code(fp, fc, STICKS, which_stick);
-        const uint32_t to = kth_unoccupied(fp, (int)agent, which_spot);
-        CW_SET_SLOT(fp, sl, to);
+        const int sl = nth_with_code(v_fp, v_fc, STICKS, which_stick);
+        const uint32_t to = kth_unoccupied(v_fp, (int)agent, which_spot);
+        CW_SET_LANE(v_fp, sl, to);
     }
     if (desired & (1u << T_BUILDHOUSE)) {                         // :258-264
-        const uint32_t which = mt.randint(count_code(fp, fc, STICKS));
-        const int sl = nth_with_code(fp, fc, STICKS, which);
-        CW_SET_SLOT(fc, sl, (uint32_t)HOUSE);
+        const uint32_t which = mt.randint(count_code(v_fp, v_fc, STICKS));
+        const int sl = nth_with_code(v_fp, v_fc, STICKS, which);
+        CW_SET_LANE(v_fc, sl, (uint32_t)HOUSE);
     }
     if (desired & (1u << T_CHOPROCK)) {                           // :265-268
-        CW_SET_SLOT(fc, 3, (uint32_t)EMPTY);
-        CW_SET_SLOT(fp, 3, CW_POS_GONE);
+        CW_SET_LANE(v_fc, 3, (uint32_t)EMPTY);
+        CW_SET_LANE(v_fp, 3, (uint32_t)CW_POS_GONE);
     }
     if (desired & (1u << T_GOTOHOUSE)) {                          // :269-276
-        const uint32_t which = mt.randint(count_code(fp, fc, HOUSE));
-        const int sl = nth_with_code(fp, fc, HOUSE, which);
-#pragma unroll
-        for (int k = 0; k < 8; k++) agent = (k == sl) ? fp[k] : agent;
+        const uint32_t which = mt.randint(count_code(v_fp, v_fc, HOUSE));
+        const int sl = nth_with_code(v_fp, v_fc, HOUSE, which);
+        if (sl >= 0) agent = __builtin_amdgcn_readlane(v_fp, sl);
     }
     if (desired & (1u << T_MOVEAXE)) {                            // :277-286 (agent cell allowed, :282)
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t present = (uint32_t)__popcll(CW_BALLOT(v_fp < CW_POS_HELD));
         const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-        CW_SET_SLOT(fp, 1, to);
+        const uint32_t to = kth_unoccupied(v_fp, -1, which_spot);
+        CW_SET_LANE(v_fp, 1, to);
     }
     if (desired & (1u << T_MOVEHAMMER)) {                         // :287-297
-        uint32_t present = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) present += (fp[k] < CW_POS_HELD) ? 1u : 0u;
+        const uint32_t present = (uint32_t)__popcll(CW_BALLOT(v_fp < CW_POS_HELD));
         const uint32_t which_spot = mt.randint((uint32_t)P.ncell - present);
-        const uint32_t to = kth_unoccupied(fp, -1, which_spot);
-        CW_SET_SLOT(fp, 2, to);
+        const uint32_t to = kth_unoccupied(v_fp, -1, which_spot);
+        CW_SET_LANE(v_fp, 2, to);
+    }
+    uint32_t fp[8], fc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        fp[k] = __builtin_amdgcn_readlane(v_fp, k);
+        fc[k] = __builtin_amdgcn_readlane(v_fc, k);
     }
 
+    CW_STAMP(env, 4);
     mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);   // coalesced write-back
+    CW_STAMP(env, 5);
     CwResetOut r;
     uint32_t goal_codes = 0;
 #pragma unroll
@@ -686,15 +708,18 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
-    const int count = all_envs ? P.n_envs : P.done_count[0];
     // few, latency-critical waves sharing CUs with the render kernel's store-bound waves: win arbitration
     if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
+    // the wave's first list entry is fetched together with the count (entries past the count are stale but in bounds)
+    const int first = (!all_envs && wave < P.n_envs) ? P.done_list[wave] : 0;
+    const int count = all_envs ? P.n_envs : P.done_count[0];
     for (int job = wave; job < count; job += n_waves) {
-        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.done_list[job]);
-        const uint32_t h_old_x = __builtin_amdgcn_readfirstlane(P.hdr[env].x);
-        const uint32_t h_old_z = __builtin_amdgcn_readfirstlane(P.hdr[env].z);
-        const uint32_t menu_id = h_old_x >> 24;
-        const CwResetOut r = reset_env_wave(P, env, menu_id, s_mt[wave_in_block], lane);
+        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : (job == wave ? first : P.done_list[job]));
+        const uint32_t v_hx = P.hdr[env].x, v_hz = P.hdr[env].z;     // in flight beside the MT state
+        uint32_t menu_id = 0;
+        const CwResetOut r = reset_env_wave(P, env, [&]() { menu_id = __builtin_amdgcn_readfirstlane(v_hx) >> 24; return menu_id; },
+                                            s_mt[wave_in_block], lane);
+        const uint32_t h_old_z = __builtin_amdgcn_readfirstlane(v_hz);
         if (lane == 0) {
             store_episode_records(P, env, r, (h_old_z & 0xFFFFu) != 0);
             P.pos[env] = r.init_pos;
@@ -740,17 +765,17 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
             if (rewards) rewards[(size_t)t * P.n_envs + env] = o.reward;
             if (dones) dones[(size_t)t * P.n_envs + env] = o.done ? 1 : 0;
         }
-        unsigned long long m = __ballot(live && o.done);
+        unsigned long long m = CW_BALLOT(live && o.done);
         n_done += __popcll(m);
-        n_succ += __popcll(__ballot(live && o.success));
-        n_inv += __popcll(__ballot(live && o.invalid));
+        n_succ += __popcll(CW_BALLOT(live && o.success));
+        n_inv += __popcll(CW_BALLOT(live && o.invalid));
         if (m && t + 1 == T && live && o.done) P.episode_length[env] = (int32_t)o.step_num;
         while (m) {                                  // auto-reset, one finished env at a time, whole wave
             const int l = __builtin_ctzll(m);
             m &= m - 1;
             const int env_l = env0 + l;
             const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
-            const CwResetOut r = reset_env_wave(P, env_l, menu_id, s_mt[wave_in_block], lane);
+            const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
             if (lane == 0) store_episode_records(P, env_l, r, true);   // step_num >= 1 here
             if (lane == l) {
                 h = reset_header(P, r, menu_id);
@@ -776,6 +801,103 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
     }
 }
 
+// One cw_step with auto-reset as a SINGLE launch (state-only and dirty-cell pixel modes): a wavefront owns `epw`
+// consecutive envs (8..64, one per lane), steps them, and resets the ones that finished itself, one after the
+// other with all 64 lanes (reset_env_wave) -- painting their frames in the pixel mode.  No done list, no second
+// launch waiting on the first: a step is bounded by one launch plus one reset's latency.  The full-frame pixel
+// mode keeps the separate kernels (its reset hides under the render kernel on a side stream).
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
+                                                                                int paint, int epw)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
+    const int env0 = wave * epw;
+    if (env0 >= P.n_envs) return;
+    const int env = env0 + lane;
+    const bool live = lane < epw && env < P.n_envs;
+    const int e = live ? env : env0;                 // idle lanes shadow a valid env (their results are dropped)
+    int a;
+    if (act_dtype == 0) a = ((const int32_t *)actions)[e];
+    else if (act_dtype == 1) a = (int)((const long long *)actions)[e];
+    else a = ((const uint8_t *)actions)[e];
+    uint4 h = P.hdr[e];
+    uint32_t sp[8];
+    unpack_pos(P.pos[e], sp);
+    const CwStepOut o = step_env(P, h, sp, a, [&]() { return P.init_pos[e]; });
+    const bool done = live && o.done;
+    if (live) {
+        P.reward[env] = o.reward;
+        P.done[env] = o.done ? 1 : 0;
+        P.achieved_out[env] = (uint16_t)o.achieved;
+        P.desired_out[env] = (uint16_t)o.desired;
+        if (o.done) P.episode_length[env] = (int32_t)o.step_num;
+        if (paint && o.changed && !o.done) {                               // render_edit, :358 (a finished env is
+            uint8_t *frame = P.obs + (size_t)env * P.frame_bytes;          //  repainted whole by its reset below)
+            const uint32_t hold = (h.x >> 16) & 0xFFu;
+            const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+            if (P.raster == 1) {
+                const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
+                alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
+                if (o.dirty1 != 0xFFFFFFFFu) {
+                    const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
+                    alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
+                }
+                alt_paint_strip(frame, P.size, hold, 0, 1, false);
+            } else {
+                paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+                if (o.dirty1 != 0xFFFFFFFFu)
+                    paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+            }
+        }
+    }
+    unsigned long long m = CW_BALLOT(done);
+    const unsigned long long m_succ = CW_BALLOT(live && o.success);
+    const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
+    if (lane == 0) {                                 // (one same-address atomic per wave would serialise the grid in L2)
+        if (wave == 0) atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
+        if (m) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m));
+        if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
+        if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
+    }
+    if (m && P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int env_l = env0 + l;
+        const uint32_t hx = __builtin_amdgcn_readlane(h.x, l);
+        if (paint && P.terminal_img) {               // keep_terminal_obs: the finished episode's last frame
+            uint32_t tp[8], rgb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) tp[k] = __builtin_amdgcn_readlane(sp[k], l);
+            const uint32_t codes = __builtin_amdgcn_readlane(h.w, l);
+            const uint32_t acell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
+            const uint32_t hold = (hx >> 16) & 0xFFu;
+            uint8_t *dst = P.terminal_img + (size_t)env_l * P.frame_bytes;
+            if (P.raster == 1) {
+                render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, tp, codes, acell, hold, lane);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
+                render_frame(dst, nullptr, P.size, P.ncell, P.div_magic, tp, rgb, acell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
+            }
+        }
+        const uint32_t menu_id = hx >> 24;
+        const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
+        if (lane == 0) store_episode_records(P, env_l, r, true);           // step_num >= 1 here
+        if (lane == l) {
+            h = reset_header(P, r, menu_id);
+            unpack_pos(r.init_pos, sp);
+        }
+        if (paint) paint_reset_frames(P, env_l, r, lane);
+    }
+    if (live) {
+        P.hdr[env] = h;
+        P.pos[env] = pack_pos(sp);
+    }
+}
+
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwParams P)
 {
@@ -785,7 +907,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwPara
     const int n_waves = gridDim.x * CW_RESET_WAVES;
     for (int env = blockIdx.x * CW_RESET_WAVES + wave_in_block; env < P.n_envs; env += n_waves) {
         CwMtWave mt;
-        mt.load(s_mt[wave_in_block], P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx[env], lane);
+        mt.load(s_mt[wave_in_block], P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
         for (int k = 0; k < P.pool_k; k++) {
             const uint32_t v_tok = shuffle_tokens(mt, P.ncell);
             uint16_t *pp = P.pool + ((size_t)env * P.pool_k + k) * 9;
@@ -1024,6 +1146,15 @@ static inline int cw_reset_grid(int jobs)
     return blocks;
 }
 
+// envs per wavefront of the kernels that reset inline (resets are serial within a wave): aim for ~4096 waves
+// (4 per SIMD) -- 64 envs per wave for large batches, down to 8 for small ones
+static int cw_envs_per_wave(int n)
+{
+    int epw = 64;
+    while (epw > 8 && (n + epw - 1) / epw < 4096) epw >>= 1;
+    return epw;
+}
+
 extern "C" {
 
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
@@ -1040,6 +1171,14 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     const bool overlapped = (obs_mode == 1 && auto_reset && tn.overlap);
     const bool ev_all = ev && (tn.profile_side || !overlapped);
     if (ev_all) (void)hipEventRecord(ev[0], st);
+    if (auto_reset && obs_mode != 1 && tn.fused_step) {        // state-only / dirty-cell: the whole step is one launch
+        const int epw = cw_envs_per_wave(n);
+        const int waves = (n + epw - 1) / epw;
+        hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
+                           *P, actions, act_dtype, pixels ? 1 : 0, epw);
+        if (ev) for (int k = 1; k < 6; k++) (void)hipEventRecord(ev[k], st);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev_all) (void)hipEventRecord(ev[1], st);
@@ -1070,9 +1209,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
 
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st)
 {
-    // aim for ~4096 waves (4 per SIMD): envs per wave = 64 for large batches, down to 8 for small ones
-    int epw = 64;
-    while (epw > 8 && (P->n_envs + epw - 1) / epw < 4096) epw >>= 1;
+    const int epw = cw_envs_per_wave(P->n_envs);
     const int waves = (P->n_envs + epw - 1) / epw;
     hipLaunchKernelGGL(cw_rollout_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
                        *P, actions, T, rewards, dones, epw);

@@ -46,6 +46,7 @@ struct CwTuning {
     int render_threads = 256;       // threads per render workgroup (64, 128, 256)
     int list_blocks = 256;          // workgroups of the done-list (terminal-frame) render
     int overlap = 1;                // full-pixel step: reset (+ its frames) on the side stream beside the main render
+    int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
 };
 

@@ -33,15 +33,37 @@ struct CwMtWave {
 
     static __device__ __forceinline__ int wrap(int i) { return i >= CW_MT_WORDS ? i - CW_MT_WORDS : i; }
 
-    __device__ __forceinline__ void load(uint32_t *lds, const uint32_t *g, int gidx, int lane_)
+    // the state comes in two halves so that a caller can put other loads (and the uses of earlier ones) between
+    // the issue of these ten and the wait for them: one memory round trip instead of two or three in a row
+    struct Pending { uint32_t w[10]; int gidx; };
+    static __device__ __forceinline__ Pending load_issue(const uint32_t *g, const int32_t *gidx_p, int lane_)
+    {
+        Pending q;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int j = lane_ + 64 * k;
+            q.w[k] = (j < CW_MT_WORDS) ? g[j] : 0u;
+        }
+        q.gidx = *gidx_p;
+        return q;
+    }
+    __device__ __forceinline__ void load_commit(uint32_t *lds, const Pending &q, int lane_)
     {
         s = lds;
         lane = lane_;
-        for (int j = lane; j < CW_MT_WORDS; j += 64) s[j] = g[j];
-        idx = __builtin_amdgcn_readfirstlane(gidx);
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int j = lane_ + 64 * k;
+            if (j < CW_MT_WORDS) s[j] = q.w[k];
+        }
+        idx = __builtin_amdgcn_readfirstlane(q.gidx);
         used = 64;
         v_out = 0;
         v_old = 0;
+    }
+    __device__ __forceinline__ void load(uint32_t *lds, const uint32_t *g, const int32_t *gidx_p, int lane_)
+    {
+        load_commit(lds, load_issue(g, gidx_p, lane_), lane_);
     }
     __device__ __forceinline__ void gen()
     {

@@ -854,3 +854,50 @@ def test_systematic_transition_table():
             assert np.array_equal(frames[i], s['obs']), tag
         env.close()
     assert N > 20000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode,raster,N', [('state', 'ray', 1003), ('state', 'ray', 70001), ('pixels_dirty', 'ray', 5000),
+                                               ('pixels_dirty', 'alt', 777)])
+def test_single_launch_step_equals_separate_kernels(obs_mode, raster, N, monkeypatch):
+    """State-only and dirty-cell modes run a whole auto-reset step as ONE launch (cw_step_fused_kernel: a wave
+    steps its envs and resets the finished ones inline); CW_TUNE_FUSED_STEP=0 selects the separate step / reset
+    kernels the full-frame mode uses.  Same seeds and actions: every buffer, counter and RNG stream must agree,
+    with batch sizes that leave the last wavefront partly filled."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    kw = dict(size=(9, 9), max_steps=17, obs_mode=obs_mode, raster=raster, seed=77)
+    if obs_mode != 'state':
+        kw['keep_terminal_obs'] = True
+    one = CraftingWorldVecEnv(N, **kw)
+    monkeypatch.setenv('CW_TUNE_FUSED_STEP', '0')
+    two = CraftingWorldVecEnv(N, **kw)
+    monkeypatch.delenv('CW_TUNE_FUSED_STEP')
+    one.reset(); two.reset()
+    phase = (np.arange(N) * 5 % 17).astype(np.int32)          # some envs finish on every step
+    one.set_state(step_num=phase); two.set_state(step_num=phase)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    ended = 0
+    for t in range(120):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.int64 if t % 2 else torch.uint8, generator=gen)
+        o1, r1, d1, i1 = one.step(a)
+        o2, r2, d2, i2 = two.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), t
+        ended += int(d1.sum())
+        if t % 10 == 0 or t == 119:
+            assert torch.equal(one.hdr, two.hdr) and torch.equal(one.slot_pos, two.slot_pos), t
+            for k in ('achieved_goal', 'desired_goal'):
+                assert torch.equal(i1[k], i2[k]), (t, k)
+            m = d1.nonzero().squeeze(1)
+            assert torch.equal(i1['episode_length'][m], i2['episode_length'][m]), t
+            if obs_mode != 'state':
+                for k in ('observation', 'desired_goal', 'init_observation'):
+                    assert torch.equal(o1[k], o2[k]), (t, k)
+                assert torch.equal(i1['terminal_observation'][m], i2['terminal_observation'][m]), t
+    assert ended > N
+    assert torch.equal(one.counters, two.counters)
+    s1, s2 = one.get_state(), two.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k
+    k1, p1 = one.get_rng_states(); k2, p2 = two.get_rng_states()
+    assert np.array_equal(k1, k2) and np.array_equal(p1, p2)
+    one.close(); two.close()

@@ -1,0 +1,33 @@
+"""Per-step wall time (HIP events) of cw_step: median, and the synchronized time-out steps.
+    python tools/microbench/time_steps.py [obs_mode] [n_envs] [desync]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from gym_craftingworld_amd import CraftingWorldVecEnv
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'state'
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+env = CraftingWorldVecEnv(N, size=(21, 21), max_steps=300, obs_mode=mode, seed=0)
+env.reset()
+desync = len(sys.argv) > 3 and sys.argv[3] == 'desync'
+if desync:      # steady state of a long run: episode phases spread out, ~N/300 envs finish on every step
+    import numpy as np
+    env.set_state(step_num=(np.arange(N) * 7 % 300).astype(np.int32))
+T = 640
+acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.uint8)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(T + 1)]
+for t in range(20):
+    env.step(acts[t])
+torch.cuda.synchronize()
+ev[0].record()
+for t in range(T):
+    env.step(acts[t])
+    ev[t + 1].record()
+torch.cuda.synchronize()
+ms = torch.tensor([ev[t].elapsed_time(ev[t + 1]) for t in range(T)])
+srt = ms.sort().values
+top = ms.topk(4)
+print('%s N=%d %s fused=%s: median %.1f us, p90 %.1f us, mean %.1f us, slowest steps %s' % (
+    mode, N, 'desync' if desync else 'sync', os.environ.get('CW_TUNE_FUSED_STEP', '1'), 1e3 * srt[T // 2], 1e3 * srt[int(T * 0.9)], 1e3 * ms.mean(),
+    ', '.join('t=%d: %.0f us' % (20 + i, 1e3 * v) for v, i in zip(top.values.tolist(), top.indices.tolist()))))
+env.close()
