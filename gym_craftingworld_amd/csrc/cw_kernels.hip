@@ -960,13 +960,12 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
 // mode 2: every env -> ext_out only                                               (cw_render)
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
 //         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
-// Per-env records are wave-uniform, so they are fetched with SCALAR loads (s_load_dwordx4 through
-// the constant cache, lgkmcnt domain; cload below).  This matters: a vector load in the frame loop
-// makes hipcc wait vmcnt(0) before the next frame -- loads and stores retire in one in-order counter
-// -- which drains all 28 outstanding frame stores of the wave once per frame (measured 0.320 ms vs
-// 0.274 ms per launch).  With scalar loads the wave never waits on its stores.  The records of the
-// next CW_REC_AHEAD frames are requested before the current frame is stored: they were written by the
-// step kernel a moment ago, so they miss to HBM under the render's own write storm.
+// Per-env records are wave-uniform and must not be loaded inside the frame loop: loads and stores retire through
+// one in-order counter (vmcnt), so waiting for a vector load there drains the wave's 28 outstanding frame stores
+// once per frame (measured 0.320 ms vs 0.274 ms per launch).  First fix: scalar loads (constant cache, lgkmcnt
+// domain) one frame ahead.  Current form (render_jobs): the records of a wave's next 64 frames are fetched one per
+// lane BEFORE the wave has a store in flight and handed out with v_readlane -- 2 % faster again on the same box
+// (the scalar loads missed to HBM under the render's own write storm, where a round trip takes ~25 us).
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 
 template <typename T>
@@ -980,20 +979,6 @@ struct CwEnvRec {
     uint32_t done_word;
     int env;
 };
-template <int MODE>
-__device__ __forceinline__ CwEnvRec rec_load(const CwParams &P, int job, int n_jobs, bool want_done)
-{
-    CwEnvRec r;
-    r.env = -1;
-    if (job < n_jobs) {
-        const int env = (MODE == 4) ? cload(P.done_list + job) : job;
-        r.env = env;
-        r.h = cload((const u32x4s *)(P.hdr + env));
-        r.pp = cload((const u32x4s *)(P.pos + env));
-        r.done_word = want_done ? cload((const uint32_t *)(P.done + (env & ~3))) : 0u;
-    }
-    return r;
-}
 __device__ __forceinline__ void unpack_pos_s(const u32x4s &v, uint32_t sp[8])
 {
     sp[0] = v.x & 0xFFFFu; sp[1] = v.x >> 16;
@@ -1001,10 +986,6 @@ __device__ __forceinline__ void unpack_pos_s(const u32x4s &v, uint32_t sp[8])
     sp[4] = v.z & 0xFFFFu; sp[5] = v.z >> 16;
     sp[6] = v.w & 0xFFFFu; sp[7] = v.w >> 16;
 }
-
-#ifndef CW_REC_AHEAD
-#define CW_REC_AHEAD 1   // deeper look-ahead (2, 4) measured no better in-step: profiles/r01_render_sweeps.txt
-#endif
 
 template <int MODE>
 __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cur, bool want_done, uint8_t *ext_out, int lane)
@@ -1045,6 +1026,10 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
 //         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
 // mode 4: envs in the done list, BEFORE their reset -> terminal_img only            (keep_terminal_obs)
+// Records in lanes: lane l fetches the records of the wave's l-th next frame, so the records of 64 frames are
+// requested at once, BEFORE the wave has a store in flight, and the frame loop itself has no load at all (frame k's
+// wave-uniform record is 9 v_readlane).  With 1024 waves and 65 536 envs that is the whole launch; larger batches
+// reload every 64 frames (the only point where the wave waits for its stores).
 template <int MODE>
 __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out)
 {
@@ -1052,20 +1037,37 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
     const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
     const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
     const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
-    if (wave >= n_jobs) return;   // (wave-uniform; the caller's release_done_list barrier comes after the call)
+    if (wave >= n_jobs) return;   // (wave-uniform)
     const bool want_done = (MODE == 3) && skip_done;
-    // software pipeline on the scalar unit, CW_REC_AHEAD frames deep
-    CwEnvRec cur[CW_REC_AHEAD], nxt[CW_REC_AHEAD];
-#pragma unroll
-    for (int k = 0; k < CW_REC_AHEAD; k++) nxt[k] = rec_load<MODE>(P, wave + k * n_waves, n_jobs, want_done);
-    for (int base = wave; base < n_jobs; base += CW_REC_AHEAD * n_waves) {
-#pragma unroll
-        for (int k = 0; k < CW_REC_AHEAD; k++) cur[k] = nxt[k];
-#pragma unroll
-        for (int k = 0; k < CW_REC_AHEAD; k++)
-            nxt[k] = rec_load<MODE>(P, base + (CW_REC_AHEAD + k) * n_waves, n_jobs, want_done);
-#pragma unroll
-        for (int k = 0; k < CW_REC_AHEAD; k++) render_one<MODE>(P, cur[k], want_done, ext_out, lane);
+    const int stride = CW_WAVE * n_waves;            // frames between two batches of this wave (n_waves <= 4096)
+    for (int base = wave;; base += stride) {
+        const int left = n_jobs - base;              // > 0
+        const int myoff = lane * n_waves;
+        int v_env = -1;
+        uint4 v_h = make_uint4(0, 0, 0, 0), v_p = make_uint4(0, 0, 0, 0);
+        uint32_t v_done = 0;
+        if (myoff < left) {
+            v_env = (MODE == 4) ? P.done_list[base + myoff] : base + myoff;
+            v_h = P.hdr[v_env];
+            v_p = P.pos[v_env];
+            if (want_done) v_done = P.done[v_env];
+        }
+        const int in_batch = left >= stride ? CW_WAVE : (int)(((uint32_t)left + (uint32_t)n_waves - 1u) / (uint32_t)n_waves);
+        for (int k = 0; k < in_batch; k++) {
+            CwEnvRec cur;
+            cur.env = __builtin_amdgcn_readlane(v_env, k);
+            cur.h.x = __builtin_amdgcn_readlane(v_h.x, k);
+            cur.h.y = 0u;
+            cur.h.z = 0u;
+            cur.h.w = __builtin_amdgcn_readlane(v_h.w, k);
+            cur.pp.x = __builtin_amdgcn_readlane(v_p.x, k);
+            cur.pp.y = __builtin_amdgcn_readlane(v_p.y, k);
+            cur.pp.z = __builtin_amdgcn_readlane(v_p.z, k);
+            cur.pp.w = __builtin_amdgcn_readlane(v_p.w, k);
+            cur.done_word = __builtin_amdgcn_readlane(v_done, k) << (8 * (cur.env & 3));
+            render_one<MODE>(P, cur, want_done, ext_out, lane);
+        }
+        if (left <= stride) break;
     }
 }
 
