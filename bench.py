@@ -196,7 +196,7 @@ def main():
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
     # step (the reference's own render_edit strategy), state-only has no frames at all.
     other = {}
-    if rank == 0 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
+    if rank == 0 and world == 1 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
         env.close()
         for mode in ('pixels_dirty', 'state'):
             e2 = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo)
@@ -264,7 +264,7 @@ def main():
             'episodes_finished': episodes,
             'other_obs_modes_1gpu': other,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (task contract)
             out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)
         print(json.dumps(out))
     if not other:
