@@ -240,6 +240,19 @@ def main():
                 traffic = json.load(open(pmcs[-1])).get('hbm_bytes_per_launch')
             except Exception:  # noqa: BLE001
                 traffic = None
+        # the practical ceiling beside the spec peak: a plain device fill of the same number of bytes,
+        # timed on this box right now (torch's vectorised fill kernel, median of 9)
+        fill_gbs = None
+        if world == 1 and args.obs_mode == 'pixels':
+            probe = torch.empty(int(alg_bytes), dtype=torch.uint8, device=dev)
+            ts = []
+            for i in range(11):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); probe.fill_(i); e1.record(); e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts = sorted(ts[2:])
+            fill_gbs = alg_bytes / (ts[len(ts) // 2] * 1e-3) / 1e9
+            del probe
         out = {
             'metric': 'env-steps/sec at 65536 envs, 1/2/4/8 MI355X; bit-exact vs CPU ref',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -254,6 +267,7 @@ def main():
                        'launch': launch_desc},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
                          'launch_ms_min_max': [prof['ms_render_kernel_min'], prof['ms_render_kernel_max']],
                          'events': 'hipEventRecord on the launch stream around every kernel, %d launches' % prof['steps']},

@@ -30,7 +30,7 @@ class cw_config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('size', C.c_int32),
                 ('max_steps', C.c_int32), ('n_task_list', C.c_int32), ('fixed_init_state', C.c_int32),
                 ('obs_mode', C.c_int32), ('auto_reset', C.c_int32), ('keep_terminal_obs', C.c_int32),
-                ('raster', C.c_int32), ('n_menus', C.c_int32),
+                ('raster', C.c_int32), ('host_outputs', C.c_int32), ('n_menus', C.c_int32),
                 ('menus', C.POINTER(cw_task_menu)), ('env_menu', C.POINTER(C.c_uint8))]
 
 
@@ -38,7 +38,8 @@ class cw_buffer_table(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('desired_goal', C.c_void_p), ('init_obs', C.c_void_p), ('terminal_obs', C.c_void_p),
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('achieved', C.c_void_p),
                 ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('hdr', C.c_void_p),
-                ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t)]
+                ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t),
+                ('host_actions', C.c_void_p)]
 
 
 class cw_state_view(C.Structure):
@@ -73,6 +74,7 @@ ABI = {
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
+    'cw_synchronize': (C.c_int, [_VP, _VP]),
     'cw_num_envs': (C.c_int, [_VP]),
     'cw_abi_version': (C.c_int, []),
     'cw_last_error': (C.c_char_p, []),

@@ -64,6 +64,8 @@ struct cw_engine {
     CwParams P{};
     CwTuning tune{};
     std::vector<void *> allocs;
+    std::vector<void *> host_allocs;   // hipHostMalloc'ed (cw_config.host_outputs)
+    int32_t *host_actions = nullptr;
     std::vector<CwMenuDev> menus;
     int n = 0, S = 0, ncell = 0, K = 0;
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
@@ -163,6 +165,23 @@ static int dev_alloc(cw_engine *e, T **out, size_t count)
     HIP_TRY(hipMalloc(&p, bytes));
     HIP_TRY(hipMemset(p, 0, bytes));
     e->allocs.push_back(p);
+    *out = (T *)p;
+    return CW_OK;
+}
+
+// pinned host memory mapped into the device's address space: kernels store into it directly (over PCIe), the host
+// reads it after a stream sync -- the single-env loop's outputs (cw_config.host_outputs)
+template <typename T>
+static int host_alloc(cw_engine *e, T **out, size_t count)
+{
+    void *p = nullptr, *d = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    e->host_allocs.push_back(p);
+    memset(p, 0, bytes);
+    HIP_TRY(hipHostGetDevicePointer(&d, p, 0));
+    if (d != p) return fail(CW_ERR_HIP, "cw_create: mapped host memory has a different device address (no unified addressing)");
     *out = (T *)p;
     return CW_OK;
 }
@@ -286,20 +305,25 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC(mt, N * CW_MT_N);
     ALLOC(mt_idx, N);
     ALLOC(pool, N * (size_t)e->K * 9);
-    ALLOC(reward, N);
-    ALLOC(done, N);
-    ALLOC(achieved_out, N);
-    ALLOC(desired_out, N);
-    ALLOC(episode_length, N);
+    // step outputs and frames: device memory, or mapped host memory for the single-env loop
+#define ALLOC_OUT(field, count)                                 \
+    if (rc == CW_OK) rc = cfg->host_outputs ? host_alloc(e, &P.field, (count)) : dev_alloc(e, &P.field, (count))
+    ALLOC_OUT(reward, N);
+    ALLOC_OUT(done, N);
+    ALLOC_OUT(achieved_out, N);
+    ALLOC_OUT(desired_out, N);
+    ALLOC_OUT(episode_length, N);
     ALLOC(done_list, N);
     ALLOC(done_count, 2);
     ALLOC(counters, 4);
     if (cfg->obs_mode != CW_OBS_STATE) {
-        ALLOC(obs, N * P.frame_bytes);
-        ALLOC(desired_img, N * P.frame_bytes);
-        ALLOC(init_img, N * P.frame_bytes);
-        if (cfg->keep_terminal_obs && cfg->auto_reset) ALLOC(terminal_img, N * P.frame_bytes);
+        ALLOC_OUT(obs, N * P.frame_bytes);
+        ALLOC_OUT(desired_img, N * P.frame_bytes);
+        ALLOC_OUT(init_img, N * P.frame_bytes);
+        if (cfg->keep_terminal_obs && cfg->auto_reset) ALLOC_OUT(terminal_img, N * P.frame_bytes);
     }
+    if (cfg->host_outputs && rc == CW_OK) rc = host_alloc(e, &e->host_actions, N);
+#undef ALLOC_OUT
 #undef ALLOC
     CwMenuDev *dmenus = nullptr;
     if (rc == CW_OK) rc = dev_alloc(e, &dmenus, menus.size());
@@ -322,6 +346,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         rc = fail(CW_ERR_HIP, "cw_create: side stream / event creation failed");
     if (rc != CW_OK) {
         for (void *p : e->allocs) (void)hipFree(p);
+        for (void *p : e->host_allocs) (void)hipHostFree(p);
         if (e->side) (void)hipStreamDestroy(e->side);
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -350,6 +375,7 @@ int cw_destroy(cw_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (void *p : e->allocs) (void)hipFree(p);
+    for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
     return CW_OK;
 }
@@ -524,6 +550,15 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out)
     out->slot_pos = (uint16_t *)P.pos;
     out->counters = (uint64_t *)P.counters;
     out->frame_bytes = P.frame_bytes;
+    out->host_actions = e->host_actions;
+    return CW_OK;
+}
+
+int cw_synchronize(cw_engine *e, cw_stream_t stream)
+{
+    if (!e) return fail(CW_ERR_INVALID, "cw_synchronize: null engine");
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return CW_OK;
 }
 

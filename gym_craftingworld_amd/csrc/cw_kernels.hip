@@ -724,6 +724,10 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
             store_episode_records(P, env, r, (h_old_z & 0xFFFFu) != 0);
             P.pos[env] = r.init_pos;
             P.hdr[env] = reset_header(P, r, menu_id);
+            if (all_envs) {                          // explicit reset(): the mask outputs describe the new episode
+                P.achieved_out[env] = 0;             // (an auto-reset leaves them at the finished step's values)
+                P.desired_out[env] = (uint16_t)r.desired;
+            }
         }
         if (paint) paint_reset_frames(P, env, r, lane);
     }

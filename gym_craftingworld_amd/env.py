@@ -1,6 +1,11 @@
 """Single-env gym.Env-shaped façades over the HIP engine with num_envs=1 -- the drop-in for
 `gym.make('craftingworld-v3')` & co. (reference registration: gym_craftingworld/__init__.py:5-18).
 
+The engine runs with cw_config.host_outputs: its kernels write frames, reward, done and the goal masks straight
+into pinned host memory, so a step() is one kernel launch and one stream sync -- no copies.  With the default
+uint8 dtype the returned arrays ARE those buffers, mutated in place by later steps: the reference's own aliasing
+contract (obs['observation'] is env.obs_image, ray.py:194-196).
+
 Same ctor kwargs, return shapes and aliasing as the reference classes:
   CraftingWorldEnv        <- CraftingWorldEnvRay      (craftingworld_ray.py:53)
   CraftingWorldEnvFlat    <- CraftingWorldEnvFlat     (craftingworld_flat.py:46)
@@ -9,6 +14,8 @@ Host arrays are numpy (uint8 by default; reference_dtypes=True up-casts to the r
 No auto-reset: after done the caller calls reset(), exactly like the reference loop
 (docs/source/envs/gen_info.rst:62-82).  Compute still runs on the GPU; there is no CPU path.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -34,7 +41,7 @@ class CraftingWorldEnv:
                                         selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
                                         stacking=stacking, reward_style=reward_style, obs_mode='pixels_dirty',
                                         device=device, seed=seed, seed_style='gym', auto_reset=False,
-                                        raster=self._raster)
+                                        raster=self._raster, host_outputs=True)
         v = self._vec
         self.STATE_W, self.STATE_H = v.STATE_W, v.STATE_H
         self.MAX_STEPS = v.MAX_STEPS
@@ -51,13 +58,23 @@ class CraftingWorldEnv:
         self.ACTIONS = list(ACTION_NAMES)
         self.ep_no = 0
         self.step_num = 0
-        self.obs_image = np.zeros(fs, self._dtype)
-        self.desired_goal = np.zeros(fs, self._dtype)
-        self.INIT_OBS = np.zeros(fs, self._dtype)
+        # the engine's host-mapped buffers (row 0 of the batch of one)
+        self._h_obs, self._h_goal, self._h_init = (t[0].numpy() for t in (v._obs, v._desired_img, v._init_img))
+        self._h_reward, self._h_done = v.reward.numpy(), v._done_u8.numpy()
+        self._h_ach, self._h_des = v.achieved_mask.numpy().view(np.uint16), v.desired_mask.numpy().view(np.uint16)
+        self._live = not reference_dtypes           # uint8: hand out the live buffers themselves
+        self.obs_image = self._h_obs if self._live else np.zeros(fs, self._dtype)
+        self.desired_goal = self._h_goal if self._live else np.zeros(fs, self._dtype)
+        self.INIT_OBS = self._h_init if self._live else np.zeros(fs, self._dtype)
         self.observation = None
         self.desired_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)  # ray.py:112
         self.achieved_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)
-        self._act = torch.zeros(1, dtype=torch.int32, device=v.device)
+        self._bit_rows = ((np.arange(1 << len(self.task_list))[:, None] >> np.arange(len(self.task_list))) & 1) \
+            if len(self.task_list) <= 12 else None                                # mask -> 0/1 row
+        # the per-step call sequence, bound once: cw_step on the mapped action buffer, then one stream sync
+        self._lib, self._eng, self._stream = v._lib, v._h, v._stream()
+        self._act = v._host_actions
+        self._act_p = C.c_void_p(self._act.ctypes.data)
 
     # -- reference attributes derived from the device state on demand --------------------
     @property
@@ -86,12 +103,14 @@ class CraftingWorldEnv:
         return k[0], int(p[0])
 
     def _pull_goals(self):
-        hdr = self._vec.hdr[0].cpu().numpy()
-        ach = int(hdr[4]) | (int(hdr[5]) << 8)
-        des = int(hdr[6]) | (int(hdr[7]) << 8)
-        n = len(self.task_list)
-        self.achieved_goal_vector[0, :] = [(ach >> i) & 1 for i in range(n)]      # mutated in place, like ray.py:659
-        self.desired_goal_vector[0, :] = [(des >> i) & 1 for i in range(n)]
+        ach, des = int(self._h_ach[0]), int(self._h_des[0])
+        if self._bit_rows is not None:
+            self.achieved_goal_vector[0, :] = self._bit_rows[ach]                 # mutated in place, like ray.py:659
+            self.desired_goal_vector[0, :] = self._bit_rows[des]
+        else:
+            n = len(self.task_list)
+            self.achieved_goal_vector[0, :] = [(ach >> i) & 1 for i in range(n)]
+            self.desired_goal_vector[0, :] = [(des >> i) & 1 for i in range(n)]
 
     def _obs_dict(self):
         self.observation = {'observation': self.obs_image, 'desired_goal': self.desired_goal,
@@ -102,25 +121,36 @@ class CraftingWorldEnv:
         if self.step_num != 0:                                                    # ray.py:200-201
             self.ep_no += 1
         self.step_num = 0
-        o = self._vec.reset()
-        self.obs_image[...] = o['observation'][0].cpu().numpy()
-        self.desired_goal[...] = o['desired_goal'][0].cpu().numpy()
-        self.INIT_OBS[...] = o['init_observation'][0].cpu().numpy()
+        self._vec.reset()                                                          # returns after the stream sync
+        if not self._live:
+            self.obs_image[...] = self._h_obs
+            self.desired_goal[...] = self._h_goal
+            self.INIT_OBS[...] = self._h_init
         self._pull_goals()
         return self._obs_dict()
+
+    def _after_step_enqueue(self):
+        """hook: more work for the same stream sync (the one-hot façade exports its state here)"""
 
     def step(self, action):
         a = int(action)
         if not 0 <= a < len(self.ACTIONS):
             raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
         self._act[0] = a
-        o, reward, done, _ = self._vec.step(self._act)
+        rc = self._lib.cw_step(self._eng, self._act_p, 0, self._stream)            # 0 = CW_ACT_I32
+        self._after_step_enqueue()
+        if rc == 0:
+            rc = self._lib.cw_synchronize(self._eng, self._stream)
+        if rc != 0:
+            from . import _lib as L
+            L.check(rc, 'cw_step')
         self.step_num += 1
-        self.obs_image[...] = o['observation'][0].cpu().numpy()
+        if not self._live:
+            self.obs_image[...] = self._h_obs
         self._pull_goals()
         info = {'task_success': self.achieved_goal_vector, 'desired_goal': self.desired_goal_vector,
                 'achieved_goal': self.achieved_goal_vector}                        # ray.py:376-378
-        return self._obs_dict(), int(reward[0].item()), bool(done[0].item()), info
+        return self._obs_dict(), int(self._h_reward[0]), bool(self._h_done[0]), info
 
     def render(self, state=None, mode='Non', tile_size=4):
         if state is not None or mode == 'human':
@@ -182,6 +212,12 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
         self._oh = np.zeros((S, S, 12), dtype=int)
         self._oh_goal = np.zeros((S, S, 12), dtype=int)
         self._oh_init = np.zeros((S, S, 12), dtype=int)
+        self._oh_pin = torch.zeros((1, S, S, 12), dtype=torch.uint8).pin_memory()   # GPU-visible host memory
+        self._oh_pin_np = self._oh_pin.numpy()[0]
+        self._oh_pin_p = C.c_void_p(self._oh_pin.data_ptr())
+
+    def _after_step_enqueue(self):
+        self._lib.cw_export_onehot(self._eng, self._oh_pin_p, self._stream)         # onehot.py:369-371
 
     def _oh_dict(self):
         self.observation = {'observation': self._oh, 'desired_goal': self._oh_goal, 'achieved_goal': self._oh,
@@ -198,7 +234,7 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def step(self, action):
         _, r, d, info = super().step(action)
-        self._oh[...] = self._vec.one_hot()[0].cpu().numpy()                     # onehot.py:369-371
+        self._oh[...] = self._oh_pin_np
         return self._oh_dict(), r, d, info
 
 

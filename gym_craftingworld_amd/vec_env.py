@@ -48,6 +48,19 @@ def _menu_struct(task_list, selected_tasks, number_of_tasks, stacking, reward_st
     return m
 
 
+_NP_OF = {torch.uint8: np.uint8, torch.int16: np.int16, torch.int32: np.int32, torch.int64: np.int64}
+
+
+def _host_view(ptr, shape, dtype):
+    """CPU tensor over engine-owned pinned host memory (cw_config.host_outputs); None for a NULL pointer."""
+    if not ptr:
+        return None
+    npdt = np.dtype(_NP_OF[dtype])
+    nbytes = int(np.prod(shape)) * npdt.itemsize
+    arr = np.frombuffer((C.c_uint8 * nbytes).from_address(int(ptr)), dtype=npdt).reshape(shape)
+    return torch.from_numpy(arr)
+
+
 _LIVE = weakref.WeakSet()
 
 
@@ -70,7 +83,10 @@ class CraftingWorldVecEnv:
     each menu a dict with any of selected_tasks / number_of_tasks / stacking / reward_style),
     raster ('ray' = CraftingWorldEnvRay's 4x4 colour tiles, 'alt' = CraftingWorldEnvAltObs's 3x3 CPV tiles),
     keep_terminal_obs (pixel modes: info['terminal_observation'] holds the last frame of every episode
-    that ended this step, as gym.vector does, at the cost of one extra frame write per finished env).
+    that ended this step, as gym.vector does, at the cost of one extra frame write per finished env),
+    host_outputs (small batches driven from host code -- the single-env gym loop: frames, reward, done and masks
+    live in pinned host memory the kernels write directly; they come back as CPU tensors, step()/reset() return
+    after one stream sync and there is no copy; actions may be plain ints/arrays).
     """
 
     metadata = {'render.modes': ['Non']}
@@ -79,7 +95,7 @@ class CraftingWorldVecEnv:
                  render_save_rate=1, task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None,
                  stacking=True, reward_style=None, obs_mode='pixels', device=None, seed=None,
                  seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None,
-                 keep_terminal_obs=False, raster='ray'):
+                 keep_terminal_obs=False, raster='ray', host_outputs=False):
         if store_gif:
             raise NotImplementedError('the GIF episode recorder (ray.py:565-597) is host-side debug I/O, out of scope')
         w, h = size
@@ -130,6 +146,8 @@ class CraftingWorldVecEnv:
         cfg.keep_terminal_obs = 1 if (keep_terminal_obs and obs_mode != 'state') else 0
         cfg.raster = L.CW_RASTER_ALT if raster == 'alt' else L.CW_RASTER_RAY
         self.raster = raster
+        self.host_outputs = bool(host_outputs)
+        cfg.host_outputs = 1 if self.host_outputs else 0
         cfg.n_menus = len(menus)
         cfg.menus = self._menus
         cfg.env_menu = env_menu.ctypes.data_as(C.POINTER(C.c_uint8)) if env_menu is not None else None
@@ -146,7 +164,9 @@ class CraftingWorldVecEnv:
         self.frame_shape = (3 * self.size + 3, 3 * self.size, 3) if raster == 'alt' else (4 * self.size, 4 * self.size, 3)
         fs = (N,) + self.frame_shape
         assert tab.frame_bytes == fs[1] * fs[2] * fs[3]
-        v = lambda p, shape, dt: tensor_view(p, shape, dt, di)  # noqa: E731
+        dv = lambda p, shape, dt: tensor_view(p, shape, dt, di)  # noqa: E731
+        v = (lambda p, shape, dt: _host_view(p, shape, dt)) if self.host_outputs else dv  # noqa: E731
+        self._host_actions = _host_view(tab.host_actions, (N,), torch.int32).numpy() if self.host_outputs else None
         self._obs = v(tab.obs, fs, torch.uint8)
         self._desired_img = v(tab.desired_goal, fs, torch.uint8)
         self._init_img = v(tab.init_obs, fs, torch.uint8)
@@ -157,9 +177,9 @@ class CraftingWorldVecEnv:
         self.achieved_mask = v(tab.achieved, (N,), torch.int16)      # bit i = task_list[i] (bit pattern of a u16)
         self.desired_mask = v(tab.desired, (N,), torch.int16)
         self.episode_length = v(tab.episode_length, (N,), torch.int32)
-        self.hdr = v(tab.hdr, (N, 16), torch.uint8)                  # packed current state, layout in craftingworld.h
-        self.slot_pos = v(tab.slot_pos, (N, 8), torch.int16)
-        self.counters = v(tab.counters, (4,), torch.int64)
+        self.hdr = dv(tab.hdr, (N, 16), torch.uint8)                 # packed current state, layout in craftingworld.h
+        self.slot_pos = dv(tab.slot_pos, (N, 8), torch.int16)
+        self.counters = dv(tab.counters, (4,), torch.int64)
         self.agent_rc = self.hdr[:, 0:2]
         self.hold = self.hdr[:, 2]
 
@@ -239,11 +259,25 @@ class CraftingWorldVecEnv:
         return {'observation': self._obs, 'desired_goal': self._desired_img, 'achieved_goal': self._obs,
                 'init_observation': self._init_img}                  # achieved_goal IS observation, ray.py:194-196
 
+    def _sync(self):
+        L.check(self._lib.cw_synchronize(self._h, self._stream()), 'cw_synchronize')
+
     def reset(self):
         L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')
+        if self.host_outputs:
+            self._sync()
         return self._observation()
 
     def step_async(self, actions):
+        if self.host_outputs and not (torch.is_tensor(actions) and actions.is_cuda):
+            a = np.asarray(actions).reshape(-1)             # host actions go through the engine's mapped buffer
+            if a.size != self.num_envs:
+                raise ValueError('expected %d actions, got %d' % (self.num_envs, a.size))
+            self._host_actions[:] = a
+            L.check(self._lib.cw_step(self._h, C.c_void_p(self._host_actions.ctypes.data), L.CW_ACT_I32, self._stream()),
+                    'cw_step')
+            self._pending = True
+            return
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions), device=self.device)
         if actions.device != self.device:
@@ -262,6 +296,8 @@ class CraftingWorldVecEnv:
         if not self._pending:
             raise RuntimeError('step_wait without step_async')
         self._pending = False
+        if self.host_outputs:
+            self._sync()
         info = {'task_success': self.achieved_mask, 'desired_goal': self.desired_mask,
                 'achieved_goal': self.achieved_mask, 'episode_length': self.episode_length}
         if self.terminal_observation is not None:

@@ -82,6 +82,11 @@ typedef struct cw_config {
     int32_t keep_terminal_obs;  /* 1 (pixel modes + auto_reset): before a finished env is reset, its last frame is
                                  * painted into cw_buffer_table.terminal_obs (gym.vector's info["terminal_observation"]) */
     int32_t raster;             /* CW_RASTER_* (pixel modes) */
+    int32_t host_outputs;       /* 1: the step outputs and the frames (every cw_buffer_table pointer down to episode_length) live in
+                                 * pinned, GPU-mapped HOST memory and are valid on the host too; cw_buffer_table.host_actions is a
+                                 * mapped int32[N] to write actions into.  For the single-env gym loop (ray.py step()/reset() called
+                                 * from host code, docs/source/envs/gen_info.rst:62-82): a step is one launch + cw_synchronize, no
+                                 * copies.  Kernel stores then cross PCIe -- not for large batches. */
     int32_t n_menus;            /* 1..CW_MAX_MENUS */
     const cw_task_menu *menus;  /* host array [n_menus] */
     const uint8_t *env_menu;    /* host array [num_envs] of menu ids, or NULL (= all envs use menu 0) */
@@ -110,6 +115,7 @@ typedef struct cw_buffer_table {
     uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
     uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
     size_t frame_bytes;      /* P*P*3 (CW_RASTER_RAY) or (3S+3)*3S*3 (CW_RASTER_ALT) */
+    int32_t *host_actions;   /* [N]  cw_config.host_outputs only (else NULL): mapped host buffer usable as cw_step's actions (CW_ACT_I32) */
 } cw_buffer_table;
 
 /* Host-side dense snapshot for parity injection / checkpointing (cw_get_state, cw_set_state).
@@ -196,6 +202,9 @@ int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out);
+/* Blocks the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize): the one host
+ * synchronisation of the single-env loop, where step() returns Python scalars (ray.py:376-378). */
+int cw_synchronize(cw_engine *e, cw_stream_t stream);
 int cw_num_envs(const cw_engine *e);
 int cw_abi_version(void);
 const char *cw_last_error(void);   /* thread-local text of the last failing call */

@@ -730,8 +730,9 @@ def test_episode_recorder_writes_gifs(tmp_path):
     rec = EpisodeRecorder(env, env_index=2, out_dir=str(tmp_path), scale=2)
     rec.after_reset(env.reset())
     paths = []
+    gen = torch.Generator(device='cuda').manual_seed(11)
     for t in range(20):
-        obs, rew, done, info = env.step(torch.randint(0, 6, (8,), device='cuda'))
+        obs, rew, done, info = env.step(torch.randint(0, 6, (8,), device='cuda', generator=gen))
         p = rec.after_step(obs, done, info)
         if p:
             paths.append(p)
@@ -901,3 +902,47 @@ def test_single_launch_step_equals_separate_kernels(obs_mode, raster, N, monkeyp
     k1, p1 = one.get_rng_states(); k2, p2 = two.get_rng_states()
     assert np.array_equal(k1, k2) and np.array_equal(p1, p2)
     one.close(); two.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode', ['pixels_dirty', 'pixels', 'state'])
+def test_host_mapped_outputs_equal_device_outputs(obs_mode):
+    """cw_config.host_outputs (the single-env loop's engine): kernels write frames, reward, done and masks straight
+    into pinned host memory; step()/reset() return CPU tensors after one stream sync and take host actions.
+    Must equal an ordinary device-resident engine on the same seeds and actions, auto-reset included."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N = 48
+    kw = dict(size=(8, 8), max_steps=21, obs_mode=obs_mode, seed=5)
+    if obs_mode != 'state':
+        kw['keep_terminal_obs'] = True
+    dev = CraftingWorldVecEnv(N, **kw)
+    host = CraftingWorldVecEnv(N, host_outputs=True, **kw)
+    od, oh = dev.reset(), host.reset()
+    assert not host.reward.is_cuda and host.hdr.is_cuda
+    if obs_mode != 'state':
+        for k in od:
+            assert not oh[k].is_cuda and torch.equal(od[k].cpu(), oh[k]), k
+    assert torch.equal(dev.desired_mask.cpu(), host.desired_mask) and int(host.achieved_mask.abs().sum()) == 0
+    rng = np.random.RandomState(3)
+    ended = 0
+    for t in range(150):
+        a = rng.randint(0, 6, size=N)
+        od, rd, dd, idv = dev.step(torch.as_tensor(a, device='cuda'))
+        oh, rh, dh, ih = host.step(a if t % 2 else a.tolist())       # host actions: arrays or plain lists
+        assert torch.equal(rd.cpu(), rh) and torch.equal(dd.cpu(), dh), t
+        for k in ('achieved_goal', 'desired_goal', 'episode_length'):
+            assert torch.equal(idv[k].cpu(), ih[k]), (t, k)
+        if obs_mode != 'state':
+            for k in od:
+                assert torch.equal(od[k].cpu(), oh[k]), (t, k)
+            m = dh.nonzero().squeeze(1)
+            assert torch.equal(idv['terminal_observation'].cpu()[m], ih['terminal_observation'][m]), t
+        ended += int(dh.sum())
+    assert ended > N
+    assert torch.equal(dev.hdr, host.hdr) and torch.equal(dev.counters, host.counters)
+    # a device tensor of actions is still accepted
+    a = torch.randint(0, 6, (N,), device='cuda')
+    _, rd, _, _ = dev.step(a)
+    _, rh, _, _ = host.step(a)
+    assert torch.equal(rd.cpu(), rh)
+    dev.close(); host.close()
