@@ -1,0 +1,143 @@
+// Micro-benchmark (GPU box only): do the gfx950 cache-policy bits of global_store (sc0, sc1, nt) change the rate of the
+// render kernel's store pattern (lane = cell, 4 x 12-byte stores, one wave per 21x21 frame)?  Also a linear 12-B fill.
+//   hipcc -O3 --offload-arch=gfx950 -o store_policy store_policy.hip && ./store_policy
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int POL>
+__device__ __forceinline__ void st3(uint8_t *p, u32x3 d)
+{
+    if (POL == 0) asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(p), "v"(d) : "memory");
+    if (POL == 1) asm volatile("global_store_dwordx3 %0, %1, off sc0" :: "v"(p), "v"(d) : "memory");
+    if (POL == 2) asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+    if (POL == 3) asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+    if (POL == 4) asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(p), "v"(d) : "memory");
+    if (POL == 5) asm volatile("global_store_dwordx3 %0, %1, off sc0 nt" :: "v"(p), "v"(d) : "memory");
+    if (POL == 6) asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" :: "v"(p), "v"(d) : "memory");
+    if (POL == 7) asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(d) : "memory");
+}
+
+template <int POL>
+__global__ __launch_bounds__(256) void frame_cells(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int f = wave; f < n_frames; f += n_waves) {
+        uint8_t *base = dst + (size_t)f * frame_bytes;
+        const uint4 p = pos[f & 1023];
+        const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+        for (uint32_t cell = lane; cell < 441; cell += 64) {
+            const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+            uint32_t col = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+            const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+            uint8_t *q = base + (size_t)(4 * r) * 252 + 12 * c;
+#pragma unroll
+            for (int dy = 0; dy < 4; dy++) st3<POL>(q + dy * 252, d);
+        }
+    }
+}
+template <int POL>
+__global__ __launch_bounds__(256) void fill3(uint8_t *dst, size_t n12, uint32_t v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const u32x3 d = {v, v + 1, v + 2};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n12; i += stride) st3<POL>(dst + i * 12, d);
+}
+
+// non-persistent: one wave per frame, 4 frames per 256-thread block, one block per 4 frames; dynamic LDS caps occupancy
+__global__ __launch_bounds__(256) void frame_cells_np(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    extern __shared__ uint32_t lds_cap[];
+    const int lane = threadIdx.x & 63;
+    const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (f >= n_frames) return;
+    if (lds_cap[lane] == 0x12345678u) dst[0] = 1;     // keep the allocation alive
+    uint8_t *base = dst + (size_t)f * frame_bytes;
+    const uint4 p = pos[f & 1023];
+    const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+    for (uint32_t cell = lane; cell < 441; cell += 64) {
+        const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+        const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+        uint8_t *q = base + (size_t)(4 * r) * 252 + 12 * c;
+#pragma unroll
+        for (int dy = 0; dy < 4; dy++) st3<0>(q + dy * 252, d);
+    }
+}
+// torch-like fill: non-persistent, each 256-thread block writes one contiguous 16-KiB chunk, 16 B per lane per store
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fill4_np(u32x4 *dst, size_t n16, uint32_t v)
+{
+    const u32x4 d = {v, v + 1, v + 2, v + 3};
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t i = base + 256 * k;
+        if (i < n16) dst[i] = d;
+    }
+}
+
+template <typename F>
+static float bench(F launch)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) launch();
+    std::vector<float> ms;
+    for (int i = 0; i < 15; i++) {
+        CHECK(hipEventRecord(a)); launch(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float t; CHECK(hipEventElapsedTime(&t, a, b)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[7];
+}
+
+template <int POL>
+static void run(const char *name, uint8_t *buf, const uint4 *pos, int N, uint32_t FB)
+{
+    const size_t bytes = (size_t)N * FB;
+    const float t1 = bench([&] { hipLaunchKernelGGL(frame_cells<POL>, dim3(256), dim3(256), 0, 0, buf, N, FB, pos); });
+    const float t2 = bench([&] { hipLaunchKernelGGL(fill3<POL>, dim3(1024), dim3(256), 0, 0, buf, bytes / 12, 1u); });
+    printf("%-12s frame cells %.3f ms %5.0f GB/s | linear fill %.3f ms %5.0f GB/s\n", name, t1, bytes / t1 / 1e6, t2, bytes / t2 / 1e6);
+}
+
+int main()
+{
+    const int N = 65536; const uint32_t FB = 21168;
+    uint8_t *buf; uint4 *pos;
+    CHECK(hipMalloc(&buf, (size_t)N * FB));
+    CHECK(hipMalloc(&pos, 1024 * 16)); CHECK(hipMemset(pos, 7, 1024 * 16));
+    {
+        const size_t bytes = (size_t)N * FB;
+        for (int wpb : {1, 2, 4}) for (size_t lds : {(size_t)0, (size_t)20 * 1024, (size_t)40 * 1024, (size_t)80 * 1024, (size_t)160 * 1024 - 64}) {
+            const int thr = 64 * wpb;
+            CHECK(hipFuncSetAttribute((const void *)frame_cells_np, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const float t = bench([&] { hipLaunchKernelGGL(frame_cells_np, dim3((N + wpb - 1) / wpb), dim3(thr), lds, 0, buf, N, FB, pos); });
+            printf("non-persistent wave-per-frame, %d waves/block, %3zu KiB LDS/block: %.3f ms %5.0f GB/s\n", wpb, lds / 1024, t, bytes / t / 1e6);
+        }
+        const float t = bench([&] { hipLaunchKernelGGL(fill4_np, dim3((unsigned)((bytes / 16 + 1023) / 1024)), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
+        printf("non-persistent 16-KiB-per-block x4 fill: %.3f ms %5.0f GB/s\n", t, bytes / t / 1e6);
+    }
+    for (int rep = 0; rep < 1; rep++) {
+        run<0>("(none)", buf, pos, N, FB);
+        run<1>("sc0", buf, pos, N, FB);
+        run<2>("sc1", buf, pos, N, FB);
+        run<3>("sc0 sc1", buf, pos, N, FB);
+        run<4>("nt", buf, pos, N, FB);
+        run<5>("sc0 nt", buf, pos, N, FB);
+        run<6>("sc1 nt", buf, pos, N, FB);
+        run<7>("sc0 sc1 nt", buf, pos, N, FB);
+    }
+    return 0;
+}
