@@ -75,6 +75,30 @@ __global__ __launch_bounds__(256) void frame_cells_np(uint8_t *dst, int n_frames
         for (int dy = 0; dy < 4; dy++) st3<0>(q + dy * 252, d);
     }
 }
+// short-lived waves: one wave per (frame, 64-cell group) = 4 stores, then retire (7 waves per 21x21 frame)
+__global__ __launch_bounds__(256) void frame_cells_short(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    extern __shared__ uint32_t lds_cap[];
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t f = gid / 7u, it = gid - f * 7u;
+    if (f >= (uint32_t)n_frames) return;
+    if (lds_cap[lane] == 0x12345678u) dst[0] = 1;
+    uint8_t *base = dst + (size_t)f * frame_bytes;
+    const uint4 p = pos[f & 1023];
+    const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+    const uint32_t cell = it * 64 + lane;
+    if (cell < 441) {
+        const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+        const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+        uint8_t *q = base + (size_t)(4 * r) * 252 + 12 * c;
+#pragma unroll
+        for (int dy = 0; dy < 4; dy++) st3<0>(q + dy * 252, d);
+    }
+}
 // torch-like fill: non-persistent, each 256-thread block writes one contiguous 16-KiB chunk, 16 B per lane per store
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void fill4_np(u32x4 *dst, size_t n16, uint32_t v)
@@ -125,6 +149,12 @@ int main()
             CHECK(hipFuncSetAttribute((const void *)frame_cells_np, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const float t = bench([&] { hipLaunchKernelGGL(frame_cells_np, dim3((N + wpb - 1) / wpb), dim3(thr), lds, 0, buf, N, FB, pos); });
             printf("non-persistent wave-per-frame, %d waves/block, %3zu KiB LDS/block: %.3f ms %5.0f GB/s\n", wpb, lds / 1024, t, bytes / t / 1e6);
+        }
+        for (int wpb : {1, 4}) for (size_t lds : {(size_t)0, (size_t)20 * 1024, (size_t)40 * 1024}) {
+            CHECK(hipFuncSetAttribute((const void *)frame_cells_short, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const unsigned waves = (unsigned)N * 7u;
+            const float t = bench([&] { hipLaunchKernelGGL(frame_cells_short, dim3((waves + wpb - 1) / wpb), dim3(64 * wpb), lds, 0, buf, N, FB, pos); });
+            printf("short waves (frame, 64 cells), %d waves/block, %3zu KiB LDS/block: %.3f ms %5.0f GB/s\n", wpb, lds / 1024, t, bytes / t / 1e6);
         }
         const float t = bench([&] { hipLaunchKernelGGL(fill4_np, dim3((unsigned)((bytes / 16 + 1023) / 1024)), dim3(256), 0, 0, (u32x4 *)buf, bytes / 16, 1u); });
         printf("non-persistent 16-KiB-per-block x4 fill: %.3f ms %5.0f GB/s\n", t, bytes / t / 1e6);
