@@ -1,0 +1,83 @@
+// Micro-benchmark (GPU box only): the frame paint's store pattern (one wave per 21x21 frame, lane = cell, 4 x 12-B stores per
+// 64-cell group, 7 groups per frame) with the ORDER of the groups staggered between waves, so that concurrently running
+// waves are not all at the same relative offset of their frames.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+// rot_mode: 0 none | 1 wave % 7 | 2 (wave / 4) % 7 | 3 frame % 7 | 4 reversed groups | 5 (wave * 3) % 7 | 6 hash
+template <int RM>
+__global__ __launch_bounds__(256) void frame_cells(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int f = wave; f < n_frames; f += n_waves) {
+        uint8_t *base = dst + (size_t)f * frame_bytes;
+        const uint4 p = pos[f & 1023];
+        const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+        uint32_t rot = 0;
+        if (RM == 1) rot = wave % 7;
+        if (RM == 2) rot = (wave / 4) % 7;
+        if (RM == 3) rot = f % 7;
+        if (RM == 5) rot = (wave * 3) % 7;
+        if (RM == 6) rot = ((uint32_t)wave * 2654435761u >> 16) % 7;
+        for (uint32_t g0 = 0; g0 < 7; g0++) {
+            uint32_t g = g0 + rot; g = g >= 7 ? g - 7 : g;
+            if (RM == 4) g = 6 - g0;
+            const uint32_t cell = g * 64 + lane;
+            if (cell < 441) {
+                const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+                uint32_t col = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+                const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+                uint8_t *q = base + (size_t)(4 * r) * 252 + 12 * c;
+#pragma unroll
+                for (int dy = 0; dy < 4; dy++) *(u32x3_a4 *)(q + dy * 252) = d;
+            }
+        }
+    }
+}
+template <typename F>
+static float bench(F launch)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) launch();
+    std::vector<float> ms;
+    for (int i = 0; i < 15; i++) {
+        CHECK(hipEventRecord(a)); launch(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float t; CHECK(hipEventElapsedTime(&t, a, b)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[7];
+}
+template <int RM>
+static void run(const char *name, uint8_t *buf, const uint4 *pos, int N, uint32_t FB)
+{
+    const float t = bench([&] { hipLaunchKernelGGL(frame_cells<RM>, dim3(256), dim3(256), 0, 0, buf, N, FB, pos); });
+    printf("%-28s %.3f ms %5.0f GB/s\n", name, t, (size_t)N * FB / t / 1e6);
+}
+int main()
+{
+    const int N = 65536; const uint32_t FB = 21168;
+    uint8_t *buf; uint4 *pos;
+    CHECK(hipMalloc(&buf, (size_t)N * FB));
+    CHECK(hipMalloc(&pos, 1024 * 16)); CHECK(hipMemset(pos, 7, 1024 * 16));
+    for (int rep = 0; rep < 3; rep++) {
+        run<0>("in order", buf, pos, N, FB);
+        run<1>("start at wave % 7", buf, pos, N, FB);
+        run<2>("start at (wave/4) % 7", buf, pos, N, FB);
+        run<3>("start at frame % 7", buf, pos, N, FB);
+        run<4>("reversed", buf, pos, N, FB);
+        run<5>("start at (3 wave) % 7", buf, pos, N, FB);
+        run<6>("start at hash(wave) % 7", buf, pos, N, FB);
+    }
+    return 0;
+}
