@@ -6,8 +6,8 @@
 
 Workload = BASELINE.json configs[2] (the config the metric is quoted on): 65 536 envs per GPU,
 21x21 grid, full-frame 4x4-pixel-cell uint8 observation every step, auto-reset, uniform random
-actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel + reset
-kernel over the ballot-compacted done list + full-frame render kernel).  Envs shard across
+actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel, then the full-frame
+render kernel with the reset kernel over the ballot-compacted done list beside it on a forked stream).  Envs shard across
 ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
 are the timing barrier and the max-over-ranks of the elapsed time.
 

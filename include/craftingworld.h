@@ -157,8 +157,10 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
 /* --- step(action) for every env (ray.py:301-378) + auto-reset of finished envs --------------
  * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
  * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
- * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues: step kernel,
- * reset kernel over the ballot-compacted done list, render kernel. */
+ * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues, in CW_OBS_PIXELS_FULL: step kernel,
+ * then the render kernel with the reset kernel (ballot-compacted done list) beside it on an engine-owned stream that
+ * forks from and joins back into `stream`; in the other modes one kernel that steps and resets inline.
+ * With cw_config.host_outputs `actions` may be cw_buffer_table.host_actions. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
 
 /* --- n_steps consecutive step()s (+ auto-reset) for every env in ONE persistent kernel launch --
