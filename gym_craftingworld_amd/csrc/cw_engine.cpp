@@ -369,6 +369,7 @@ int cw_destroy(cw_engine *e)
 {
     if (!e) return CW_OK;
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     (void)hipDeviceSynchronize();
     prof_free(e);
     if (e->side) (void)hipStreamDestroy(e->side);
@@ -384,6 +385,7 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
 {
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_seed_mt: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(keys, keys + N * CW_MT_N);
     std::vector<int32_t> idx(N);
@@ -399,6 +401,7 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
 {
     if (!e || !seeds) return fail(CW_ERR_INVALID, "cw_seed_int: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
     std::vector<int32_t> idx(N);
@@ -414,6 +417,7 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
 {
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_get_mt: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
     HIP_TRY(hipDeviceSynchronize());
@@ -428,6 +432,7 @@ int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
     if (!e) return fail(CW_ERR_INVALID, "cw_generate_fixed_states: null engine");
     if (e->K == 0) return CW_OK;
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_pool(&e->P, (hipStream_t)stream));
     return CW_OK;
 }
@@ -436,6 +441,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
 {
     if (!e) return fail(CW_ERR_INVALID, "cw_reset: null engine");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     e->has_reset = true;
     return CW_OK;
@@ -447,6 +453,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step: bad action dtype %d", action_dtype);
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
                             e->ev_fork, e->ev_join, ev));
@@ -462,6 +469,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
         return fail(CW_ERR_INVALID, "cw_rollout needs obs_mode CW_OBS_STATE and auto_reset (frames are not painted by the persistent kernel)");
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_rollout called before cw_reset");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
@@ -471,6 +479,7 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
     if (!e || !out_frames) return fail(CW_ERR_INVALID, "cw_render: null argument");
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_render called before cw_reset");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
@@ -479,6 +488,7 @@ int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_grid: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_export(&e->P, out, 0, (hipStream_t)stream));
     return CW_OK;
 }
@@ -487,6 +497,7 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_export(&e->P, out, 1, (hipStream_t)stream));
     return CW_OK;
 }
@@ -495,6 +506,7 @@ int cw_profile_begin(cw_engine *e, int max_steps)
 {
     if (!e || max_steps < 1 || max_steps > 100000) return fail(CW_ERR_INVALID, "cw_profile_begin: bad argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     prof_free(e);
     e->prof_ev.resize((size_t)max_steps * 6);
     for (auto &ev : e->prof_ev) HIP_TRY(hipEventCreate(&ev));
@@ -506,6 +518,7 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_profile_end: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
@@ -558,6 +571,7 @@ int cw_synchronize(cw_engine *e, cw_stream_t stream)
 {
     if (!e) return fail(CW_ERR_INVALID, "cw_synchronize: null engine");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return CW_OK;
 }
@@ -574,6 +588,7 @@ int cw_get_state(cw_engine *e, cw_state_view *v)
 {
     if (!e || !v) return fail(CW_ERR_INVALID, "cw_get_state: null argument");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
     const int S = e->S, nc = e->ncell;
     std::vector<uint32_t> hdr(N * 4), goal_codes(N);
@@ -610,6 +625,7 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     if (!e || !v) return fail(CW_ERR_INVALID, "cw_set_state: null argument");
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_set_state called before cw_reset");
     DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
     const int S = e->S, nc = e->ncell;
     std::vector<uint32_t> hdr(N * 4);
