@@ -946,3 +946,76 @@ def test_host_mapped_outputs_equal_device_outputs(obs_mode):
     _, rh, _, _ = host.step(a)
     assert torch.equal(rd.cpu(), rh)
     dev.close(); host.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,variant', [('ray5_scripted', 'dict'), ('ray8_selected', 'int64'), ('ray5_subset', 'flat'),
+                                          ('ray8_scripted', 'onehot'), ('alt5_random', 'alt'), ('alt8_scripted', 'alt_stacked')])
+def test_single_env_facades_replay_fixtures(name, variant):
+    """The gym.Env-shaped N=1 classes (host-mapped outputs, no auto-reset, numpy in/out) on whole reference
+    trajectories: every reward, done, achieved mask, frame and reset of the fixture, through each façade's own
+    return convention (Dict / int64 copies / Flat's bare frame / OneHot states / AltObs Dict and stacked)."""
+    import gym_craftingworld_amd as cw
+    meta, kw, g = load(name)
+    cls = {'dict': cw.CraftingWorldEnv, 'int64': cw.CraftingWorldEnv, 'flat': cw.CraftingWorldEnvFlat,
+           'onehot': cw.CraftingWorldEnvOneHot, 'alt': cw.CraftingWorldEnvAltObs, 'alt_stacked': cw.CraftingWorldEnvAltObs}[variant]
+    extra = {}
+    if variant == 'int64':
+        extra['reference_dtypes'] = True
+    if variant == 'alt_stacked':
+        extra['stacked_obs'] = True
+    if variant == 'flat':
+        kw = {k: v for k, v in kw.items() if k != 'fixed_init_state'}
+    env = cls(**kw, **extra)
+    env.set_rng_state(g['key0'], int(g['pos0']))
+
+    def frames(o):      # -> (observation, desired_goal or None, init_observation or None) as uint8
+        if variant == 'flat':
+            return o, None, None
+        if variant == 'alt_stacked':
+            assert o.shape[0] == 4 and np.array_equal(o[0], o[2])
+            return o[0], o[1], o[3]
+        return o['observation'], o['desired_goal'], o['init_observation']
+
+    def grid_of(oh):
+        return (oh[:, :, :8] * np.arange(1, 9)).sum(axis=2).astype(np.uint8)
+
+    ri = 0
+
+    def check_reset(o, t):
+        nonlocal ri
+        assert g['r_at_step'][ri] == t
+        if variant == 'onehot':
+            assert crc(grid_of(o['observation'])) == crc(g['r_grid'][ri]) and np.array_equal(o['observation'], o['init_observation'])
+            assert tuple(np.argwhere(o['observation'][:, :, 8] == 1)[0]) == tuple(g['r_agent'][ri])
+        else:
+            ob, des, ini = frames(o)
+            assert crc(ob.astype(np.uint8)) == g['r_obs_crc'][ri], (name, 'reset obs', ri)
+            if des is not None:
+                assert crc(des.astype(np.uint8)) == g['r_desired_img_crc'][ri] and crc(ini.astype(np.uint8)) == g['r_init_img_crc'][ri]
+            if variant == 'int64':
+                assert ob.dtype == np.int64
+        bits = sum(int(b) << i for i, b in enumerate(env.desired_goal_vector[0]))
+        assert bits == g['r_desired'][ri] and env.ep_no == g['r_ep_no'][ri]
+        ri += 1
+
+    check_reset(env.reset(), 0)
+    T = min(len(g['action']), 1500)
+    for t in range(T):
+        o, r, d, info = env.step(int(g['action'][t]))
+        assert r == g['reward'][t] and d == bool(g['done'][t]), (name, t)
+        assert sum(int(b) << i for i, b in enumerate(info['achieved_goal'][0])) == g['achieved'][t], (name, 'achieved', t)
+        assert env.step_num == g['step_num'][t]
+        if d:
+            check_reset(env.reset(), t + 1)
+        elif variant == 'onehot':
+            assert crc(grid_of(o['observation'])) == g['grid_crc'][t], (name, 'grid', t)
+            ar, ac = g['agent'][t]
+            assert o['observation'][ar, ac, 8] == 1 and o['observation'][:, :, 8].sum() == 1
+            assert o['observation'][ar, ac, 9:].sum() == (1 if g['hold'][t] else 0)
+            if g['hold'][t]:
+                assert o['observation'][ar, ac, 8 + g['hold'][t]] == 1
+        else:
+            assert crc(frames(o)[0].astype(np.uint8)) == g['obs_crc'][t], (name, 'obs', t)
+    assert ri >= 2
+    env.close()
