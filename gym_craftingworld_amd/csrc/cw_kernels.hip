@@ -962,10 +962,6 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
     }
 }
 
-// mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
-// mode 2: every env -> ext_out only                                               (cw_render)
-// mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
-//         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
 // Per-env records are wave-uniform and must not be loaded inside the frame loop: loads and stores retire through
 // one in-order counter (vmcnt), so waiting for a vector load there drains the wave's 28 outstanding frame stores
 // once per frame (measured 0.320 ms vs 0.274 ms per launch).  First fix: scalar loads (constant cache, lgkmcnt
