@@ -20,6 +20,8 @@ hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mo
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
+hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
+                                   int *waves_per_block);
 hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st);
 }
 
@@ -200,6 +202,80 @@ static int upload_mt(cw_engine *e, const std::vector<uint32_t> &words, const std
     return CW_OK;
 }
 
+// XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
+// than their neighbours' (workgroups go round-robin over the 8 XCDs, so it shows as even vs odd workgroup index), and a
+// launch lasts as long as its slowest wave.  Measure it instead of assuming it: a few equal-share launches with the waves'
+// busy time summed per index parity, then the slow class paints q_all frames per wave and the fast class the rest.  Only
+// performance depends on the outcome; which frames are painted does not (cw_kernels.hip: render_jobs).
+static int calibrate_render_shares(cw_engine *e)
+{
+    CwTuning &tn = e->tune;
+    tn.render_q_all = 0;
+    tn.render_fast_parity = -1;
+    const char *off = getenv("CW_TUNE_RENDER_SHARES");
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || (off && atoi(off) == 0)) return CW_OK;
+    if (const char *q = getenv("CW_TUNE_RENDER_QALL")) {          // forced (experiments): "q_all,parity"
+        int qa = 0, par = -1;
+        if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
+        return CW_OK;
+    }
+    unsigned long long *stats = nullptr;
+    int rc = dev_alloc(e, &stats, 2);
+    if (rc != CW_OK) return rc;
+    int blocks = 0, wpb = 0;
+    e->P.render_stats = stats;
+    // busy[c] = summed busy time of the waves of workgroup-index parity c over 3 launches (after one warm-up launch)
+    auto measure = [&](int q_all, int parity, double busy[2]) -> int {
+        busy[0] = busy[1] = 0;
+        for (int rep = 0; rep < 4; rep++) {
+            unsigned long long h[2] = {0, 0};
+            if (hipMemset(stats, 0, sizeof(h)) != hipSuccess ||
+                cwk_launch_render_calib(&e->P, &tn, nullptr, q_all, parity, &blocks, &wpb) != hipSuccess ||
+                hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(CW_ERR_HIP, "cw_create: render calibration failed");
+            if (rep > 0) { busy[0] += (double)h[0]; busy[1] += (double)h[1]; }
+        }
+        return CW_OK;
+    };
+    double busy[2], busy0[2];
+    rc = measure(0, -1, busy0);                                  // equal shares
+    int q_all = 0, fast = -1;
+    long long n_half = 0;
+    if (rc == CW_OK && blocks >= 16 && !(blocks & 1) && busy0[0] > 0 && busy0[1] > 0) {
+        n_half = (long long)blocks * wpb / 2;
+        fast = busy0[1] < busy0[0] ? 1 : 0;
+        double rho = busy0[1 - fast] / busy0[fast];              // per-frame cost of the slow class relative to the fast one
+        if (rho >= 1.03) {
+            // the classes share the memory system, so shifting frames changes both costs: refine on what is measured
+            for (int it = 0; it < 3 && rc == CW_OK; it++) {
+                if (rho > 1.6) rho = 1.6;
+                q_all = (int)((double)e->n / ((double)n_half * (1.0 + rho)));
+                if (q_all < 1) { q_all = 0; break; }
+                rc = measure(q_all, fast, busy);
+                if (rc != CW_OK || busy[0] <= 0 || busy[1] <= 0) break;
+                const double q_fast = ((double)e->n - (double)q_all * (double)n_half) / (double)n_half;
+                const double per_frame_slow = busy[1 - fast] / (double)q_all, per_frame_fast = busy[fast] / q_fast;
+                rho = per_frame_slow / per_frame_fast;
+                if (rho < 1.0) rho = 1.0;
+            }
+            if (q_all >= 1) q_all = (int)((double)e->n / ((double)n_half * (1.0 + (rho > 1.6 ? 1.6 : rho))));
+        }
+    }
+    e->P.render_stats = nullptr;
+    if (rc != CW_OK) return rc;
+    if (q_all < 1) return CW_OK;                                 // small batch, or balanced already: equal shares
+    tn.render_q_all = q_all;
+    tn.render_fast_parity = fast;
+    const long long n_waves = 2 * n_half;
+    busy[0] = busy0[0];
+    busy[1] = busy0[1];
+    if (getenv("CW_TUNE_VERBOSE"))
+        fprintf(stderr, "[craftingworld] render shares: waves of even/odd workgroups busy %.1f / %.1f us on equal shares -> %d frames per slow wave, "
+                "%s workgroups take the rest\n", busy[0] / 3.0 / (double)(n_waves / 2) / 100.0, busy[1] / 3.0 / (double)(n_waves / 2) / 100.0,
+                q_all, fast ? "odd" : "even");
+    return CW_OK;
+}
+
 extern "C" {
 
 const char *cw_last_error(void) { return g_err; }
@@ -358,6 +434,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
+    if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc != CW_OK) {
         cw_destroy(e);
         *out = nullptr;

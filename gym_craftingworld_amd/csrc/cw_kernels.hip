@@ -23,6 +23,10 @@
 #include "cw_mt.h"
 
 #define CW_WAVE 64
+// per-class busy time of the render waves (100 MHz wall clock), summed into P.render_stats[class] when the engine is
+// calibrating (cw_create) -- a null pointer otherwise, and then this is two scalar clock reads per wave
+#define CW_WAVE_CLOCK(var) const unsigned long long var = wall_clock64()
+#define CW_WAVE_BUSY(P, t0, cls) do { if ((P).render_stats && lane == 0) atomicAdd((P).render_stats + (cls), wall_clock64() - (t0)); } while (0)
 #define CW_BALLOT(p) __builtin_amdgcn_ballot_w64(p)   // the compare's own SGPR pair (__ballot goes through a select + compare)
 
 // -DCW_TRACE (make trace -> libcraftingworld_trace.so, tools/microbench only): 100 MHz wall-clock stamps of the reset's phases
@@ -31,8 +35,12 @@ __device__ unsigned long long cw_trace_buf[1024 * 8];
 #define CW_STAMP(env, k) do { if (lane == 0) { cw_trace_buf[((env) & 1023) * 8 + (k)] = wall_clock64(); \
                                                if ((k) == 0 || (k) == 5) cw_trace_buf[((env) & 1023) * 8 + 6 + ((k) ? 1 : 0)] = clock64(); } } while (0)
 extern "C" hipError_t cwk_trace_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cw_trace_buf), sizeof(cw_trace_buf)); }
+__device__ unsigned long long cw_trace_render[1024 * 2];      // per render wave: start, end (100 MHz wall clock)
+extern "C" hipError_t cwk_trace_render_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cw_trace_render), sizeof(cw_trace_render)); }
+#define CW_WAVE_STAMP(wave, k) do { if (lane == 0) cw_trace_render[((wave) & 1023) * 2 + (k)] = wall_clock64(); } while (0)
 #else
 #define CW_STAMP(env, k) do { } while (0)
+#define CW_WAVE_STAMP(wave, k) do { } while (0)
 #endif
 
 enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6, HOUSE = 7, WHEAT = 8 };
@@ -1032,29 +1040,47 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // requested at once, BEFORE the wave has a store in flight, and the frame loop itself has no load at all (frame k's
 // wave-uniform record is 9 v_readlane).  With 1024 waves and 65 536 envs that is the whole launch; larger batches
 // reload every 64 frames (the only point where the wave waits for its stores).
+//
+// Which frames a wave paints.  Rounds 0..q_all-1: every wave paints one frame per round (frame i*n_waves + wave), so all
+// waves sweep through memory together.  XCD-aware part: the workgroups of every other XCD write ~15 % slower
+// (tools/microbench/render_waves.py: with equal shares the waves of even-numbered workgroups finish at ~255 us, the
+// odd ones at ~222 us, whatever frames they paint), and a launch lasts as long as its slowest wave.  So the frames
+// past round q_all go to the fast class only, one per fast wave per round; q_all and the fast parity come from a
+// calibration at cw_create (cw_engine.cpp).  fast_parity < 0: no classes, q_all covers everything.  The partition
+// depends on workgroup indices only, never on where a workgroup actually runs: coverage is exact either way.
 template <int MODE>
-__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out)
+__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE);
-    const int n_waves = (gridDim.x * blockDim.x) / CW_WAVE;
+    const int wpb = blockDim.x / CW_WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * wpb + wave_in_block;
+    const int n_waves = gridDim.x * wpb;
     const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform)
     const bool want_done = (MODE == 3) && skip_done;
-    const int stride = CW_WAVE * n_waves;            // frames between two batches of this wave (n_waves <= 4096)
-    for (int base = wave;; base += stride) {
-        const int left = n_jobs - base;              // > 0
-        const int myoff = lane * n_waves;
+    const bool classes = (MODE == 2 || MODE == 3) && fast_parity >= 0;
+    if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
+    const int n_fast = (gridDim.x / 2) * wpb;                              // (classes only: the grid is even)
+    const bool fast = classes && (int)(blockIdx.x & 1u) == fast_parity;
+    const int fast_rank = (int)(blockIdx.x >> 1) * wpb + wave_in_block;
+    const int tail0 = q_all * n_waves;                                     // first frame of the fast class's extra rounds
+    const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
+    CW_WAVE_CLOCK(t_start);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
+    for (int base = 0; base < q_mine; base += CW_WAVE) {
+        const int i = base + lane;                                         // this lane holds the wave's i-th frame
+        const int f = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
         int v_env = -1;
         uint4 v_h = make_uint4(0, 0, 0, 0), v_p = make_uint4(0, 0, 0, 0);
         uint32_t v_done = 0;
-        if (myoff < left) {
-            v_env = (MODE == 4) ? P.done_list[base + myoff] : base + myoff;
+        if (i < q_mine && f < n_jobs) {
+            v_env = (MODE == 4) ? P.done_list[f] : f;
             v_h = P.hdr[v_env];
             v_p = P.pos[v_env];
             if (want_done) v_done = P.done[v_env];
         }
-        const int in_batch = left >= stride ? CW_WAVE : (int)(((uint32_t)left + (uint32_t)n_waves - 1u) / (uint32_t)n_waves);
+        const int in_batch = min(q_mine - base, CW_WAVE);
         for (int k = 0; k < in_batch; k++) {
             CwEnvRec cur;
             cur.env = __builtin_amdgcn_readlane(v_env, k);
@@ -1067,24 +1093,25 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
             cur.pp.z = __builtin_amdgcn_readlane(v_p.z, k);
             cur.pp.w = __builtin_amdgcn_readlane(v_p.w, k);
             cur.done_word = __builtin_amdgcn_readlane(v_done, k) << (8 * (cur.env & 3));
-            render_one<MODE>(P, cur, want_done, ext_out, lane);
+            render_one<MODE>(P, cur, want_done, ext_out, lane);            // (env < 0: nothing to paint)
         }
-        if (left <= stride) break;
     }
+    CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
 // the per-step full-frame render (mode 3) and cw_render (mode 2): the roofline kernel
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out)
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
 {
-    if (mode == 3) render_jobs<3>(P, skip_done, ext_out);
-    else render_jobs<2>(P, skip_done, ext_out);
+    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity);
+    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity);
 }
 // off the per-step path: the three frames of every env after cw_reset (mode 0), or the last frames of the
 // done list's envs before their reset (mode 4, keep_terminal_obs)
 __global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
 {
-    if (mode == 0) render_jobs<0>(P, 0, nullptr);
-    else render_jobs<4>(P, 0, nullptr);
+    if (mode == 0) render_jobs<0>(P, 0, nullptr, 0, -1);
+    else render_jobs<4>(P, 0, nullptr, 0, -1);
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1195,7 +1222,8 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         if (ev && tn.profile_side) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr,
+                           tn.render_q_all, tn.render_fast_parity);
         if (ev) (void)hipEventRecord(ev[5], st);
         (void)hipStreamWaitEvent(st, ev_join, 0);
         return hipGetLastError();
@@ -1206,7 +1234,8 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, 1, 0, pixels ? 1 : 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete; finished envs are painted twice (rare path, tuning only)
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr,
+                           tn.render_q_all, tn.render_fast_parity);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -1237,10 +1266,22 @@ hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
     return hipGetLastError();
 }
 
+// one launch of the step's render kernel (all frames -> obs) with the given shares and P->render_stats set: cw_create's calibration
+hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
+                                   int *waves_per_block)
+{
+    const CwTuning &tn = *T;
+    *blocks = cw_render_grid(tn, P->n_envs);
+    *waves_per_block = tn.render_threads / CW_WAVE;
+    hipLaunchKernelGGL(cw_render_kernel, dim3(*blocks), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr, q_all, fast_parity);
+    return hipGetLastError();
+}
+
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
     const CwTuning &tn = *T;
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, P->n_envs)), dim3(tn.render_threads), 0, st, *P, 2, 0, out);
+    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, P->n_envs)), dim3(tn.render_threads), 0, st, *P, 2, 0, out,
+                       tn.render_q_all, tn.render_fast_parity);
     return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ struct CwTuning {
     int render_threads = 256;       // threads per render workgroup (64, 128, 256)
     int list_blocks = 256;          // workgroups of the done-list (terminal-frame) render
     int overlap = 1;                // full-pixel step: reset (+ its frames) on the side stream beside the main render
+    int render_q_all = 0;           // XCD-aware frame shares (cw_create calibrates): rounds painted by every wave ...
+    int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
 };
@@ -79,6 +81,7 @@ struct CwParams {
     // done-list compaction: done_count[0] = entries, [1] = release ticket (cw_kernels.hip)
     int32_t *done_list;      // [N]
     int32_t *done_count;     // [2]
+    unsigned long long *render_stats;   // [2] calibration only (else null): busy time of even / odd render workgroups' waves
     unsigned long long *counters; // [4]
     const CwMenuDev *menus;
     // constants
