@@ -1019,3 +1019,36 @@ def test_single_env_facades_replay_fixtures(name, variant):
             assert crc(frames(o)[0].astype(np.uint8)) == g['obs_crc'][t], (name, 'obs', t)
     assert ri >= 2
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,shares', [(5000, '1,0'), (5000, '3,1'), (5000, '4,0'), (65536, '10,1'), (65536, '63,0'), (65536, 'off'),
+                                      (70001, '40,1')])
+def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
+    """The full-frame render kernel splits the frames unevenly between even and odd workgroups (XCD-aware shares that
+    cw_create calibrates).  Whatever the split -- forced here to extreme values, either parity, or switched off --
+    every frame must be painted exactly as the dirty-cell engine paints it: the split may only change the speed."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    kw = dict(size=(21, 21), max_steps=9, seed=13)
+    if shares == 'off':
+        monkeypatch.setenv('CW_TUNE_RENDER_SHARES', '0')
+    else:
+        monkeypatch.setenv('CW_TUNE_RENDER_QALL', shares)
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    monkeypatch.delenv('CW_TUNE_RENDER_SHARES', raising=False)
+    monkeypatch.delenv('CW_TUNE_RENDER_QALL', raising=False)
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    of, od = full.reset(), dirty.reset()
+    full.obs_fill = of['observation'].fill_(7)            # poison: a frame the kernel skipped would keep this value
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    for t in range(12):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen)
+        of, rf, df, _ = full.step(a)
+        od, rd, dd, _ = dirty.step(a)
+        assert torch.equal(of['observation'], od['observation']), t
+        assert torch.equal(rf, rd) and torch.equal(df, dd)
+        if t == 5:
+            of['observation'].fill_(9)
+    out = torch.full_like(od['observation'], 5)
+    assert torch.equal(full.render(out), od['observation'])          # cw_render (mode 2) uses the same split
+    full.close(); dirty.close()
