@@ -92,6 +92,10 @@ def main():
     ap.add_argument('--rollout', action='store_true',
                     help='state-only mode: run the K steps as ONE persistent-kernel launch (cw_rollout; actions known up front)')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the short dirty-cell / state-only side measurements')
+    ap.add_argument('--desync', action='store_true',
+                    help='spread the episode phases out after the reset (step_num = 7 e mod max_steps): about N/max_steps envs '
+                         'finish on EVERY step, the steady state of a long run (default: all envs start together, so the window '
+                         'holds two steps on which every env times out at once, as SURVEY 8d defines the metric)')
     ap.add_argument('--graph-steps', type=int, default=0,
                     help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
     args = ap.parse_args()
@@ -128,6 +132,8 @@ def main():
     env = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=args.obs_mode,
                               device=dev, seed=lo, raster=args.raster)
     env.reset()
+    if args.desync:
+        env.set_state(step_num=((np.arange(lo, hi) * 7) % args.max_steps).astype(np.int32))
     # synthetic actions: uniform in [0,6), pre-generated on device, one row per step (not part of the env)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     rows = min(K + W, 1024)
@@ -264,7 +270,7 @@ def main():
                                                                         'state': 'state-only'}[args.obs_mode], args.max_steps),
                        'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
                        'sharding': 'contiguous env ranges per rank, no data-path collective',
-                       'launch': launch_desc},
+                       'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
