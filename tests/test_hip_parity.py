@@ -1052,3 +1052,40 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
     out = torch.full_like(od['observation'], 5)
     assert torch.equal(full.render(out), od['observation'])          # cw_render (mode 2) uses the same split
     full.close(); dirty.close()
+
+
+@pytest.mark.gpu
+def test_long_reset_chains_on_one_stream_vs_oracle():
+    """3 000 consecutive episodes on each of 256 MT19937 streams (max_steps=1: every step ends an episode), so that
+    the lazily regenerated state is entered at every alignment and wraps hundreds of times per stream; state, goal
+    state and the exact stream (key and position) must still equal the oracle's at the end and on the way."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, chunk = 256, 3000, 750
+    kw = dict(size=(9, 9), max_steps=1)
+    env = CraftingWorldVecEnv(N, obs_mode='state', seed=2024, **kw)
+    keys, pos = env.get_rng_states()
+    ora = OracleBatch(N, rng_states=[(keys[i], int(pos[i])) for i in range(N)], **kw)
+    env.reset()
+    ora.reset()
+    rng = np.random.RandomState(8)
+    for c in range(T // chunk):
+        acts = rng.randint(0, 6, size=(chunk, N)).astype(np.int8)
+        if c % 2:                                                # alternate the two code paths that reset inline
+            env.rollout(torch.as_tensor(acts.astype(np.uint8), device=env.device), record=False)
+        else:
+            for t in range(chunk):
+                env.step(torch.as_tensor(acts[t].astype(np.uint8), device=env.device))
+        assert ora.rollout(acts, nthreads=8) == chunk * N
+        st = env.get_state()
+        k2, p2 = env.get_rng_states()
+        for i, s in enumerate(ora.states()):
+            assert np.array_equal(st['grid'][i], s['grid']) and np.array_equal(st['goal_grid'][i], s['goal_grid']), (c, i)
+            assert st['desired'][i] == s['desired'] and st['ep_no'][i] == s['ep_no'], (c, i)
+        for i in range(0, N, 5):
+            ok, op = ora.envs[i].get_rng()
+            assert p2[i] % 624 == op % 624, (c, i)
+            if op % 624:
+                assert np.array_equal(k2[i][1:], ok[1:]), (c, i)
+    assert int(env.counters[1].item()) == N * T
+    env.close()
