@@ -213,7 +213,7 @@ static int calibrate_render_shares(cw_engine *e)
     tn.render_q_all = 0;
     tn.render_fast_parity = -1;
     const char *off = getenv("CW_TUNE_RENDER_SHARES");
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || (off && atoi(off) == 0)) return CW_OK;
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (off && atoi(off) == 0)) return CW_OK;   // (host-mapped frames: PCIe-bound anyway)
     if (const char *q = getenv("CW_TUNE_RENDER_QALL")) {          // forced (experiments): "q_all,parity"
         int qa = 0, par = -1;
         if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
