@@ -33,11 +33,35 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    16-CPU share to a container that still sees all 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                                   # cgroup v2: "<quota|max> <period>"
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:                                                                        # cgroup v1
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                quota = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(size, max_steps, seconds=12.0):
-    """Time the CPU oracle (port of the reference's step()/reset(), render_edit repaint included)
-    on all host cores: n envs x T steps with auto-reset, sized to ~`seconds` of wall time."""
+    """Time the CPU oracle (port of the reference's step()/reset()) on this host's CPU share: n envs x T steps with
+    auto-reset, sized to ~`seconds` of wall time.  Two rates: `value` with the reference's own observation strategy
+    (render_edit: the persistent frame, <= 2 cells repainted per step) and `full_frame_value` with the whole frame
+    rendered after every step -- the work the GPU headline configuration does."""
     from oracle import OracleBatch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = host_cpu_share()
     n = 64 * cores
     keys_pos = []
     for i in range(n):
@@ -48,29 +72,36 @@ def cpu_baseline(size, max_steps, seconds=12.0):
     rng = np.random.RandomState(1)
     T0 = 2 * max_steps
     acts = rng.randint(0, 6, size=(T0, n)).astype(np.int8)
-    t0 = time.perf_counter()
-    steps = batch.rollout(acts, nthreads=cores)           # calibration, also warms caches
-    dt = time.perf_counter() - t0
-    reps = max(1, int(seconds / max(dt, 1e-3)))
-    total, t0 = 0, time.perf_counter()
-    for _ in range(reps):
-        total += batch.rollout(acts, nthreads=cores)
-    dt = time.perf_counter() - t0
+
+    def timed(fn, budget):
+        t0 = time.perf_counter()
+        fn(acts, nthreads=cores)                                 # calibration, also warms caches
+        dt = time.perf_counter() - t0
+        reps = max(1, int(budget / max(dt, 1e-3)))
+        total, t0 = 0, time.perf_counter()
+        for _ in range(reps):
+            total += fn(acts, nthreads=cores)
+        dt = time.perf_counter() - t0
+        return total / dt, reps, dt
+
+    rate, reps, dt = timed(batch.rollout, 0.6 * seconds)
+    rate_full, reps_full, dt_full = timed(batch.rollout_full_frame, 0.4 * seconds)
     calib = None
     try:   # port vs the reference's own Python, both timed in the build container (tools/calibrate_cpu.py)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'cpu_calibration.json')) as f:
             c = json.load(f)
         calib = dict(port_over_reference_1core=c['port_over_reference'],
                      reference_python_env_steps_per_s_core=c['reference_python_env_steps_per_s'],
-                     reference_equivalent_of_value=total / dt / c['port_over_reference'],
+                     reference_equivalent_of_value=rate / c['port_over_reference'],
                      note='ratio measured in the build container on one core, not on this host')
     except (OSError, KeyError, ValueError):
         pass
-    return dict(value=total / dt, unit='env-steps/s', cores=cores, kind='port', calibration=calib,
+    return dict(value=rate, unit='env-steps/s', cores=cores, kind='port', full_frame_value=rate_full, calibration=calib,
                 reference_note='the reference itself (pure Python) cannot travel to the GPU box; BASELINE.md §2 has it at '
                                '64-78 k env-steps/s on one 2.1 GHz Xeon core (measured in the build container)',
-                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset, dirty-cell repaint like the reference), '
-                       '%.1f s on %d OpenMP threads' % (n, T0 * reps, size, size, max_steps, dt, cores))
+                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset), %.1f s on %d OpenMP threads (= the cgroup CPU share) '
+                       'with the reference\'s dirty-cell repaint -> value; x %d steps, %.1f s with a full render() per step -> '
+                       'full_frame_value' % (n, T0 * reps, size, size, max_steps, dt, cores, T0 * reps_full, dt_full))
 
 
 def main():

@@ -543,3 +543,27 @@ int64_t cwo_batch_rollout(cwo_env **envs, int32_t n, const int8_t *actions, int3
     (void)nthreads;
     return total;
 }
+
+/* Same loop, but every step is followed by render() of the whole frame (ray.py:442-520) instead of relying on the
+ * persistent image that render_edit keeps up to date: what "full-frame pixel obs every step" costs on host cores
+ * (bench.py's cpu_baseline, beside the reference's own dirty-cell strategy timed by cwo_batch_rollout). */
+int64_t cwo_batch_rollout_full(cwo_env **envs, int32_t n, const int8_t *actions, int32_t T, int32_t nthreads)
+{
+    int64_t total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) reduction(+ : total) schedule(static)
+#endif
+    for (int i = 0; i < n; i++) {
+        cwo_env *e = envs[i];
+        for (int t = 0; t < T; t++) {
+            int32_t r, d;
+            if (cwo_step(e, actions[(size_t)t * n + i], &r, &d) != 0) continue;
+            if (d) cwo_reset(e);
+            if (e->cfg.alt_obs) cwo_render_alt(e->cfg.size, e->grid, e->agent_r, e->agent_c, e->hold, e->obs);
+            else cwo_render(e->cfg.size, e->grid, e->agent_r, e->agent_c, e->hold, e->obs);
+            total++;
+        }
+    }
+    (void)nthreads;
+    return total;
+}

@@ -94,6 +94,7 @@ void cwo_render(int32_t size, const uint8_t *grid, int32_t agent_r, int32_t agen
  * Returns the number of env-steps executed. */
 int64_t cwo_batch_rollout(cwo_env **envs, int32_t n, const int8_t *actions, int32_t T,
                           int32_t nthreads, int32_t *rewards, uint8_t *dones);
+int64_t cwo_batch_rollout_full(cwo_env **envs, int32_t n, const int8_t *actions, int32_t T, int32_t nthreads);
 
 #ifdef __cplusplus
 }

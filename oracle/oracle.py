@@ -74,6 +74,8 @@ def _lib():
         lib.cwo_set_state.argtypes = [vp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                       C.c_uint32, C.c_int32]
         lib.cwo_render.argtypes = [C.c_int32, u8p, C.c_int32, C.c_int32, C.c_int32, u8p]
+        lib.cwo_batch_rollout_full.restype = C.c_int64
+        lib.cwo_batch_rollout_full.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_int8), C.c_int32, C.c_int32]
         lib.cwo_batch_rollout.restype = C.c_int64
         lib.cwo_batch_rollout.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_int8), C.c_int32,
                                           C.c_int32, i32p, u8p]
@@ -256,6 +258,13 @@ class OracleBatch:
             rew.ctypes.data_as(C.POINTER(C.c_int32)) if record else None,
             don.ctypes.data_as(C.POINTER(C.c_uint8)) if record else None)
         return (total, rew, don) if record else total
+
+    def rollout_full_frame(self, actions, nthreads=1):
+        """Like rollout(record=False), but with a full render() of every env's frame after every step."""
+        a = np.ascontiguousarray(actions, dtype=np.int8)
+        T, n = a.shape
+        assert n == self.num_envs
+        return _lib().cwo_batch_rollout_full(self._handles, n, a.ctypes.data_as(C.POINTER(C.c_int8)), T, nthreads)
 
     def states(self):
         return [e.state() for e in self.envs]
