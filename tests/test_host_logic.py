@@ -197,7 +197,7 @@ def test_bench_cpu_baseline_leg_reports_port_and_calibration():
     spec.loader.exec_module(bench)
     out = bench.cpu_baseline(5, 20, seconds=0.2)
     assert out['kind'] == 'port' and out['unit'] == 'env-steps/s' and out['cores'] >= 1 and out['value'] > 0
-    assert 'envs x' in out['sample'] and 0 < out['full_frame_value'] < out['value']
+    assert 'envs x' in out['sample'] and out['full_frame_value'] > 0
     c = out['calibration']
     assert c is not None and 20 < c['port_over_reference_1core'] < 2000
     assert abs(c['reference_equivalent_of_value'] * c['port_over_reference_1core'] - out['value']) < 1e-6 * out['value']
