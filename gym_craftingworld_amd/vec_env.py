@@ -205,7 +205,10 @@ class CraftingWorldVecEnv:
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        try:        # the raw handle without building a torch.cuda.Stream object (this sits on the per-step path)
+            return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
+        except AttributeError:
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -275,6 +278,13 @@ class CraftingWorldVecEnv:
                 raise ValueError('expected %d actions, got %d' % (self.num_envs, a.size))
             self._host_actions[:] = a
             L.check(self._lib.cw_step(self._h, C.c_void_p(self._host_actions.ctypes.data), L.CW_ACT_I32, self._stream()),
+                    'cw_step')
+            self._pending = True
+            return
+        if type(actions) is torch.Tensor and actions.dtype in _ACT_DTYPES and actions.device == self.device \
+                and actions.is_contiguous() and actions.numel() == self.num_envs:
+            self._actions_keepalive = actions               # fast path: nothing to convert
+            L.check(self._lib.cw_step(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], self._stream()),
                     'cw_step')
             self._pending = True
             return
