@@ -1089,3 +1089,57 @@ def test_long_reset_chains_on_one_stream_vs_oracle():
                 assert np.array_equal(k2[i][1:], ok[1:]), (c, i)
     assert int(env.counters[1].item()) == N * T
     env.close()
+
+
+@pytest.mark.gpu
+def test_random_configurations_vs_oracle():
+    """A seeded sweep over the configuration space itself -- grid size, episode length, ordered task subsets with
+    number_of_tasks / stacking / reward style, fixed-init pools, observation mode, raster -- each drawn at random and run
+    against the oracle with auto-reset: reward, done, masks every step; state, frames and RNG stream at the end."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    cfg_rng = np.random.RandomState(20260101)
+    for c in range(40):
+        S = int(cfg_rng.choice([4, 5, 6, 7, 9, 11, 13, 16, 21, 24, 33]))
+        sel = [TASKS[i] for i in cfg_rng.permutation(9)[:cfg_rng.randint(1, 10)]]
+        kw = dict(size=(S, S), max_steps=int(cfg_rng.randint(1, 40)), selected_tasks=sel,
+                  number_of_tasks=int(cfg_rng.randint(1, len(sel) + 1)) if cfg_rng.rand() < 0.7 else None,
+                  stacking=bool(cfg_rng.rand() < 0.7), reward_style=None if cfg_rng.rand() < 0.6 else 'subset',
+                  fixed_init_state=int(cfg_rng.choice([0, 0, 0, 1, 5])))
+        obs_mode = str(cfg_rng.choice(['pixels', 'pixels_dirty', 'state']))
+        raster = 'alt' if (obs_mode != 'state' and cfg_rng.rand() < 0.3) else 'ray'
+        N, T = int(cfg_rng.choice([1, 3, 17, 64, 130])), int(cfg_rng.randint(20, 90))
+        tag = (c, S, kw, obs_mode, raster, N, T)
+        keys, pos = _np_states(N, 5000 + 37 * c)
+        env = CraftingWorldVecEnv(N, obs_mode=obs_mode, raster=raster, **kw)
+        env.set_rng_states(keys, pos)
+        if kw['fixed_init_state']:
+            from gym_craftingworld_amd import _lib as L
+            L.check(env._lib.cw_generate_fixed_states(env._h, env._stream()), 'pool')
+        ora = OracleBatch(N, rng_states=list(zip(keys, pos)), alt_obs=(raster == 'alt'), **kw)
+        env.reset(); ora.reset()
+        acts = np.random.RandomState(c).randint(0, 6, size=(T, N)).astype(np.int64)
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.as_tensor(acts[t], device=env.device))
+            o_rew, o_done, o_ach = np.empty(N, np.int32), np.zeros(N, bool), np.empty(N, np.int64)
+            for i, e in enumerate(ora.envs):
+                _, o_rew[i], o_done[i], _ = e.step(int(acts[t, i]))
+                o_ach[i] = e.view().achieved
+                if o_done[i]:
+                    e.reset()
+            assert np.array_equal(rew.cpu().numpy(), o_rew) and np.array_equal(done.cpu().numpy(), o_done), (tag, t)
+            assert np.array_equal(info['achieved_goal'].cpu().numpy().astype(np.int64) & 0xFFFF, o_ach), (tag, t)
+        st = env.get_state()
+        frames = env.render().cpu().numpy()
+        k2, p2 = env.get_rng_states()
+        for i, s in enumerate(ora.states()):
+            assert np.array_equal(st['grid'][i], s['grid']) and np.array_equal(st['goal_grid'][i], s['goal_grid']), (tag, i)
+            assert tuple(st['agent_rc'][i]) == s['agent'] and st['hold'][i] == s['hold'] and st['desired'][i] == s['desired'], (tag, i)
+            assert st['ep_no'][i] == s['ep_no'] and st['step_num'][i] == s['step_num'], (tag, i)
+            assert np.array_equal(frames[i], s['obs']), (tag, i)
+            if obs_mode != 'state':
+                assert np.array_equal(obs['observation'][i].cpu().numpy(), s['obs']), (tag, i)
+                assert np.array_equal(obs['desired_goal'][i].cpu().numpy(), s['desired_img']), (tag, i)
+            ok, op = ora.envs[i].get_rng()
+            assert p2[i] % 624 == op % 624, (tag, i)
+        env.close()
