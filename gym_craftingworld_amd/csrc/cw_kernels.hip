@@ -2,13 +2,17 @@
 //
 //   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward,
 //                     done, wave-ballot compaction of the done list; in DIRTY pixel mode also
-//                     render_edit() (ray.py:522-557) of the <=2 changed cells.
+//                     render_edit() (ray.py:522-557) of the <=2 changed cells.  (Full-frame mode and
+//                     engines without auto-reset.)
+//   cw_step_fused_kernel  state-only / dirty-cell modes: the whole auto-reset step in ONE launch -- a wave
+//                     steps its 8..64 envs and resets the finished ones inline.
 //   cw_reset_kernel   one WAVEFRONT per finished env: reset() of ray.py:156-218 = task draw, legacy
 //                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS,
 //                     lane-parallel rejection sampling), imagine_obs(); in the pixel modes the same
 //                     wave then paints the env's three frames (obs, init_obs, desired_goal).
 //   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520; a lane paints one cell's
-//                     4 pixel rows with 4 x 12-byte stores; records arrive by scalar loads.
+//                     4 pixel rows with 4 x 12-byte stores; the records of a wave's 64 frames are fetched
+//                     one per lane up front; frame shares per workgroup parity are XCD-aware.
 //   cw_render_reset_kernel  the three frames of every env after cw_reset; terminal frames of the done list.
 //   cw_rollout_kernel persistent: T steps of every env in one launch (state-only mode).
 //   cw_export_*       dense grid / one-hot views of the slot state.
