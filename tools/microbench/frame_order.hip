@@ -44,6 +44,33 @@ __global__ __launch_bounds__(256) void frame_cells(uint8_t *dst, int n_frames, u
         }
     }
 }
+// row-aligned variant: 63 lanes = 3 whole grid rows per group (7 groups), so every store instruction writes 3 complete
+// 252-byte pixel-row segments and no segment is split between two groups
+__global__ __launch_bounds__(256) void frame_rows(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int f = wave; f < n_frames; f += n_waves) {
+        uint8_t *base = dst + (size_t)f * frame_bytes;
+        const uint4 p = pos[f & 1023];
+        const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+        for (uint32_t g = 0; g < 7; g++) {
+            const uint32_t cell = g * 63 + lane;
+            if (lane < 63) {
+                const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+                uint32_t col = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+                const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+                uint8_t *q = base + (size_t)(4 * r) * 252 + 12 * c;
+#pragma unroll
+                for (int dy = 0; dy < 4; dy++) *(u32x3_a4 *)(q + dy * 252) = d;
+            }
+        }
+    }
+}
+
 template <typename F>
 static float bench(F launch)
 {
@@ -72,6 +99,8 @@ int main()
     CHECK(hipMalloc(&pos, 1024 * 16)); CHECK(hipMemset(pos, 7, 1024 * 16));
     for (int rep = 0; rep < 3; rep++) {
         run<0>("in order", buf, pos, N, FB);
+        { const float t = bench([&] { hipLaunchKernelGGL(frame_rows, dim3(256), dim3(256), 0, 0, buf, N, FB, pos); });
+          printf("%-28s %.3f ms %5.0f GB/s\n", "63 lanes = 3 whole rows", t, (size_t)N * FB / t / 1e6); }
         run<1>("start at wave % 7", buf, pos, N, FB);
         run<2>("start at (wave/4) % 7", buf, pos, N, FB);
         run<3>("start at frame % 7", buf, pos, N, FB);
