@@ -71,6 +71,49 @@ __global__ __launch_bounds__(256) void frame_rows(uint8_t *dst, int n_frames, ui
     }
 }
 
+// torch-fill shape: NOT persistent; a 256-thread block = one 63-cell group (3 grid rows) of one frame, wave dy of the block
+// writes pixel row dy of those cells: ONE 12-byte store per lane, the block's 4 waves cover 3024 contiguous bytes.
+// Records by scalar loads; colours from a 9-entry table held in lanes of a VGPR (v_readlane by code).
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void frame_torchlike(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t dy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t f = blockIdx.x / 7u, g = blockIdx.x - f * 7u;
+    const u32x4s p = *(const __attribute__((address_space(4))) u32x4s *)(pos + (f & 1023u));
+    const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+    if (lane < 63) {
+        const uint32_t cell = g * 63 + lane;
+        const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+        const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+        uint8_t *q = dst + (size_t)f * frame_bytes + (size_t)(4 * r + dy) * 252 + 12 * c;
+        *(u32x3_a4 *)q = d;
+    }
+}
+// the same with 2 or 4 frames' worth of work per block kept torch-like: block = (frame, group), wave = pixel row, 64-thread blocks
+__global__ __launch_bounds__(64) void frame_torchlike64(uint8_t *dst, int n_frames, uint32_t frame_bytes, const uint4 *pos)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x;                       // one wave per (frame, group, dy)
+    const uint32_t fg = w >> 2, dy = w & 3u;
+    const uint32_t f = fg / 7u, g = fg - f * 7u;
+    const u32x4s p = *(const __attribute__((address_space(4))) u32x4s *)(pos + (f & 1023u));
+    const uint32_t sp[8] = {p.x & 0xffff, p.x >> 16, p.y & 0xffff, p.y >> 16, p.z & 0xffff, p.z >> 16, p.w & 0xffff, p.w >> 16};
+    if (lane < 63) {
+        const uint32_t cell = g * 63 + lane;
+        const uint32_t r = __umulhi(cell, 204522253u), c = cell - r * 21;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? (0x112233u * (k + 1)) : col;
+        const u32x3 d = {col | (col << 24), (col >> 8) | (col << 16), (col >> 16) | (col << 8)};
+        uint8_t *q = dst + (size_t)f * frame_bytes + (size_t)(4 * r + dy) * 252 + 12 * c;
+        *(u32x3_a4 *)q = d;
+    }
+}
+
 template <typename F>
 static float bench(F launch)
 {
@@ -98,6 +141,10 @@ int main()
     CHECK(hipMalloc(&buf, (size_t)N * FB));
     CHECK(hipMalloc(&pos, 1024 * 16)); CHECK(hipMemset(pos, 7, 1024 * 16));
     for (int rep = 0; rep < 3; rep++) {
+        { const float t = bench([&] { hipLaunchKernelGGL(frame_torchlike, dim3(N * 7), dim3(256), 0, 0, buf, N, FB, pos); });
+          printf("%-28s %.3f ms %5.0f GB/s\n", "torch-like, 256-thr blocks", t, (size_t)N * FB / t / 1e6); }
+        { const float t = bench([&] { hipLaunchKernelGGL(frame_torchlike64, dim3(N * 28), dim3(64), 0, 0, buf, N, FB, pos); });
+          printf("%-28s %.3f ms %5.0f GB/s\n", "torch-like, 64-thr blocks", t, (size_t)N * FB / t / 1e6); }
         run<0>("in order", buf, pos, N, FB);
         { const float t = bench([&] { hipLaunchKernelGGL(frame_rows, dim3(256), dim3(256), 0, 0, buf, N, FB, pos); });
           printf("%-28s %.3f ms %5.0f GB/s\n", "63 lanes = 3 whole rows", t, (size_t)N * FB / t / 1e6); }
