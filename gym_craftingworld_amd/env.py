@@ -37,7 +37,7 @@ class CraftingWorldEnv:
         size = self._default_size if size is None else size
         max_steps = self._default_max_steps if max_steps is None else max_steps
         self._vec = CraftingWorldVecEnv(1, size=size, fixed_init_state=fixed_init_state, max_steps=max_steps,
-                                        store_gif=store_gif, render_save_rate=render_save_rate, task_list=task_list,
+                                        store_gif=False, render_save_rate=render_save_rate, task_list=task_list,
                                         selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
                                         stacking=stacking, reward_style=reward_style, obs_mode='pixels_dirty',
                                         device=device, seed=seed, seed_style='gym', auto_reset=False,
@@ -75,6 +75,42 @@ class CraftingWorldEnv:
         self._lib, self._eng, self._stream = v._lib, v._h, v._stream()
         self._act = v._host_actions
         self._act_p = C.c_void_p(self._act.ctypes.data)
+        self.store_gif, self.render_save_rate = False, render_save_rate            # ray.py:135-136
+        self._gif_frames = None
+        if store_gif:                                                              # ray.py:142-143
+            self.allow_gif_storage()
+
+    # -- episode GIFs (ray.py:160-167, 205-216, 370-374, 769-782): host-side debug I/O off the step path.  Same files in
+    # the same places (renders/env<id>/E<ep>(<steps>)_<desired>(<achieved>).gif, every render_save_rate-th episode) and
+    # the same draw from the env's RNG stream for <id>; frames are observation | desired_goal side by side (pillow), not
+    # the reference's matplotlib figure with legend and captions.
+    def allow_gif_storage(self, store_gif=True):
+        self.store_gif = store_gif
+        if self.store_gif is True:
+            import os
+            rs = np.random.RandomState()
+            k, p = self.get_rng_state()
+            rs.set_state(('MT19937', k, p, 0, 0.0))
+            self.env_id = int(rs.randint(0, 1000000))                              # np_random.randint(0, 1000000), :778
+            st = rs.get_state()
+            self.set_rng_state(st[1], st[2])
+            os.makedirs('renders/env{}'.format(self.env_id), exist_ok=False)
+            self._gif_frames = []
+
+    def _gif_frame(self):
+        a, b = np.asarray(self.obs_image, np.uint8), np.asarray(self.desired_goal, np.uint8)
+        if a.shape != b.shape:
+            return a.copy()
+        return np.concatenate([a, np.zeros((a.shape[0], 4, 3), np.uint8), b], axis=1)
+
+    def _gif_save(self):
+        from PIL import Image
+        tasknums = '-'.join(str(i) for i in np.where(self.desired_goal_vector[0] == 1)[0])
+        completed = '-'.join(str(i) for i in np.where(self.achieved_goal_vector[0] == 1)[0])
+        path = 'renders/env{}/E{}({})_{}({}).gif'.format(self.env_id, self.ep_no, self.step_num, tasknums, completed)
+        imgs = [Image.fromarray(np.kron(f, np.ones((4, 4, 1), np.uint8))) for f in self._gif_frames]
+        imgs[0].save(path, save_all=True, append_images=imgs[1:], duration=100, loop=0)
+        return path
 
     # -- reference attributes derived from the device state on demand --------------------
     @property
@@ -118,6 +154,8 @@ class CraftingWorldEnv:
         return self.observation
 
     def reset(self, render_next=False):
+        if self.store_gif is True and self.step_num != 0 and self.ep_no % self.render_save_rate == 0 and self._gif_frames:
+            self._gif_save()                                                      # ray.py:160-167
         if self.step_num != 0:                                                    # ray.py:200-201
             self.ep_no += 1
         self.step_num = 0
@@ -127,6 +165,8 @@ class CraftingWorldEnv:
             self.desired_goal[...] = self._h_goal
             self.INIT_OBS[...] = self._h_init
         self._pull_goals()
+        if self.store_gif:                                                        # ray.py:205-216
+            self._gif_frames = [self._gif_frame()] if self.ep_no % self.render_save_rate == 0 else []
         return self._obs_dict()
 
     def _after_step_enqueue(self):
@@ -148,6 +188,8 @@ class CraftingWorldEnv:
         if not self._live:
             self.obs_image[...] = self._h_obs
         self._pull_goals()
+        if self.store_gif is True and self.ep_no % self.render_save_rate == 0:    # ray.py:370-374
+            self._gif_frames.append(self._gif_frame())
         info = {'task_success': self.achieved_goal_vector, 'desired_goal': self.desired_goal_vector,
                 'achieved_goal': self.achieved_goal_vector}                        # ray.py:376-378
         return self._obs_dict(), int(self._h_reward[0]), bool(self._h_done[0]), info

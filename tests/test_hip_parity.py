@@ -4,6 +4,7 @@
   (3) injected single-step states covering the whole transition table,
   (4) size-independent properties at BASELINE's full batch size (65 536 envs).
 Bit-exact everywhere: the path is integer-only."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1181,3 +1182,39 @@ def test_facade_render_of_a_supplied_state():
     with pytest.raises(ValueError):
         other.render(state=np.zeros((5, 5, 12), int))
     env.close(); other.close()
+
+
+@pytest.mark.gpu
+def test_facade_store_gif_files_and_rng_draw(tmp_path, monkeypatch):
+    """store_gif=True on the single-env class (ray.py:142-143,160-167,205-216,370-374,769-782): the env id is one
+    randint(0, 1000000) taken from the env's own stream at construction (so later placements shift exactly as the
+    reference's do), and every render_save_rate-th finished episode is written as
+    renders/env<id>/E<ep>(<steps>)_<desired>(<achieved>).gif with one frame per reset/step."""
+    import glob
+    from PIL import Image
+    import gym_craftingworld_amd as cw
+    monkeypatch.chdir(tmp_path)
+    kw = dict(size=(5, 5), max_steps=6, seed=3)
+    plain = cw.CraftingWorldEnv(**kw)
+    rec = cw.CraftingWorldEnv(store_gif=True, render_save_rate=2, **kw)
+    k, p = plain.get_rng_state()
+    rs = np.random.RandomState()
+    rs.set_state(('MT19937', k, p, 0, 0.0))
+    assert rec.env_id == int(rs.randint(0, 1000000))
+    k2, p2 = rec.get_rng_state()
+    assert p2 == rs.get_state()[2] and np.array_equal(k2[1:], rs.get_state()[1][1:])   # (word 0's low bits do not survive export)
+    assert os.path.isdir('renders/env%d' % rec.env_id)
+    rng = np.random.RandomState(0)
+    rec.reset()
+    episodes = 0
+    while episodes < 5:
+        _, _, d, _ = rec.step(int(rng.randint(6)))
+        if d:
+            rec.reset()
+            episodes += 1
+    files = sorted(glob.glob('renders/env%d/*.gif' % rec.env_id))
+    eps = sorted(int(os.path.basename(f)[1:].split('(')[0]) for f in files)
+    assert eps == [0, 2, 4], files
+    im = Image.open([f for f in files if os.path.basename(f).startswith('E0(')][0])
+    assert im.size == ((2 * 20 + 4) * 4, 20 * 4) and 1 <= im.n_frames <= 7
+    plain.close(); rec.close()
