@@ -130,6 +130,23 @@ class CraftingWorldEnv:
     def seed(self, seed=None):
         return self._vec.seed(seed)                                               # ray.py:145-147
 
+    @property
+    def np_random(self):
+        """The env's RNG stream as a numpy RandomState (ray.py:146).  Reading gives a SNAPSHOT of the device-resident
+        stream (drawing from it does not advance the env); assigning a RandomState -- `env.np_random =
+        np.random.RandomState(12345)`, as reference users do to pin a stream -- injects its state."""
+        k, p = self.get_rng_state()
+        rs = np.random.RandomState()
+        rs.set_state(('MT19937', k, p, 0, 0.0))
+        return rs
+
+    @np_random.setter
+    def np_random(self, rs):
+        st = rs.get_state()
+        if st[0] != 'MT19937':
+            raise ValueError('np_random must be a numpy RandomState (MT19937), as with gym <= 0.21')
+        self.set_rng_state(st[1], st[2])
+
     def set_rng_state(self, key, pos):
         """Inject a numpy RandomState state (`env.np_random.set_state` in reference terms)."""
         self._vec.set_rng_states(np.asarray(key)[None], np.asarray([pos]))

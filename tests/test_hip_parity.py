@@ -367,9 +367,10 @@ def test_single_env_facade_matches_golden():
     vector: RandomState(12345) reset + 300 actions from RandomState(999)."""
     import gym_craftingworld_amd as g
     env = g.make('craftingworld-v3')
-    st = np.random.RandomState(12345).get_state()
-    env.set_rng_state(st[1], st[2])
+    env.np_random = np.random.RandomState(12345)              # exactly what SURVEY 8c's reference session did
+    assert env.np_random.get_state()[2] % 624 == 0            # (reading gives a snapshot of the device-resident stream)
     obs = env.reset()
+    assert env.np_random.get_state()[2] == 617                # "MT pos after reset 617"
     assert obs['achieved_goal'] is obs['observation']
     assert env.desired_goal_vector.tolist() == [[1, 0, 0, 1, 0, 0, 0, 1, 0]] and env.agent_pos == (8, 5)
     assert crc(obs['observation']) == 0xf34f1edc and crc(obs['desired_goal']) == 0x9e9a73eb
