@@ -69,6 +69,7 @@ ABI = {
     'cw_render': (C.c_int, [_VP, _VP, _VP]),
     'cw_export_grid': (C.c_int, [_VP, _VP, _VP]),
     'cw_export_onehot': (C.c_int, [_VP, _VP, _VP]),
+    'cw_export_onehot_of': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'cw_get_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
     'cw_set_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),

@@ -22,7 +22,7 @@ hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
-hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st);
+hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, int which, hipStream_t st);
 }
 
 static thread_local char g_err[512] = "";
@@ -566,7 +566,7 @@ int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_grid: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_export(&e->P, out, 0, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_export(&e->P, out, 0, 0, (hipStream_t)stream));
     return CW_OK;
 }
 
@@ -575,7 +575,18 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_export(&e->P, out, 1, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_export(&e->P, out, 1, 0, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t stream)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot_of: null argument");
+    if (which < CW_STATE_CURRENT || which > CW_STATE_INIT) return fail(CW_ERR_INVALID, "cw_export_onehot_of: which must be CW_STATE_*");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_export_onehot_of called before cw_reset");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    HIP_TRY(cwk_launch_export(&e->P, out, 1, which, (hipStream_t)stream));
     return CW_OK;
 }
 

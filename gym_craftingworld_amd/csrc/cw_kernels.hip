@@ -1133,7 +1133,9 @@ __global__ __launch_bounds__(256) void cw_export_grid_kernel(CwParams P, uint8_t
     }
 }
 // one-hot [N][S][S][12] (observation_vector_space, ray.py:94-98): 0-7 objects, 8 agent, 9-11 hold
-__global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8_t *out)
+// which: 0 the current state, 1 the episode's goal state (imagine_obs' final_state, the OneHot variant's desired_goal,
+// onehot.py:310), 2 the state at reset (its init_observation, onehot.py:203); nothing is held in 1 and 2
+__global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8_t *out, int which)
 {
     const size_t total = (size_t)P.n_envs * P.ncell;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1142,10 +1144,12 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
         const uint32_t cell = (uint32_t)(g - (size_t)env * P.ncell);
         const uint4 h = P.hdr[env];
         uint32_t sp[8];
-        unpack_pos(P.pos[env], sp);
-        const uint32_t code = code_of(h.w, slot_at(sp, cell));
-        const uint32_t agent_cell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
-        const uint32_t hold = (h.x >> 16) & 0xFFu;
+        unpack_pos(which == 1 ? P.goal_pos[env] : which == 2 ? P.init_pos[env] : P.pos[env], sp);
+        const uint32_t codes = which == 1 ? P.goal_codes[env] : which == 2 ? CW_CODES_INITIAL : h.w;
+        const uint32_t code = code_of(codes, slot_at(sp, cell));
+        const uint32_t agent_cell = which == 1 ? (uint32_t)P.goal_agent[env] : which == 2 ? (uint32_t)P.init_agent[env]
+                                                                                            : (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+        const uint32_t hold = which ? 0u : (h.x >> 16) & 0xFFu;
         uint32_t bits = code ? (1u << (code - 1)) : 0u;
         if (cell == agent_cell) bits |= (1u << 8) | (hold ? (1u << (8 + hold)) : 0u);
         // 12 bytes of 0/1
@@ -1289,12 +1293,12 @@ hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, hipStream_t st)
+hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, int which, hipStream_t st)
 {
     const size_t total = (size_t)P->n_envs * P->ncell;
     int blocks = (int)((total + 255) / 256 < 256 * 32 ? (total + 255) / 256 : 256 * 32);
     if (blocks < 1) blocks = 1;
-    if (onehot) hipLaunchKernelGGL(cw_export_onehot_kernel, dim3(blocks), dim3(256), 0, st, *P, out);
+    if (onehot) hipLaunchKernelGGL(cw_export_onehot_kernel, dim3(blocks), dim3(256), 0, st, *P, out, which);
     else hipLaunchKernelGGL(cw_export_grid_kernel, dim3(blocks), dim3(256), 0, st, *P, out);
     return hipGetLastError();
 }

@@ -309,9 +309,10 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def reset(self, render_next=False):
         super().reset()
-        st = self._vec.get_state()
-        self._oh[...] = _one_hot_from(st['grid'][0], st['agent_rc'][0], int(st['hold'][0]))
-        self._oh_goal[...] = _one_hot_from(st['goal_grid'][0], st['goal_agent_rc'][0], 0)   # onehot.py:310
+        for which, dst in ((1, self._oh_goal), (0, self._oh)):                    # goal state (onehot.py:310), current state
+            self._lib.cw_export_onehot_of(self._eng, which, self._oh_pin_p, self._stream)
+            self._lib.cw_synchronize(self._eng, self._stream)
+            dst[...] = self._oh_pin_np
         self._oh_init[...] = self._oh                                             # onehot.py:203
         return self._oh_dict()
 

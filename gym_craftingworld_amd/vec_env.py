@@ -354,11 +354,13 @@ class CraftingWorldVecEnv:
         L.check(self._lib.cw_export_grid(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_grid')
         return out
 
-    def one_hot(self, out=None):
-        """obs_one_hot of ray.py:119 for every env: uint8 [N,S,S,12]."""
+    def one_hot(self, out=None, which='current'):
+        """obs_one_hot of ray.py:119 for every env: uint8 [N,S,S,12].  which='goal' / 'init' give the episode's goal state
+        and its state at reset -- CraftingWorldEnvOneHot's desired_goal and init_observation (onehot.py:310, :203)."""
         if out is None:
             out = torch.empty((self.num_envs, self.size, self.size, 12), dtype=torch.uint8, device=self.device)
-        L.check(self._lib.cw_export_onehot(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_onehot')
+        w = {'current': 0, 'goal': 1, 'init': 2}[which]
+        L.check(self._lib.cw_export_onehot_of(self._h, w, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_onehot_of')
         return out
 
     def mask_to_vector(self, mask):

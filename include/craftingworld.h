@@ -181,6 +181,10 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);
  * uint8 0/1 (channels 0-7 objects, 8 agent, 9-11 held item at the agent cell). */
 int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream);
 int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream);
+/* The same one-hot view of the episode's other two states -- what CraftingWorldEnvOneHot returns as desired_goal
+ * (imagine_obs' final state, carftingworld_onehot.py:310) and init_observation (the state at reset, :203). */
+enum { CW_STATE_CURRENT = 0, CW_STATE_GOAL = 1, CW_STATE_INIT = 2 };
+int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t stream);
 
 /* --- state injection / checkpoint (synchronous; SURVEY §5 "checkpoint / resume") ------------ */
 int cw_get_state(cw_engine *e, cw_state_view *host);

@@ -1219,3 +1219,28 @@ def test_facade_store_gif_files_and_rng_draw(tmp_path, monkeypatch):
     im = Image.open([f for f in files if os.path.basename(f).startswith('E0(')][0])
     assert im.size == ((2 * 20 + 4) * 4, 20 * 4) and 1 <= im.n_frames <= 7
     plain.close(); rec.close()
+
+
+@pytest.mark.gpu
+def test_one_hot_of_goal_and_init_states_vs_oracle():
+    """The OneHot variant's other two observations at batch scale: one_hot(which='goal') is imagine_obs' final state
+    (onehot.py:310), one_hot(which='init') the state at reset (onehot.py:203), both [N,S,S,12] on the device."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, kw = 96, dict(size=(8, 8), max_steps=15)
+    keys, pos = _np_states(N, 777)
+    env = CraftingWorldVecEnv(N, obs_mode='state', **kw)
+    env.set_rng_states(keys, pos)
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), **kw)
+    env.reset(); ora.reset()
+    acts = np.random.RandomState(1).randint(0, 6, size=(40, N)).astype(np.int8)
+    env.rollout(torch.as_tensor(acts.astype(np.uint8), device=env.device), record=False)
+    ora.rollout(acts, nthreads=4)
+    goal, init, cur = (env.one_hot(which=w).cpu().numpy() for w in ('goal', 'init', 'current'))
+    codes = lambda oh: (oh[:, :, :8] * np.arange(1, 9)).sum(axis=2)   # noqa: E731
+    for i, s in enumerate(ora.states()):
+        assert np.array_equal(codes(goal[i]), s['goal_grid']) and np.array_equal(codes(init[i]), s['init_grid']), i
+        assert np.array_equal(codes(cur[i]), s['grid']), i
+        assert tuple(np.argwhere(goal[i][:, :, 8] == 1)[0]) == s['goal_agent'], i
+        assert goal[i][:, :, 8].sum() == 1 and init[i][:, :, 8].sum() == 1 and goal[i][:, :, 9:].sum() == 0 and init[i][:, :, 9:].sum() == 0
+    env.close()
