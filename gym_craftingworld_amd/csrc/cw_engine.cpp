@@ -18,6 +18,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
+hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
@@ -717,9 +718,18 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     const size_t N = (size_t)e->n;
     const int S = e->S, nc = e->ncell;
     std::vector<uint32_t> hdr(N * 4);
-    std::vector<uint16_t> pos(N * 8), ipos(N * 8);
+    std::vector<uint16_t> pos(N * 8), ipos(N * 8), gpos, gagent, iagent;
+    std::vector<uint32_t> gcodes;
     std::vector<int32_t> epno(N);
+    const bool restore_episode = v->goal_grid || v->goal_agent_rc || v->init_agent_rc;
     HIP_TRY(hipDeviceSynchronize());
+    if (restore_episode) {                           // the episode records: goal state (imagine_obs' result) and the agent's start cell
+        gpos.resize(N * 8); gagent.resize(N); iagent.resize(N); gcodes.resize(N);
+        HIP_TRY(hipMemcpy(gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(gcodes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
+    }
     HIP_TRY(hipMemcpy(hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
@@ -771,6 +781,28 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
                 ipos[i * 8 + g[c] - 1] = (uint16_t)c;
             }
         }
+        if (v->goal_grid) {                          // any slot order paints the same goal frame
+            const uint8_t *g = v->goal_grid + i * nc;
+            uint32_t codes = 0;
+            int k = 0;
+            for (int c = 0; c < nc; c++) {
+                if (g[c] == 0) continue;
+                if (g[c] > 8 || k >= 8) return fail(CW_ERR_INVALID, "cw_set_state: env %zu goal grid: code > 8 or more than 8 objects", i);
+                gpos[i * 8 + k] = (uint16_t)c;
+                codes |= (uint32_t)g[c] << (4 * k);
+                k++;
+            }
+            for (; k < 8; k++) gpos[i * 8 + k] = CW_POS_GONE;
+            gcodes[i] = codes;
+        }
+        if (v->goal_agent_rc) {
+            if (v->goal_agent_rc[i * 2] >= S || v->goal_agent_rc[i * 2 + 1] >= S) return fail(CW_ERR_INVALID, "cw_set_state: goal agent of env %zu off the grid", i);
+            gagent[i] = (uint16_t)(v->goal_agent_rc[i * 2] * S + v->goal_agent_rc[i * 2 + 1]);
+        }
+        if (v->init_agent_rc) {
+            if (v->init_agent_rc[i * 2] >= S || v->init_agent_rc[i * 2 + 1] >= S) return fail(CW_ERR_INVALID, "cw_set_state: init agent of env %zu off the grid", i);
+            iagent[i] = (uint16_t)(v->init_agent_rc[i * 2] * S + v->init_agent_rc[i * 2 + 1]);
+        }
         if (v->achieved) h[1] = (h[1] & 0xFFFF0000u) | v->achieved[i];
         if (v->desired) h[1] = (h[1] & 0x0000FFFFu) | ((uint32_t)v->desired[i] << 16);
         if (v->step_num) {
@@ -783,8 +815,16 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     HIP_TRY(hipMemcpy(e->P.pos, pos.data(), N * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->P.init_pos, ipos.data(), N * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->P.ep_no, epno.data(), N * 4, hipMemcpyHostToDevice));
-    if (e->obs_mode != CW_OBS_STATE)   // the persistent frame must follow the injected state
-        HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, nullptr));
+    if (restore_episode) {
+        HIP_TRY(hipMemcpy(e->P.goal_pos, gpos.data(), N * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->P.goal_codes, gcodes.data(), N * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->P.goal_agent, gagent.data(), N * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->P.init_agent, iagent.data(), N * 2, hipMemcpyHostToDevice));
+    }
+    if (e->obs_mode != CW_OBS_STATE) {   // the persistent frames must follow the injected state
+        if (restore_episode) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));
+        else HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, nullptr));
+    }
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }

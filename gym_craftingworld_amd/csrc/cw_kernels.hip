@@ -1016,12 +1016,24 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     const uint32_t hold = (hx >> 16) & 0xFFu;
     const uint32_t hold_rgb = hold ? rgb_of_code(hold) : 0x00FFFFFFu;
     constexpr bool three = (MODE == 0);
+    constexpr bool goal_too = (MODE == 0) || (MODE == 5);
     const size_t off = (size_t)cur_env * P.frame_bytes;
     uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
     if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane);
     else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
-    if (three) {                                             // desired_goal = render(final_state), ray.py:299
+    if (MODE == 5) {                                         // restored checkpoint: INIT_OBS from the reset-time state
+        uint32_t ip[8], irgb[8];
+        const u32x4s ipp = cload((const u32x4s *)(P.init_pos + cur_env));
+        unpack_pos_s(ipp, ip);
+        const uint32_t iaw = cload((const uint32_t *)((const uint8_t *)P.init_agent + ((2 * cur_env) & ~3)));
+        const uint32_t ia = (iaw >> (16 * (cur_env & 1))) & 0xFFFFu;
+#pragma unroll
+        for (int k = 0; k < 8; k++) irgb[k] = rgb_of_code((uint32_t)k + 1u);
+        if (P.raster == 1) render_frame_alt(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, CW_CODES_INITIAL, ia, 0u, lane);
+        else render_frame(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, irgb, ia, 0x00FFFFFFu, lane);
+    }
+    if (goal_too) {                                          // desired_goal = render(final_state), ray.py:299
         uint32_t gp[8], grgb[8];
         const u32x4s gpp = cload((const u32x4s *)(P.goal_pos + cur_env));
         unpack_pos_s(gpp, gp);
@@ -1115,6 +1127,7 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
 __global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
 {
     if (mode == 0) render_jobs<0>(P, 0, nullptr, 0, -1);
+    else if (mode == 5) render_jobs<5>(P, 0, nullptr, 0, -1);    // cw_set_state: all three frames of every env from its restored state
     else render_jobs<4>(P, 0, nullptr, 0, -1);
 }
 
@@ -1264,6 +1277,13 @@ hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mo
     hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1, 0);
     if (obs_mode != 0)
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(tn, n)), dim3(256), 0, st, *P, 0);
+    return hipGetLastError();
+}
+
+// every env's observation, desired_goal and init_observation frames from its (restored) current, goal and reset-time states
+hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st)
+{
+    hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(*T, P->n_envs)), dim3(256), 0, st, *P, 5);
     return hipGetLastError();
 }
 

@@ -267,6 +267,7 @@ class CraftingWorldVecEnv:
 
     def reset(self):
         L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')
+        self._has_reset = True
         if self.host_outputs:
             self._sync()
         return self._observation()
@@ -381,10 +382,12 @@ class CraftingWorldVecEnv:
         return out
 
     def set_state(self, **fields):
-        """Overwrite dynamic state from numpy arrays (any subset of grid, init_grid, agent_rc, hold,
-        achieved, desired, step_num, ep_no)."""
-        dt = dict(grid=np.uint8, init_grid=np.uint8, agent_rc=np.uint8, hold=np.uint8, achieved=np.uint16,
-                  desired=np.uint16, step_num=np.int32, ep_no=np.int32)
+        """Overwrite state from numpy arrays: any subset of get_state()'s fields (grid, init_grid, goal_grid, agent_rc,
+        init_agent_rc, goal_agent_rc, hold, achieved, desired, step_num, ep_no); with a goal / init-agent field given,
+        all three frames are repainted from the restored states."""
+        dt = dict(grid=np.uint8, init_grid=np.uint8, goal_grid=np.uint8, agent_rc=np.uint8, init_agent_rc=np.uint8,
+                  goal_agent_rc=np.uint8, hold=np.uint8, achieved=np.uint16, desired=np.uint16, step_num=np.int32,
+                  ep_no=np.int32)
         keep = {}
         view = L.cw_state_view()
         for k, a in fields.items():
@@ -395,6 +398,28 @@ class CraftingWorldVecEnv:
                 raise ValueError('%s must have num_envs rows' % k)
             setattr(view, k, keep[k].ctypes.data_as(C.c_void_p))
         L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state')
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def save_checkpoint(self, path):
+        """Everything the env batch needs to continue bit-identically -- state, episode records (goal state, start
+        state), RNG streams -- as one .npz (host copy; synchronises)."""
+        keys, pos = self.get_rng_states()
+        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list))
+        np.savez_compressed(path, rng_keys=keys, rng_pos=pos, counters=self.counters.cpu().numpy(),
+                            meta=np.frombuffer(repr(sorted(meta.items())).encode(), dtype=np.uint8), **self.get_state())
+
+    def load_checkpoint(self, path):
+        """Restore a save_checkpoint() file into an engine built with the same configuration (task menus are part
+        of the configuration, not of the checkpoint).  The step/episode counters of this engine keep counting on."""
+        z = np.load(path)
+        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list))
+        if bytes(z['meta']).decode() != repr(sorted(meta.items())):
+            raise ValueError('checkpoint was written by a different configuration: %s' % bytes(z['meta']).decode())
+        if not getattr(self, '_has_reset', False):
+            self.reset()                                        # set_state needs an initialised engine
+        self.set_rng_states(z['rng_keys'], z['rng_pos'])
+        self.set_state(**{k: z[k] for k in ('grid', 'init_grid', 'goal_grid', 'agent_rc', 'init_agent_rc', 'goal_agent_rc',
+                                            'hold', 'achieved', 'desired', 'step_num', 'ep_no')})
 
     def profile_begin(self, max_steps):
         """Bracket each kernel of the following step() calls with HIP events on the launch stream."""

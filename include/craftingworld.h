@@ -123,10 +123,10 @@ typedef struct cw_buffer_table {
 typedef struct cw_state_view {
     uint8_t *grid;        /* [N][S][S] cell codes            (obs_one_hot[:,:,:8], ray.py:119)   */
     uint8_t *init_grid;   /* [N][S][S] codes at reset        (INIT_OBS_VECTOR, ray.py:183)       */
-    uint8_t *goal_grid;   /* [N][S][S] imagine_obs final_state codes (get only)                  */
+    uint8_t *goal_grid;   /* [N][S][S] imagine_obs final_state codes (set: restores a checkpoint's goal)  */
     uint8_t *agent_rc;    /* [N][2]                          (agent_pos)                          */
-    uint8_t *init_agent_rc; /* [N][2] agent cell at reset (get only; channel 8 of INIT_OBS_VECTOR) */
-    uint8_t *goal_agent_rc; /* [N][2] (get only)                                                   */
+    uint8_t *init_agent_rc; /* [N][2] agent cell at reset (channel 8 of INIT_OBS_VECTOR)              */
+    uint8_t *goal_agent_rc; /* [N][2] agent cell of the goal state                                    */
     uint8_t *hold;        /* [N]                                                                   */
     uint16_t *achieved;   /* [N]                             (achieved_goal_vector)               */
     uint16_t *desired;    /* [N]                             (desired_goal_vector)                */
