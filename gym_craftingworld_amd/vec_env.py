@@ -404,15 +404,18 @@ class CraftingWorldVecEnv:
         """Everything the env batch needs to continue bit-identically -- state, episode records (goal state, start
         state), RNG streams -- as one .npz (host copy; synchronises)."""
         keys, pos = self.get_rng_states()
-        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list))
+        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list),
+                    fixed_init_state=self.fixed_init_state)
         np.savez_compressed(path, rng_keys=keys, rng_pos=pos, counters=self.counters.cpu().numpy(),
                             meta=np.frombuffer(repr(sorted(meta.items())).encode(), dtype=np.uint8), **self.get_state())
 
     def load_checkpoint(self, path):
         """Restore a save_checkpoint() file into an engine built with the same configuration (task menus are part
-        of the configuration, not of the checkpoint).  The step/episode counters of this engine keep counting on."""
+        of the configuration, not of the checkpoint; so are fixed_init_state pools: build the engine with the seed the
+        original was built with and they are the same).  The step/episode counters of this engine keep counting on."""
         z = np.load(path)
-        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list))
+        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list),
+                    fixed_init_state=self.fixed_init_state)
         if bytes(z['meta']).decode() != repr(sorted(meta.items())):
             raise ValueError('checkpoint was written by a different configuration: %s' % bytes(z['meta']).decode())
         if not getattr(self, '_has_reset', False):
