@@ -72,6 +72,9 @@ ABI = {
     'cw_export_onehot_of': (C.c_int, [_VP, C.c_int, _VP, _VP]),
     'cw_get_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
     'cw_set_state': (C.c_int, [_VP, C.POINTER(cw_state_view)]),
+    'cw_checkpoint_bytes': (C.c_size_t, [_VP]),
+    'cw_checkpoint_save': (C.c_int, [_VP, _VP, C.c_size_t]),
+    'cw_checkpoint_load': (C.c_int, [_VP, _VP, C.c_size_t]),
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),

@@ -17,13 +17,14 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
-hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st);
+hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
+hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
-hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, int which, hipStream_t st);
+hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
 
 static thread_local char g_err[512] = "";
@@ -70,6 +71,7 @@ struct cw_engine {
     std::vector<void *> host_allocs;   // hipHostMalloc'ed (cw_config.host_outputs)
     int32_t *host_actions = nullptr;
     std::vector<CwMenuDev> menus;
+    uint32_t *seed_scratch = nullptr;  // [N] device: seeds of cw_seed_int
     int n = 0, S = 0, ncell = 0, K = 0;
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
     hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
@@ -194,13 +196,6 @@ static void prof_free(cw_engine *e)
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     e->prof_ev.clear();
     e->prof_cap = e->prof_n = 0;
-}
-
-static int upload_mt(cw_engine *e, const std::vector<uint32_t> &words, const std::vector<int32_t> &idx)
-{
-    HIP_TRY(hipMemcpy(e->P.mt, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->P.mt_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    return CW_OK;
 }
 
 // XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
@@ -356,6 +351,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
         CwTuning &tn = e->tune;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
+        tn.list_blocks = tn.n_cu;
         tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
         tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
         const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
@@ -382,6 +380,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC(mt, N * CW_MT_N);
     ALLOC(mt_idx, N);
     ALLOC(pool, N * (size_t)e->K * 9);
+    if (rc == CW_OK) rc = dev_alloc(e, &e->seed_scratch, N);
     // step outputs and frames: device memory, or mapped host memory for the single-env loop
 #define ALLOC_OUT(field, count)                                 \
     if (rc == CW_OK) rc = cfg->host_outputs ? host_alloc(e, &P.field, (count)) : dev_alloc(e, &P.field, (count))
@@ -459,20 +458,22 @@ int cw_destroy(cw_engine *e)
     return CW_OK;
 }
 
+// Both seeders run on the device (cw_seed_kernel, one lane per env): the host only copies what the caller handed over.
+// (A host-side conversion built an N x 624-word vector serially: 2.6 GB and seconds at 2^20 envs per GPU.)
 int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
 {
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_seed_mt: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t N = (size_t)e->n;
-    std::vector<uint32_t> words(keys, keys + N * CW_MT_N);
-    std::vector<int32_t> idx(N);
-    for (size_t i = 0; i < N; i++) {
+    for (size_t i = 0; i < N; i++)
         if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
-        idx[i] = cwh_mt_from_numpy(&words[i * CW_MT_N], pos[i]);
-    }
     HIP_TRY(hipDeviceSynchronize());
-    return upload_mt(e, words, idx);
+    HIP_TRY(hipMemcpy(e->P.mt, keys, N * CW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->P.mt_idx, pos, N * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(cwk_launch_seed(&e->P, nullptr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return CW_OK;
 }
 
 int cw_seed_int(cw_engine *e, const uint32_t *seeds)
@@ -480,15 +481,11 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     if (!e || !seeds) return fail(CW_ERR_INVALID, "cw_seed_int: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    const size_t N = (size_t)e->n;
-    std::vector<uint32_t> words(N * CW_MT_N);
-    std::vector<int32_t> idx(N);
-    for (size_t i = 0; i < N; i++) {
-        cwh_mt_init_genrand(&words[i * CW_MT_N], seeds[i]);
-        idx[i] = cwh_mt_from_numpy(&words[i * CW_MT_N], CW_MT_N);   // init_genrand leaves pos = 624
-    }
     HIP_TRY(hipDeviceSynchronize());
-    return upload_mt(e, words, idx);
+    HIP_TRY(hipMemcpy(e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return CW_OK;
 }
 
 int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
@@ -511,7 +508,9 @@ int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
     if (e->K == 0) return CW_OK;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_pool(&e->P, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_pool(&e->P, &e->tune, (hipStream_t)stream));
+    // one-time, off the hot path: the pool and the advanced RNG streams are complete before any other stream can reset from them
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return CW_OK;
 }
 
@@ -567,7 +566,7 @@ int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_grid: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_export(&e->P, out, 0, 0, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 0, 0, (hipStream_t)stream));
     return CW_OK;
 }
 
@@ -576,7 +575,7 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_export(&e->P, out, 1, 0, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, 0, (hipStream_t)stream));
     return CW_OK;
 }
 
@@ -587,7 +586,7 @@ int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t strea
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_export_onehot_of called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    HIP_TRY(cwk_launch_export(&e->P, out, 1, which, (hipStream_t)stream));
+    HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, which, (hipStream_t)stream));
     return CW_OK;
 }
 
@@ -825,6 +824,110 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
         if (restore_episode) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));
         else HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, nullptr));
     }
+    HIP_TRY(hipDeviceSynchronize());
+    return CW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ checkpoint blob
+// The engine's complete resumable state as one opaque host blob: the RAW device records (header, slots, episode
+// records, RNG streams in engine form, fixed_init_state pool, last step outputs, counters), restored verbatim -- so a
+// resumed engine returns the same tensors as the run that never stopped, slot order included -- plus a header that
+// pins the configuration the records only make sense under (batch, grid, episode length, task_list width, pool size,
+// and a hash of the task menus; each env's menu id and reward rule travel inside its header record).
+struct CwCkptHeader {
+    char magic[8];
+    uint32_t version, header_bytes;
+    int32_t n_envs, size, max_steps, pool_k;
+    uint32_t task_mask, n_menus;
+    uint64_t menus_hash, total_bytes;
+};
+static const char CW_CKPT_MAGIC[8] = {'C', 'W', 'C', 'K', 'P', 'T', 0, 1};
+
+struct CkptSection { void *dev; size_t bytes; };
+static std::vector<CkptSection> ckpt_sections(cw_engine *e)
+{
+    const CwParams &P = e->P;
+    const size_t N = (size_t)e->n;
+    return {{P.hdr, N * 16}, {P.pos, N * 16}, {P.init_pos, N * 16}, {P.goal_pos, N * 16}, {P.goal_codes, N * 4},
+            {P.init_agent, N * 2}, {P.goal_agent, N * 2}, {P.ep_no, N * 4}, {P.mt, N * CW_MT_N * 4}, {P.mt_idx, N * 4},
+            {P.pool, N * (size_t)e->K * 9 * 2}, {P.reward, N * 4}, {P.done, N}, {P.achieved_out, N * 2}, {P.desired_out, N * 2},
+            {P.episode_length, N * 4}, {P.counters, 4 * 8}};
+}
+static uint64_t menus_hash(const cw_engine *e)
+{
+    uint64_t h = 1469598103934665603ull;                 // FNV-1a over the device-form menus
+    const unsigned char *b = (const unsigned char *)e->menus.data();
+    for (size_t i = 0; i < e->menus.size() * sizeof(CwMenuDev); i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+static CwCkptHeader ckpt_header(cw_engine *e)
+{
+    CwCkptHeader h{};
+    memcpy(h.magic, CW_CKPT_MAGIC, 8);
+    h.version = 1;
+    h.header_bytes = (uint32_t)sizeof(CwCkptHeader);
+    h.n_envs = e->n; h.size = e->S; h.max_steps = e->P.max_steps; h.pool_k = e->K;
+    h.task_mask = e->P.task_mask; h.n_menus = (uint32_t)e->menus.size();
+    h.menus_hash = menus_hash(e);
+    h.total_bytes = sizeof(CwCkptHeader);
+    for (const CkptSection &sec : ckpt_sections(e)) h.total_bytes += sec.bytes;
+    return h;
+}
+
+extern "C" {
+
+size_t cw_checkpoint_bytes(cw_engine *e) { return e ? (size_t)ckpt_header(e).total_bytes : 0; }
+
+int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity)
+{
+    if (!e || !buf) return fail(CW_ERR_INVALID, "cw_checkpoint_save: null argument");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_checkpoint_save called before cw_reset");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    const CwCkptHeader h = ckpt_header(e);
+    if (capacity < h.total_bytes) return fail(CW_ERR_INVALID, "cw_checkpoint_save: buffer of %zu bytes, %llu needed", capacity, (unsigned long long)h.total_bytes);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned char *p = (unsigned char *)buf;
+    memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    for (const CkptSection &sec : ckpt_sections(e)) {
+        if (sec.bytes) HIP_TRY(hipMemcpy(p, sec.dev, sec.bytes, hipMemcpyDefault));
+        p += sec.bytes;
+    }
+    return CW_OK;
+}
+
+int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
+{
+    if (!e || !buf) return fail(CW_ERR_INVALID, "cw_checkpoint_load: null argument");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    CwCkptHeader h;
+    if (length < sizeof(h)) return fail(CW_ERR_INVALID, "cw_checkpoint_load: %zu bytes is not a checkpoint", length);
+    memcpy(&h, buf, sizeof(h));
+    const CwCkptHeader mine = ckpt_header(e);
+    if (memcmp(h.magic, CW_CKPT_MAGIC, 8) != 0 || h.version != 1 || h.header_bytes != sizeof(CwCkptHeader))
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: not a CraftingWorld checkpoint (or another version)");
+    if (h.n_envs != mine.n_envs || h.size != mine.size || h.max_steps != mine.max_steps || h.pool_k != mine.pool_k ||
+        h.task_mask != mine.task_mask)
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: checkpoint of %d envs, size %d, max_steps %d, fixed_init_state %d, task mask %#x; "
+                    "this engine: %d, %d, %d, %d, %#x", h.n_envs, h.size, h.max_steps, h.pool_k, h.task_mask, mine.n_envs, mine.size,
+                    mine.max_steps, mine.pool_k, mine.task_mask);
+    if (h.n_menus != mine.n_menus || h.menus_hash != mine.menus_hash)
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: the checkpoint was written with different task menus (selected_tasks / "
+                    "number_of_tasks / stacking / reward_style)");
+    if (h.total_bytes != mine.total_bytes || length < h.total_bytes)
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
+    HIP_TRY(hipDeviceSynchronize());
+    const unsigned char *p = (const unsigned char *)buf + sizeof(h);
+    for (const CkptSection &sec : ckpt_sections(e)) {
+        if (sec.bytes) HIP_TRY(hipMemcpy(sec.dev, p, sec.bytes, hipMemcpyDefault));
+        p += sec.bytes;
+    }
+    e->has_reset = true;
+    if (e->obs_mode != CW_OBS_STATE) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));   // frames follow the records
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }

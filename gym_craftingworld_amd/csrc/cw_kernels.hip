@@ -1174,6 +1174,39 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
     }
 }
 
+// ------------------------------------------------------------------------------------ seeding
+// seed() (ray.py:145-147) at batch scale, one lane per env: numpy RandomState(seed) is init_genrand -- 623 dependent
+// multiplies, embarrassingly parallel over envs -- and leaves pos = 624; an injected RandomState state (key, pos) is
+// already in P.mt / P.mt_idx.  Either way the first `pos` iterations of numpy's in-place twist loop turn the key into
+// the engine's consume-and-replace form (cw_mt.h): words < pos next-generation, the rest current.
+__global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t *seeds)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_envs) return;
+    uint32_t *s = P.mt + (size_t)i * CW_MT_WORDS;
+    int pos;
+    if (seeds) {
+        uint32_t x = seeds[i];
+        s[0] = x;
+        for (int k = 1; k < CW_MT_WORDS; k++) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+            s[k] = x;
+        }
+        pos = CW_MT_WORDS;
+    } else {
+        pos = min(max(P.mt_idx[i], 0), CW_MT_WORDS);
+    }
+    uint32_t cur = s[0];
+    for (int k = 0; k < pos; k++) {
+        const uint32_t nxt = s[k + 1 == CW_MT_WORDS ? 0 : k + 1];          // (word 0 is already next-generation at k = 623)
+        const uint32_t far = s[k + 397 >= CW_MT_WORDS ? k + 397 - CW_MT_WORDS : k + 397];
+        const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+        s[k] = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        cur = nxt;
+    }
+    P.mt_idx[i] = pos == CW_MT_WORDS ? 0 : pos;
+}
+
 // ------------------------------------------------------------------------------------ launchers
 static inline int cw_render_grid(const CwTuning &tn, int jobs)
 {
@@ -1183,17 +1216,17 @@ static inline int cw_render_grid(const CwTuning &tn, int jobs)
     // leaves the wave slots for the reset kernel running beside it
     const int wpb = tn.render_threads / CW_WAVE;
     int blocks = (jobs + wpb - 1) / wpb;
-    if (blocks > 256 * tn.render_blocks_per_cu) blocks = 256 * tn.render_blocks_per_cu;
+    if (blocks > tn.n_cu * tn.render_blocks_per_cu) blocks = tn.n_cu * tn.render_blocks_per_cu;
     if (tn.render_blocks_abs > 0 && blocks > tn.render_blocks_abs) blocks = tn.render_blocks_abs;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
 
-static inline int cw_reset_grid(int jobs)
+static inline int cw_reset_grid(const CwTuning &tn, int jobs)
 {
     // persistent: one wave per env in flight, 2 workgroups (8 waves) per CU at most
     int blocks = (jobs + CW_RESET_WAVES - 1) / CW_RESET_WAVES;
-    if (blocks > 256 * 2) blocks = 256 * 2;
+    if (blocks > tn.n_cu * 2) blocks = tn.n_cu * 2;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -1218,7 +1251,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
 {
     const CwTuning &tn = *T;
     const int n = P->n_envs;
-    const dim3 reset_grid(cw_reset_grid(n)), reset_block(CW_RESET_WAVES * CW_WAVE);
+    const dim3 reset_grid(cw_reset_grid(tn, n)), reset_block(CW_RESET_WAVES * CW_WAVE);
     const bool pixels = obs_mode != 0;
     const bool overlapped = (obs_mode == 1 && auto_reset && tn.overlap);
     const bool ev_all = ev && (tn.profile_side || !overlapped);
@@ -1274,7 +1307,7 @@ hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mo
 {
     const CwTuning &tn = *T;
     const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1, 0);
+    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(tn, n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1, 0);
     if (obs_mode != 0)
         hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(tn, n)), dim3(256), 0, st, *P, 0);
     return hipGetLastError();
@@ -1287,10 +1320,16 @@ hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipSt
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_pool(const CwParams *P, hipStream_t st)
+hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(cw_seed_kernel, dim3((P->n_envs + 255) / 256), dim3(256), 0, st, *P, seeds_dev);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st)
 {
     const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_pool_kernel, dim3(cw_reset_grid(n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P);
+    hipLaunchKernelGGL(cw_pool_kernel, dim3(cw_reset_grid(*T, n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P);
     return hipGetLastError();
 }
 
@@ -1313,10 +1352,11 @@ hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_export(const CwParams *P, uint8_t *out, int onehot, int which, hipStream_t st)
+hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st)
 {
     const size_t total = (size_t)P->n_envs * P->ncell;
-    int blocks = (int)((total + 255) / 256 < 256 * 32 ? (total + 255) / 256 : 256 * 32);
+    const size_t cap = (size_t)T->n_cu * 32;
+    int blocks = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
     if (blocks < 1) blocks = 1;
     if (onehot) hipLaunchKernelGGL(cw_export_onehot_kernel, dim3(blocks), dim3(256), 0, st, *P, out, which);
     else hipLaunchKernelGGL(cw_export_grid_kernel, dim3(blocks), dim3(256), 0, st, *P, out);

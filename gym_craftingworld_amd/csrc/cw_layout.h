@@ -41,10 +41,11 @@ struct CwMenuDev {
 // Host-side launch tuning of one engine (defaults = the measured best; the CW_TUNE_* /
 // CW_PROFILE_* environment variables read in cw_create override them for experiments).
 struct CwTuning {
+    int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
     int render_blocks_per_cu = 1;   // render workgroups per CU (persistent, grid-stride over frames)
     int render_blocks_abs = 0;      // >0: absolute cap on render workgroups
     int render_threads = 256;       // threads per render workgroup (64, 128, 256)
-    int list_blocks = 256;          // workgroups of the done-list (terminal-frame) render
+    int list_blocks = 0;            // workgroups of the done-list (terminal-frame) render (0: one per CU)
     int overlap = 1;                // full-pixel step: reset (+ its frames) on the side stream beside the main render
     int render_q_all = 0;           // XCD-aware frame shares (cw_create calibrates): rounds painted by every wave ...
     int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)

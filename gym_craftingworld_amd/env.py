@@ -235,7 +235,9 @@ class CraftingWorldEnv:
             self._scratch = CraftingWorldVecEnv(1, size=(S, S), obs_mode='state', device=self._vec.device, seed=0,
                                                 auto_reset=False, raster=self._raster)
             self._scratch.reset()
-        self._scratch.set_state(grid=grid[None], init_grid=grid[None], agent_rc=np.array([[ar[0], ac[0]]]), hold=np.array([hold]))
+        # rendering needs only (grid, agent, hold); the scratch engine's init records are irrelevant -- and a reachable state
+        # may hold two sticks / breads / houses, which no init grid can (sample_state places one of each)
+        self._scratch.set_state(grid=grid[None], agent_rc=np.array([[ar[0], ac[0]]]), hold=np.array([hold]))
         return self._scratch.render()[0].cpu().numpy().astype(self._dtype)
 
     def compute_reward(self, achieved_goal, desired_goal, info=None):

@@ -59,3 +59,16 @@ class MultiDiscrete:
 
     def sample(self):
         return (self._rng.random_sample(self.nvec.shape) * self.nvec).astype(np.int64)
+
+
+def batch_space(space, n):
+    """gym.vector.utils.batch_space for the spaces used here: a leading axis of n on every Box (low/high tiled), Dict
+    batched key by key, Discrete -> MultiDiscrete.  Works on gym's own classes and on the stand-ins above."""
+    if hasattr(space, 'spaces'):
+        return Dict({k: batch_space(v, n) for k, v in space.spaces.items()})
+    if hasattr(space, 'n'):
+        return MultiDiscrete([space.n] * n)
+    low = np.broadcast_to(np.asarray(space.low), space.shape)
+    high = np.broadcast_to(np.asarray(space.high), space.shape)
+    b = Box(low=low.min() if low.size else 0, high=high.max() if high.size else 0, shape=(n,) + tuple(space.shape), dtype=space.dtype)
+    return b

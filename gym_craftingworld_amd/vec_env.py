@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 from . import seeding
 from ._wrap import tensor_view
-from .spaces import Box, Dict, Discrete, MultiDiscrete
+from .spaces import Box, Dict, Discrete, MultiDiscrete, batch_space
 
 TASK_LIST = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe',
              'MoveHammer', 'MoveSticks']                       # ray.py:40-41
@@ -90,6 +90,8 @@ class CraftingWorldVecEnv:
     """
 
     metadata = {'render.modes': ['Non']}
+    is_vector_env = True          # gym.vector.VectorEnv marker (wrappers key on it)
+    viewer = None
 
     def __init__(self, num_envs, size=(21, 21), fixed_init_state=0, max_steps=300, store_gif=False,
                  render_save_rate=1, task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None,
@@ -191,7 +193,7 @@ class CraftingWorldVecEnv:
         else:
             self.single_observation_space = Dict({k: Box(0, 255, pix, np.uint8) for k in
                                                   ('observation', 'desired_goal', 'achieved_goal', 'init_observation')})
-        self.observation_space = self.single_observation_space       # batched along axis 0 of every tensor
+        self.observation_space = batch_space(self.single_observation_space, N)   # gym.vector: leading N on every Box
         self.observation_vector_space = Dict(dict(                   # ray.py:94-110
             observation=Box(0, 1, (self.size, self.size, 12), np.uint8),
             desired_goal=Box(0, 1, (1, len(self.task_list)), np.uint8),
@@ -210,10 +212,25 @@ class CraftingWorldVecEnv:
         except AttributeError:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def close(self):
+    def close_extras(self, **kwargs):
+        """gym.vector hook: nothing besides the engine to release."""
+
+    def close(self, **kwargs):
         if getattr(self, '_h', None):
+            self.close_extras(**kwargs)
             self._lib.cw_destroy(self._h)
             self._h = None
+
+    @property
+    def closed(self):
+        return getattr(self, '_h', None) is None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def __repr__(self):
+        return 'CraftingWorldVecEnv(%d envs, %dx%d, obs_mode=%r, %s)' % (self.num_envs, self.size, self.size, self.obs_mode, self.device)
 
     def __del__(self):
         if sys is None or sys.is_finalizing():
@@ -225,10 +242,16 @@ class CraftingWorldVecEnv:
 
     # ------------------------------------------------------------------ RNG (ray.py:145-147)
     def seed(self, seed=None):
-        """Env i gets seed+i.  seed_style 'numpy': stream of numpy RandomState(seed+i);
-        'gym': gym<=0.21 np_random(seed+i) hashing (seeding.py, unpinned)."""
-        base = seeding.create_seed(seed)
-        seeds = [(base + i) for i in range(self.num_envs)]
+        """gym.vector's seed(seeds): an int -> env i gets seed+i; a list/array of num_envs ints -> env i gets seeds[i];
+        None -> OS entropy (ray.py:70).  seed_style 'numpy': env stream = numpy RandomState(seed_i);
+        'gym': gym<=0.21 np_random(seed_i) hashing (seeding.py, unpinned).  Returns the per-env seeds."""
+        if seed is not None and not isinstance(seed, (int, np.integer)):
+            seeds = [seeding.create_seed(int(s)) for s in np.asarray(seed).reshape(-1)]
+            if len(seeds) != self.num_envs:
+                raise ValueError('expected %d seeds, got %d' % (self.num_envs, len(seeds)))
+        else:
+            base = seeding.create_seed(seed)
+            seeds = [(base + i) for i in range(self.num_envs)]
         if self.seed_style == 'gym':
             keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
             pos = np.empty(self.num_envs, dtype=np.int32)
@@ -265,12 +288,22 @@ class CraftingWorldVecEnv:
     def _sync(self):
         L.check(self._lib.cw_synchronize(self._h, self._stream()), 'cw_synchronize')
 
-    def reset(self):
-        L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')
+    def reset_async(self):
+        L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')     # enqueues; nothing waits
         self._has_reset = True
+        self._reset_pending = True
+
+    def reset_wait(self):
+        if not getattr(self, '_reset_pending', False):
+            raise RuntimeError('reset_wait without reset_async')
+        self._reset_pending = False
         if self.host_outputs:
             self._sync()
         return self._observation()
+
+    def reset(self):
+        self.reset_async()
+        return self.reset_wait()
 
     def step_async(self, actions):
         if self.host_outputs and not (torch.is_tensor(actions) and actions.is_cuda):
@@ -401,28 +434,23 @@ class CraftingWorldVecEnv:
 
     # ------------------------------------------------------------------ checkpoint / resume
     def save_checkpoint(self, path):
-        """Everything the env batch needs to continue bit-identically -- state, episode records (goal state, start
-        state), RNG streams -- as one .npz (host copy; synchronises)."""
-        keys, pos = self.get_rng_states()
-        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list),
-                    fixed_init_state=self.fixed_init_state)
-        np.savez_compressed(path, rng_keys=keys, rng_pos=pos, counters=self.counters.cpu().numpy(),
-                            meta=np.frombuffer(repr(sorted(meta.items())).encode(), dtype=np.uint8), **self.get_state())
+        """Everything the env batch needs to continue bit-identically, as one file written exactly at `path`: the engine's
+        raw records (current state, the episode's goal and start states, RNG streams, fixed_init_state pools, the last
+        step's outputs, counters) behind a header that pins the configuration (cw_checkpoint_save; synchronises)."""
+        n = int(self._lib.cw_checkpoint_bytes(self._h))
+        buf = np.empty(n, dtype=np.uint8)
+        L.check(self._lib.cw_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_save')
+        with open(path, 'wb') as f:
+            buf.tofile(f)
 
     def load_checkpoint(self, path):
-        """Restore a save_checkpoint() file into an engine built with the same configuration (task menus are part
-        of the configuration, not of the checkpoint; so are fixed_init_state pools: build the engine with the seed the
-        original was built with and they are the same).  The step/episode counters of this engine keep counting on."""
-        z = np.load(path)
-        meta = dict(num_envs=self.num_envs, size=self.size, max_steps=self.MAX_STEPS, n_task_list=len(self.task_list),
-                    fixed_init_state=self.fixed_init_state)
-        if bytes(z['meta']).decode() != repr(sorted(meta.items())):
-            raise ValueError('checkpoint was written by a different configuration: %s' % bytes(z['meta']).decode())
-        if not getattr(self, '_has_reset', False):
-            self.reset()                                        # set_state needs an initialised engine
-        self.set_rng_states(z['rng_keys'], z['rng_pos'])
-        self.set_state(**{k: z[k] for k in ('grid', 'init_grid', 'goal_grid', 'agent_rc', 'init_agent_rc', 'goal_agent_rc',
-                                            'hold', 'achieved', 'desired', 'step_num', 'ep_no')})
+        """Restore a save_checkpoint() file into an engine built with the same configuration (num_envs, size, max_steps,
+        task_list, fixed_init_state and task menus are verified: ValueError otherwise).  Records are restored verbatim, so
+        the state-mode observation tensors (hdr, slot_pos) equal the uninterrupted run's too; frames are repainted.  Per-env
+        menu ids, reward rules, pools and counters come from the file."""
+        buf = np.fromfile(path, dtype=np.uint8)
+        L.check(self._lib.cw_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.size), 'cw_checkpoint_load')
+        self._has_reset = True
 
     def profile_begin(self, max_steps):
         """Bracket each kernel of the following step() calls with HIP events on the launch stream."""

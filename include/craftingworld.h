@@ -141,14 +141,14 @@ int cw_destroy(cw_engine *e);
 /* --- RNG: replaces seed() (ray.py:145-147) ----------------------------------------------------
  * cw_seed_mt injects numpy RandomState states: keys[N][624], pos[N] (RandomState.get_state()[1:3]).
  * cw_seed_int seeds env i like numpy RandomState(seeds[i]) (init_genrand).  Both are synchronous
- * host calls.  cw_get_mt returns states a numpy RandomState accepts via set_state and that
+ * host calls; the conversion itself runs on the device, one lane per env.  cw_get_mt returns states a numpy RandomState accepts via set_state and that
  * continue the identical stream. */
 int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos);
 int cw_seed_int(cw_engine *e, const uint32_t *seeds);
 int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos);
 
 /* generate_fixed_states (ray.py:149-154): draw fixed_init_state placements per env from the
- * env's current RNG stream.  No-op when fixed_init_state == 0. */
+ * env's current RNG stream.  No-op when fixed_init_state == 0.  Returns after the pool is complete (one-time cost). */
 int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream);
 
 /* --- reset() for every env (ray.py:156-218): task draw, placement, imagine_obs, render ------ */
@@ -189,6 +189,17 @@ int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t strea
 /* --- state injection / checkpoint (synchronous; SURVEY §5 "checkpoint / resume") ------------ */
 int cw_get_state(cw_engine *e, cw_state_view *host);
 int cw_set_state(cw_engine *e, const cw_state_view *host);
+
+/* --- checkpoint / resume of the whole batch as one opaque host blob (the reference has none: its de-facto
+ * state is the attribute set of ray.py:119-141).  The blob holds the engine's raw records -- current state, the
+ * episode's goal and start states, every env's RNG stream, the fixed_init_state pool, the last step's outputs, the
+ * counters -- and is restored verbatim, so a resumed engine continues bit-identically, state tensors included.
+ * cw_checkpoint_load needs an engine created with the same num_envs, size, max_steps, len(task_list),
+ * fixed_init_state and task menus (verified; CW_ERR_INVALID otherwise); it repaints the frames in the pixel modes and
+ * needs no cw_reset first.  Synchronous host calls. */
+size_t cw_checkpoint_bytes(cw_engine *e);
+int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity);
+int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length);
 
 /* --- per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg) -----
  * cw_profile_begin: from now on cw_step brackets each of its kernels with hipEventRecord on the

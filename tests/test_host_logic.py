@@ -22,7 +22,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     hdr = open(os.path.join(ROOT, 'include', 'craftingworld.h')).read()
-    declared = set(re.findall(r'^\s*(?:const\s+)?(?:int|char\s*\*|const char \*)\s*\*?\s*(cw_[a-z_0-9]+)\s*\(', hdr, re.M))
+    declared = set(re.findall(r'^\s*(?:const\s+)?(?:int|size_t|char\s*\*|const char \*)\s*\*?\s*(cw_[a-z_0-9]+)\s*\(', hdr, re.M))
     assert len(declared) >= 16, declared
     from gym_craftingworld_amd import _lib
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
@@ -197,7 +197,44 @@ def test_bench_cpu_baseline_leg_reports_port_and_calibration():
     spec.loader.exec_module(bench)
     out = bench.cpu_baseline(5, 20, seconds=0.2)
     assert out['kind'] == 'port' and out['unit'] == 'env-steps/s' and out['cores'] >= 1 and out['value'] > 0
-    assert 'envs x' in out['sample'] and out['full_frame_value'] > 0
+    assert 'envs x' in out['sample'] and out['dirty_cell_value'] > 0
+    assert 'whole frame' in out['like_for_like']           # `value` is like for like with the GPU headline
     c = out['calibration']
     assert c is not None and 20 < c['port_over_reference_1core'] < 2000
-    assert abs(c['reference_equivalent_of_value'] * c['port_over_reference_1core'] - out['value']) < 1e-6 * out['value']
+    assert abs(c['reference_equivalent_env_steps_per_s'] * c['port_over_reference_1core'] - out['dirty_cell_value']) < 1e-6 * out['dirty_cell_value']
+
+
+def test_vector_env_surface_matches_gym_vector():
+    """SURVEY 8b "interface": the gym.vector.VectorEnv surface of the batch class -- attribute and method names with the
+    argument lists gym.vector (<= 0.21) gives them -- checked without constructing an engine (no GPU here)."""
+    import inspect
+    from gym_craftingworld_amd import CraftingWorldVecEnv as V
+    sig = lambda f: list(inspect.signature(f).parameters)  # noqa: E731
+    assert V.is_vector_env is True and V.viewer is None
+    assert sig(V.seed) == ['self', 'seed']                       # seed(seeds=None): int | list | None
+    assert sig(V.reset_async) == ['self'] and sig(V.reset_wait) == ['self'] and sig(V.reset) == ['self']
+    assert sig(V.step_async) == ['self', 'actions'] and sig(V.step_wait) == ['self'] and sig(V.step) == ['self', 'actions']
+    assert sig(V.close_extras) == ['self', 'kwargs'] and sig(V.close) == ['self', 'kwargs']
+    assert isinstance(V.closed, property) and isinstance(V.unwrapped, property)
+    ctor = sig(V.__init__)
+    for kw in ('num_envs', 'size', 'fixed_init_state', 'max_steps', 'store_gif', 'render_save_rate', 'task_list',
+               'selected_tasks', 'number_of_tasks', 'stacking', 'reward_style'):      # ray.py:59-60 + num_envs
+        assert kw in ctor, kw
+    src = inspect.getsource(V.__init__)
+    for attr in ('self.num_envs', 'self.single_observation_space', 'self.single_action_space', 'self.observation_space',
+                 'self.action_space'):
+        assert attr in src, attr
+    v = object.__new__(V)                                        # no engine: closed, and close() is a no-op
+    assert v.closed is True
+    v.close()
+
+
+def test_batch_space_adds_a_leading_axis():
+    from gym_craftingworld_amd.spaces import Box, Dict, Discrete, batch_space
+    single = Dict({'observation': Box(0, 255, (84, 84, 3), np.uint8), 'hdr': Box(0, 255, (16,), np.uint8),
+                   'slot_pos': Box(-2, 32767, (8,), np.int16)})
+    b = batch_space(single, 7)
+    assert b['observation'].shape == (7, 84, 84, 3) and b['observation'].dtype == np.uint8
+    assert b['hdr'].shape == (7, 16) and b['slot_pos'].shape == (7, 8) and b['slot_pos'].dtype == np.int16
+    assert int(b['slot_pos'].low.min()) == -2 and int(b['slot_pos'].high.max()) == 32767 and int(b['observation'].high.max()) == 255
+    assert batch_space(Discrete(6), 5).nvec.tolist() == [6] * 5

@@ -1,0 +1,97 @@
+"""bench.py's plain `--gpus N` start: the parent spawns N fresh ranks before anything touches HIP (launch.py).
+CPU only: the children here are tiny Python programs (and, once, bench.py itself failing for want of a GPU)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gym_craftingworld_amd import launch  # noqa: E402
+
+
+def test_rank_environments_match_torchrun_conventions():
+    envs = launch.rank_environments(4, base_env={'PATH': '/bin', 'WORLD_SIZE': 'stale'}, port=29511)
+    assert [e['RANK'] for e in envs] == ['0', '1', '2', '3']
+    assert [e['LOCAL_RANK'] for e in envs] == ['0', '1', '2', '3']
+    assert all(e['WORLD_SIZE'] == '4' and e['LOCAL_WORLD_SIZE'] == '4' for e in envs)
+    assert all(e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '29511' for e in envs)
+    assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and e['PATH'] == '/bin' for e in envs)
+    # a base env that already carries the IPC setting keeps its own
+    assert launch.rank_environments(1, base_env={'HSA_ENABLE_IPC_MODE_LEGACY': '1'}, port=1)[0]['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'
+    with pytest.raises(ValueError):
+        launch.rank_environments(0)
+    # one free port for all ranks of a launch, a real one
+    envs = launch.rank_environments(2, base_env={})
+    assert envs[0]['MASTER_PORT'] == envs[1]['MASTER_PORT'] and 1024 < int(envs[0]['MASTER_PORT']) < 65536
+
+
+def test_needs_self_launch():
+    assert launch.needs_self_launch(2, environ={})
+    assert launch.needs_self_launch(8, environ={'RANK': '0'})
+    assert not launch.needs_self_launch(1, environ={})
+    assert not launch.needs_self_launch(2, environ={'WORLD_SIZE': '2'})      # torch.distributed.run set the ranks up
+
+
+def _script(tmp_path, body):
+    p = tmp_path / 'child.py'
+    p.write_text(textwrap.dedent(body))
+    return [sys.executable, str(p)]
+
+
+def test_spawn_relays_rank0_stdout_only_and_waits_for_all(tmp_path):
+    argv = _script(tmp_path, '''
+        import json, os, time
+        r = int(os.environ['RANK'])
+        time.sleep(0.2 * r)
+        open(os.path.join(os.path.dirname(__file__), 'rank%d.json' % r), 'w').write(json.dumps(
+            {k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))
+        print('line from rank %d' % r)
+    ''')
+    with open(tmp_path / 'out.txt', 'w') as f:
+        rc = launch.spawn_ranks(argv, 3, stdout=f)
+    assert rc == 0
+    assert (tmp_path / 'out.txt').read_text() == 'line from rank 0\n'
+    seen = [json.loads((tmp_path / ('rank%d.json' % r)).read_text()) for r in range(3)]
+    assert [s['RANK'] for s in seen] == ['0', '1', '2'] and all(s['WORLD_SIZE'] == '3' for s in seen)
+    assert len({s['MASTER_PORT'] for s in seen}) == 1
+
+
+def test_spawn_returns_failing_rank_code_and_stops_the_others(tmp_path):
+    argv = _script(tmp_path, '''
+        import os, sys, time
+        if os.environ['RANK'] == '1':
+            sys.exit(7)
+        time.sleep(60)
+    ''')
+    t0 = time.monotonic()
+    rc = launch.spawn_ranks(argv, 2, stdout=subprocess.DEVNULL)
+    assert rc == 7
+    assert time.monotonic() - t0 < 30          # rank 0 was not waited for: it was terminated
+
+
+def test_spawn_timeout(tmp_path):
+    argv = _script(tmp_path, 'import time; time.sleep(60)\n')
+    t0 = time.monotonic()
+    assert launch.spawn_ranks(argv, 2, timeout=1.0, stdout=subprocess.DEVNULL) == 124
+    assert time.monotonic() - t0 < 30
+
+
+def test_bench_plain_multi_gpu_start_spawns_ranks_instead_of_refusing():
+    """`python bench.py --gpus 2` (no torchrun): in this GPU-less container the child ranks must be the ones that stop
+    (no GPU for them), not the parent with "needs torch.distributed.run" as in round 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--dist-backend', 'gloo'], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['n_gpus'] == 2
+    else:
+        assert p.returncode != 0
+        assert 'torch.distributed.run' not in p.stderr
+        assert 'needs GPU' in p.stderr or 'no MI355X' in p.stderr or 'device' in p.stderr.lower()
