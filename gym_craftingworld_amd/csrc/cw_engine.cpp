@@ -24,6 +24,7 @@ hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
+int cwk_render_jobs(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
 
@@ -198,6 +199,65 @@ static void prof_free(cw_engine *e)
     e->prof_cap = e->prof_n = 0;
 }
 
+// Pace of the linear-sweep render (cw_kernels.hip: render_groups): idle clocks per pair of jobs.  The write path is less
+// efficient saturated than kept just short of saturation, and where that point lies depends on the box (memory clocks, the
+// XCDs' relative speed) and on the shape (job size, batch): so it is measured here, on the engine's own buffers -- the median of
+// a few launches per candidate, 0..12 sleeps of 64 clocks -- and only performance depends on the outcome.
+static int calibrate_render_pace(cw_engine *e, bool refine)
+{
+    CwTuning &tn = e->tune;
+    const char *forced = getenv("CW_TUNE_RENDER_PACE");
+    if (forced) { tn.render_pace = atoi(forced) < 0 ? 0 : atoi(forced); return CW_OK; }      // (256 + n: with the sleep inside each job)
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || !tn.render_linear || e->P.grp_rows == 0 || e->P.raster != CW_RASTER_RAY)
+        return CW_OK;
+    if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return fail(CW_ERR_HIP, "cw_create: event creation failed");
+    int blocks = 0, wpb = 0, rc = CW_OK;
+    auto median_ms = [&](int pace, double *out) -> int {
+        const int saved = tn.render_pace;
+        tn.render_pace = pace;
+        float ms[5];
+        for (int rep = 0; rep < 6; rep++) {                                      // first launch discarded
+            if (hipEventRecord(ev0, nullptr) != hipSuccess ||
+                cwk_launch_render_calib(&e->P, &tn, nullptr, tn.render_q_all, tn.render_fast_parity, &blocks, &wpb) != hipSuccess ||
+                hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
+                (rep > 0 && hipEventElapsedTime(&ms[rep - 1], ev0, ev1) != hipSuccess)) {
+                tn.render_pace = saved;
+                return fail(CW_ERR_HIP, "cw_create: render pace calibration failed");
+            }
+        }
+        tn.render_pace = saved;
+        for (int i = 1; i < 5; i++) for (int j = i; j > 0 && ms[j] < ms[j - 1]; j--) { const float t = ms[j]; ms[j] = ms[j - 1]; ms[j - 1] = t; }
+        *out = ms[2];
+        return CW_OK;
+    };
+    int best = tn.render_pace;
+    double best_ms = 0, t = 0;
+    char log[400] = "";
+    size_t len = 0;
+    auto try_pace = [&](int pace) {
+        rc = median_ms(pace, &t);
+        if (rc == CW_OK && (best_ms == 0 || t < best_ms)) { best_ms = t; best = pace; }
+        if (len < sizeof(log) - 24) len += (size_t)snprintf(log + len, sizeof(log) - len, " %s%d:%.4f", (pace & 0x100) ? "m+" : "", pace & 0xFF, t);
+    };
+    if (!refine) {
+        static const int cand[] = {0x100, 0x101, 0x102, 0x103, 0x104, 0, 1, 2, 3, 4, 6};
+        for (size_t i = 0; i < sizeof(cand) / sizeof(cand[0]) && rc == CW_OK; i++) try_pace(cand[i]);
+    } else {                                                                    // after the shares are known: the neighbours once more
+        const int mid = tn.render_pace & 0x100, p0 = tn.render_pace & 0xFF;
+        for (int pp = (p0 > 0 ? p0 - 1 : 0); pp <= p0 + 1 && rc == CW_OK; pp++) try_pace(mid | pp);
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc != CW_OK) return rc;
+    tn.render_pace = best;
+    if (getenv("CW_TUNE_VERBOSE"))
+        fprintf(stderr, "[craftingworld] render pace%s: ms per launch by sleeps per pair of jobs (m+: and one inside each job)%s -> %s%d\n",
+                refine ? " (with shares)" : "", log, (best & 0x100) ? "m+" : "", best & 0xFF);
+    return CW_OK;
+}
+
 // XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
 // than their neighbours' (workgroups go round-robin over the 8 XCDs, so it shows as even vs odd workgroup index), and a
 // launch lasts as long as its slowest wave.  Measure it instead of assuming it: a few equal-share launches with the waves'
@@ -233,6 +293,7 @@ static int calibrate_render_shares(cw_engine *e)
         }
         return CW_OK;
     };
+    const int jobs = cwk_render_jobs(&e->P, &tn);              // frames, or (frame, row group) pairs of the linear sweep
     double busy[2], busy0[2];
     rc = measure(0, -1, busy0);                                  // equal shares
     int q_all = 0, fast = -1;
@@ -245,16 +306,16 @@ static int calibrate_render_shares(cw_engine *e)
             // the classes share the memory system, so shifting frames changes both costs: refine on what is measured
             for (int it = 0; it < 3 && rc == CW_OK; it++) {
                 if (rho > 1.6) rho = 1.6;
-                q_all = (int)((double)e->n / ((double)n_half * (1.0 + rho)));
+                q_all = (int)((double)jobs / ((double)n_half * (1.0 + rho)));
                 if (q_all < 1) { q_all = 0; break; }
                 rc = measure(q_all, fast, busy);
                 if (rc != CW_OK || busy[0] <= 0 || busy[1] <= 0) break;
-                const double q_fast = ((double)e->n - (double)q_all * (double)n_half) / (double)n_half;
+                const double q_fast = ((double)jobs - (double)q_all * (double)n_half) / (double)n_half;
                 const double per_frame_slow = busy[1 - fast] / (double)q_all, per_frame_fast = busy[fast] / q_fast;
                 rho = per_frame_slow / per_frame_fast;
                 if (rho < 1.0) rho = 1.0;
             }
-            if (q_all >= 1) q_all = (int)((double)e->n / ((double)n_half * (1.0 + (rho > 1.6 ? 1.6 : rho))));
+            if (q_all >= 1) q_all = (int)((double)jobs / ((double)n_half * (1.0 + (rho > 1.6 ? 1.6 : rho))));
         }
     }
     e->P.render_stats = nullptr;
@@ -266,7 +327,7 @@ static int calibrate_render_shares(cw_engine *e)
     busy[0] = busy0[0];
     busy[1] = busy0[1];
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] render shares: waves of even/odd workgroups busy %.1f / %.1f us on equal shares -> %d frames per slow wave, "
+        fprintf(stderr, "[craftingworld] render shares: waves of even/odd workgroups busy %.1f / %.1f us on equal shares -> %d jobs per slow wave, "
                 "%s workgroups take the rest\n", busy[0] / 3.0 / (double)(n_waves / 2) / 100.0, busy[1] / 3.0 / (double)(n_waves / 2) / 100.0,
                 q_all, fast ? "odd" : "even");
     return CW_OK;
@@ -347,6 +408,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
     P.raster = cfg->raster;
     P.frame_bytes = cfg->raster == CW_RASTER_ALT ? 27u * (uint32_t)e->S * (uint32_t)(e->S + 1) : 48u * (uint32_t)e->ncell;
+    P.grp_rows = e->S <= 64 ? 64 / e->S : 0;
+    P.grp_per_frame = P.grp_rows ? (e->S + P.grp_rows - 1) / P.grp_rows : 0;
     {   // experiment knobs; the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
@@ -362,6 +425,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.overlap = geti("CW_TUNE_OVERLAP", tn.overlap);
         tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
+        tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
         if (tn.list_blocks < 1) tn.list_blocks = 1;
     }
@@ -434,7 +498,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
+    if (rc == CW_OK) rc = calibrate_render_pace(e, false);
     if (rc == CW_OK) rc = calibrate_render_shares(e);
+    if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
     if (rc != CW_OK) {
         cw_destroy(e);
         *out = nullptr;

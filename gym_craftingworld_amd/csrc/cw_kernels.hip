@@ -1116,8 +1116,128 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
-// the per-step full-frame render (mode 3) and cw_render (mode 2): the roofline kernel
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
+// ---- the same frames as ONE LINEAR SWEEP of the frame array (the default for the per-step render) ------------------
+// In the [N][4S][4S][3] layout a GRID row is 4 pixel rows = 48*S contiguous bytes, so a run of whole grid rows is a
+// contiguous byte range.  Job = (frame, group): the frame's next grp_rows = floor(64/S) grid rows (<= 64 cells, lane =
+// cell; 21x21: 3 rows = 63 cells = 3024 B, 7 groups per frame).  Job ids are laid out in ADDRESS order and handed out
+// round-robin -- wave w paints jobs w, w + n_waves, ... -- so at any moment the launch's ~1024 waves write ONE
+// contiguous ~3-MB window that slides through the frame array, the shape of a plain fill, instead of 1024 separate
+// 21-KB-stride streams.  A wave needs a new env record per JOB (7x the record fetches of frame-per-wave; still ~1 % of
+// the traffic): the records of a wave's next 64 jobs are fetched one per lane, a BATCH AHEAD (the loads queue behind
+// stores already in flight and have 64 jobs' time to return, so a batch boundary waits for the wave's last few
+// stores, not for a load round trip under the write storm), and handed out with v_readlane.
+//
+// PACING.  The kernel is bound by the memory system's write path, and that path is LESS efficient when saturated than
+// when kept just short of it: with every wave pushing stores as fast as it can the launch takes 0.254 ms, with 128 idle
+// clocks per pair of jobs 0.241 ms, with 256 it is slower again (profiles/r02_render_linear.txt; the same holds for every
+// store shape tried, 16-B-per-lane stores staged through LDS included, each with its own optimum).  WHERE the idle clocks
+// sit matters too: 64 clocks between a job's second and third store beat the same clocks between jobs by 2.5 %
+// (0.2407 vs 0.2471 ms) -- the smoother the stream of stores, the better.  So a wave sleeps 64 clocks in the middle of
+// a job's stores (`pace` bit 8) and `pace & 0xFF` x 64 clocks per pair of jobs; cw_create finds both on the box it runs on,
+// as it does the XCD shares.
+template <int MODE>
+__device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wpb = blockDim.x / CW_WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * wpb + wave_in_block;
+    const int n_waves = gridDim.x * wpb;
+    const int S = P.size, gr = P.grp_rows, G = P.grp_per_frame;
+    const int n_jobs = P.n_envs * G;                                         // (the launcher checked that this fits)
+    if (wave >= n_jobs) return;
+    const bool want_done = (MODE == 3) && skip_done;
+    const bool classes = fast_parity >= 0;
+    if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
+    const int n_fast = (gridDim.x / 2) * wpb;
+    const bool fast = classes && (int)(blockIdx.x & 1u) == fast_parity;
+    const int fast_rank = (int)(blockIdx.x >> 1) * wpb + wave_in_block;
+    const int tail0 = q_all * n_waves;
+    const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
+    // lane -> cell of the group, once
+    const uint32_t row_bytes = 12u * S;
+    const uint32_t r_local = __umulhi((uint32_t)lane, P.div_magic);
+    const uint32_t c_local = (uint32_t)lane - r_local * S;
+    const bool lane_in_group = lane < gr * S;
+    const uint32_t v_off = 4u * r_local * row_bytes + 12u * c_local;
+    const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
+    uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
+    const int pace_pair = pace & 0xFF;                                       // sleeps of 64 clocks per pair of jobs
+    const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
+    CW_WAVE_CLOCK(t_start);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
+    struct Rec { int env, g; uint32_t hx, hw, done; uint4 p; };
+    auto fetch = [&](int base) {
+        Rec r;
+        const int i = base + lane;
+        const int id = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
+        r.env = -1; r.g = 0; r.hx = 0; r.hw = 0; r.done = 0;
+        r.p = make_uint4(0, 0, 0, 0);
+        if (i < q_mine && id < n_jobs) {
+            r.env = id / G;
+            r.g = id - r.env * G;
+            const uint32_t *h = (const uint32_t *)(P.hdr + r.env);
+            r.hx = h[0];
+            r.hw = h[3];
+            r.p = P.pos[r.env];
+            if (want_done) r.done = P.done[r.env];     // (envs that finished are left to the resetting wave on the side stream)
+        }
+        return r;
+    };
+    Rec nxt = fetch(0);
+    for (int base = 0; base < q_mine; base += CW_WAVE) {
+        const Rec cur = nxt;
+        if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
+        const int in_batch = min(q_mine - base, CW_WAVE);
+        for (int k = 0; k < in_batch; k++) {
+            if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
+            const int env = __builtin_amdgcn_readlane(cur.env, k);
+            if (env < 0) continue;
+            if (want_done && __builtin_amdgcn_readlane(cur.done, k)) continue;
+            const uint32_t g = __builtin_amdgcn_readlane(cur.g, k);
+            const uint32_t hx = __builtin_amdgcn_readlane(cur.hx, k), codes = __builtin_amdgcn_readlane(cur.hw, k);
+            u32x4s pp;
+            pp.x = __builtin_amdgcn_readlane(cur.p.x, k);
+            pp.y = __builtin_amdgcn_readlane(cur.p.y, k);
+            pp.z = __builtin_amdgcn_readlane(cur.p.z, k);
+            pp.w = __builtin_amdgcn_readlane(cur.p.w, k);
+            uint32_t sp[8];
+            unpack_pos_s(pp, sp);
+            const uint32_t row0 = g * gr;
+            const uint32_t cell = row0 * S + (uint32_t)lane;
+            uint32_t code = 0;                                               // the lane's cell: slot code by 8 compares ...
+#pragma unroll
+            for (int q = 0; q < 8; q++) code = (cell == sp[q]) ? ((codes >> (4 * q)) & 15u) : code;
+            const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);   // ... colour from the table register
+            const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+            const uint32_t hold = (hx >> 16) & 0xFFu;
+            const uint32_t hold_rgb = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;
+            const u32x3 d = cell_row_dwords(col);
+            const bool ag = (cell == agent_cell);
+            const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
+            const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
+            if (lane_in_group && row0 + r_local < (uint32_t)S) {
+                uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes + v_off;
+                *(u32x3_a4 *)(q) = d;
+                *(u32x3_a4 *)(q + row_bytes) = d1;
+                if (pace_mid) __builtin_amdgcn_s_sleep(1);                // (see PACING above)
+                *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
+                *(u32x3_a4 *)(q + 3 * row_bytes) = d;
+            }
+        }
+    }
+    CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
+}
+
+// the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
+{
+    if (mode == 3) render_groups<3>(P, skip_done, ext_out, q_all, fast_parity, pace);
+    else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace);
+}
+// the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
+__global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
 {
     if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity);
     else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity);
@@ -1208,6 +1328,14 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------ launchers
+// linear sweep only where the geometry allows it: Ray raster, S <= 64, job ids fit an int
+static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
+{
+    return tn.render_linear && P.raster == 0 && P.grp_rows > 0 && (long long)P.n_envs * P.grp_per_frame < (1ll << 30);
+}
+static inline int cw_render_grid(const CwTuning &tn, int jobs);
+static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
+                                    int fast_parity, hipStream_t st);
 static inline int cw_render_grid(const CwTuning &tn, int jobs)
 {
     // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
@@ -1220,6 +1348,14 @@ static inline int cw_render_grid(const CwTuning &tn, int jobs)
     if (tn.render_blocks_abs > 0 && blocks > tn.render_blocks_abs) blocks = tn.render_blocks_abs;
     if (blocks < 1) blocks = 1;
     return blocks;
+}
+
+static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
+                                    int fast_parity, hipStream_t st)
+{
+    const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
+    if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
+    else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity);
 }
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
@@ -1276,8 +1412,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         if (ev && tn.profile_side) (void)hipEventRecord(ev[3], side);
         (void)hipEventRecord(ev_join, side);
         if (ev) (void)hipEventRecord(ev[4], st);
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 1, (uint8_t *)nullptr,
-                           tn.render_q_all, tn.render_fast_parity);
+        cw_launch_render(*P, tn, 3, 1, nullptr, tn.render_q_all, tn.render_fast_parity, st);
         if (ev) (void)hipEventRecord(ev[5], st);
         (void)hipStreamWaitEvent(st, ev_join, 0);
         return hipGetLastError();
@@ -1288,8 +1423,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, 1, 0, pixels ? 1 : 0);
     if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
     if (obs_mode == 1)   // no overlap: the reset is complete; finished envs are painted twice (rare path, tuning only)
-        hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, n)), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr,
-                           tn.render_q_all, tn.render_fast_parity);
+        cw_launch_render(*P, tn, 3, 0, nullptr, tn.render_q_all, tn.render_fast_parity, st);
     if (ev) (void)hipEventRecord(ev[5], st);
     return hipGetLastError();
 }
@@ -1340,15 +1474,16 @@ hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStre
     const CwTuning &tn = *T;
     *blocks = cw_render_grid(tn, P->n_envs);
     *waves_per_block = tn.render_threads / CW_WAVE;
-    hipLaunchKernelGGL(cw_render_kernel, dim3(*blocks), dim3(tn.render_threads), 0, st, *P, 3, 0, (uint8_t *)nullptr, q_all, fast_parity);
+    cw_launch_render(*P, tn, 3, 0, nullptr, q_all, fast_parity, st);
     return hipGetLastError();
 }
+
+int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
     const CwTuning &tn = *T;
-    hipLaunchKernelGGL(cw_render_kernel, dim3(cw_render_grid(tn, P->n_envs)), dim3(tn.render_threads), 0, st, *P, 2, 0, out,
-                       tn.render_q_all, tn.render_fast_parity);
+    cw_launch_render(*P, tn, 2, 0, out, tn.render_q_all, tn.render_fast_parity, st);
     return hipGetLastError();
 }
 

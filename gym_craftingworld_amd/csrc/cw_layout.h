@@ -51,6 +51,9 @@ struct CwTuning {
     int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
+    int render_linear = 1;          // full-frame render as ONE linear sweep: job = a run of whole grid rows (<= 64 cells, contiguous bytes)
+    int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job;
+                                    //   cw_create calibrates it (cw_kernels.hip: PACING)
 };
 
 // Everything the kernels need, passed by value.
@@ -96,4 +99,6 @@ struct CwParams {
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
     int32_t tune_reset_prio; // 1: reset waves raise their priority (s_setprio 3)
+    int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
+    int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)
 };

@@ -175,6 +175,7 @@ class OracleEnv:
         return dict(grid=self._arr(v.grid, (s, s)).copy(), init_grid=self._arr(v.init_grid, (s, s)).copy(),
                     goal_grid=self._arr(v.goal_grid, (s, s)).copy(),
                     agent=(v.agent_r, v.agent_c), hold=v.hold, goal_agent=(v.goal_agent_r, v.goal_agent_c),
+                    init_agent=(v.init_agent_r, v.init_agent_c),
                     achieved=v.achieved, desired=v.desired, step_num=v.step_num, ep_no=v.ep_no,
                     obs=self._arr(v.obs, ish).copy(),
                     desired_img=self._arr(v.desired_img, ish).copy(),

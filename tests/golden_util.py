@@ -24,3 +24,16 @@ def load(name):
 
 def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def one_hot(grid, agent, hold=0):
+    """(S,S) cell codes + agent (r,c) + hold -> the reference's (S,S,12) one-hot state (ray.py:94-98: channels 0-7
+    objects, 8 agent, 9-11 the held sticks/axe/hammer at the agent's cell) as uint8."""
+    g = np.asarray(grid)
+    oh = np.zeros(g.shape + (12,), dtype=np.uint8)
+    r, c = np.nonzero(g)
+    oh[r, c, g[r, c] - 1] = 1
+    oh[agent[0], agent[1], 8] = 1
+    if hold:
+        oh[agent[0], agent[1], 8 + int(hold)] = 1
+    return oh

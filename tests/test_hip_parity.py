@@ -45,6 +45,15 @@ def test_golden_fixture_replay(name, obs_mode):
         L.check(env._lib.cw_generate_fixed_states(env._h, env._stream()), 'pool')
     size = kw['size'][0]
     ri = 0
+    # fixtures captured from CraftingWorldEnvOneHot hold what THAT class returns: (S,S,12) one-hot states
+    # (carftingworld_onehot.py:203,310,369-371) -- the engine's one-hot views of the current / goal / reset states
+    onehot = meta['env'] == 'CraftingWorldEnvOneHot'
+
+    def view(obs, key):
+        if onehot:
+            which = {'observation': 'current', 'desired_goal': 'goal', 'init_observation': 'init'}[key]
+            return env.one_hot(which=which)[0].cpu().numpy()
+        return obs[key][0].cpu().numpy()
 
     def check_reset(obs, t):
         nonlocal ri
@@ -52,13 +61,15 @@ def test_golden_fixture_replay(name, obs_mode):
         assert st['desired'][0] == g['r_desired'][ri], (name, 'desired', ri)
         assert np.array_equal(st['grid'][0], g['r_grid'][ri]), (name, 'reset grid', ri)
         assert tuple(st['agent_rc'][0]) == tuple(g['r_agent'][ri])
-        assert crc(obs['observation'][0].cpu().numpy()) == g['r_obs_crc'][ri], (name, 'reset obs', ri)
-        assert crc(obs['desired_goal'][0].cpu().numpy()) == g['r_desired_img_crc'][ri], (name, 'desired img', ri)
-        assert crc(obs['init_observation'][0].cpu().numpy()) == g['r_init_img_crc'][ri]
+        assert crc(view(obs, 'observation')) == g['r_obs_crc'][ri], (name, 'reset obs', ri)
+        assert crc(view(obs, 'desired_goal')) == g['r_desired_img_crc'][ri], (name, 'desired img', ri)
+        assert crc(view(obs, 'init_observation')) == g['r_init_img_crc'][ri]
         assert g['r_at_step'][ri] == t
         assert st['ep_no'][0] == g['r_ep_no'][ri]
+        if onehot:
+            assert np.array_equal(st['goal_grid'][0], g['r_goal_grid'][ri]) and tuple(st['goal_agent_rc'][0]) == tuple(g['r_goal_agent'][ri])
         if ri < len(g['img_desired']):
-            assert np.array_equal(obs['desired_goal'][0].cpu().numpy(), g['img_desired'][ri])
+            assert np.array_equal(view(obs, 'desired_goal'), g['img_desired'][ri])
         ri += 1
 
     obs = env.reset()
@@ -80,10 +91,10 @@ def test_golden_fixture_replay(name, obs_mode):
             assert tuple(f['agent'][0]) == tuple(g['agent'][t]), (name, 'agent', t)
             assert f['hold'][0] == g['hold'][t], (name, 'hold', t)
             assert f['step_num'][0] == g['step_num'][t]
-            assert crc(obs['observation'][0].cpu().numpy()) == g['obs_crc'][t], (name, 'obs', t)
+            assert crc(view(obs, 'observation')) == g['obs_crc'][t], (name, 'obs', t)
             assert crc(env.grid()[0].cpu().numpy()) == g['grid_crc'][t], (name, 'grid', t)
     assert ri == len(g['r_desired'])
-    assert np.array_equal(obs['observation'][0].cpu().numpy(), g['final_obs'])
+    assert np.array_equal(view(obs, 'observation'), g['final_obs'])
     # the MT19937 stream position after the last reset is the reference's
     keys, pos = env.get_rng_states()
     assert pos[0] % 624 == g['r_rng_pos'][-1] % 624
@@ -1429,3 +1440,64 @@ def test_vector_env_surface_on_the_device():
     env.close()
     assert env.closed
     env.close()                                           # idempotent
+
+
+@pytest.mark.parametrize('name', [n for n in fixture_names() if n.startswith(('flat', 'onehot'))])
+def test_flat_and_onehot_facades_replay_their_own_reference_fixtures(name):
+    """SURVEY 8f rank 1, pinned by the reference's own classes: fixtures captured from CraftingWorldEnvFlat
+    (craftingworld_flat.py:40-43,57,119,185) and CraftingWorldEnvOneHot (carftingworld_onehot.py:84-103,201-203,310,
+    369-371), replayed through the product's classes of the same names built with the SAME ctor kwargs the reference
+    class was given (none for flat8_*: the 8x8 / 100-step defaults).  Everything each class returned is compared:
+    Flat's bare frame after every reset and step; OneHot's one-hot observation / desired_goal (the un-rendered goal
+    state) / init_observation; reward, done, achieved bits, step_num, ep_no, desired bits, RNG stream position."""
+    import gym_craftingworld_amd as cw
+    meta, kw, g = load(name)
+    flat = meta['env'] == 'CraftingWorldEnvFlat'
+    ck = dict(meta['ctor_kwargs'])
+    if 'size' in ck:
+        ck['size'] = tuple(ck['size'])
+    rs = np.random.RandomState()
+    rs.set_state(('MT19937', g['key0'], int(g['pos0']), 0, 0.0))
+    env = (cw.CraftingWorldEnvFlat if flat else cw.CraftingWorldEnvOneHot)(**ck)
+    env.np_random = rs                                   # the reference user's way of pinning a stream
+    if ck.get('fixed_init_state'):                        # the pool is drawn at construction (ray.py:116-118): redo it on that stream
+        from gym_craftingworld_amd import _lib as L
+        L.check(env._vec._lib.cw_generate_fixed_states(env._vec._h, env._vec._stream()), 'pool')
+    assert (env.STATE_W, env.MAX_STEPS) == (kw['size'][0], kw['max_steps'])
+    if flat:
+        assert env.observation_space.shape == (4 * env.STATE_W, 4 * env.STATE_W, 3)
+    else:
+        assert env.observation_space['desired_goal'].shape == (env.STATE_W, env.STATE_W, 12)
+    ri = 0
+
+    def check_reset(o, t):
+        nonlocal ri
+        assert g['r_at_step'][ri] == t
+        if flat:
+            assert o is env.obs_image and o.shape == (4 * env.STATE_W, 4 * env.STATE_W, 3)
+            assert crc(o.astype(np.uint8)) == g['r_obs_crc'][ri], (name, 'reset frame', ri)
+            assert crc(env.desired_goal.astype(np.uint8)) == g['r_desired_img_crc'][ri] and crc(env.INIT_OBS.astype(np.uint8)) == g['r_init_img_crc'][ri]
+        else:
+            assert o['achieved_goal'] is o['observation']
+            assert crc(o['observation'].astype(np.uint8)) == g['r_obs_crc'][ri], (name, 'reset one-hot', ri)
+            assert crc(o['desired_goal'].astype(np.uint8)) == g['r_desired_img_crc'][ri], (name, 'goal state', ri)
+            assert crc(o['init_observation'].astype(np.uint8)) == g['r_init_img_crc'][ri]
+            if ri < len(g['img_desired']):
+                assert np.array_equal(o['desired_goal'], g['img_desired'][ri]) and np.array_equal(o['observation'], g['img_obs'][ri])
+        bits = sum(int(b) << i for i, b in enumerate(env.desired_goal_vector[0]))
+        assert bits == g['r_desired'][ri] and env.ep_no == g['r_ep_no'][ri]
+        assert env.get_rng_state()[1] % 624 == g['r_rng_pos'][ri] % 624, (name, 'rng position', ri)
+        ri += 1
+
+    check_reset(env.reset(), 0)
+    for t in range(len(g['action'])):
+        o, r, d, info = env.step(int(g['action'][t]))
+        assert r == g['reward'][t] and d == bool(g['done'][t]), (name, t)
+        assert sum(int(b) << i for i, b in enumerate(info['achieved_goal'][0])) == g['achieved'][t], (name, 'achieved', t)
+        assert env.step_num == g['step_num'][t]
+        ob = o if flat else o['observation']
+        assert crc(ob.astype(np.uint8)) == g['obs_crc'][t], (name, 'returned observation', t)
+        if d:
+            check_reset(env.reset(), t + 1)
+    assert ri == len(g['r_desired'])
+    env.close()

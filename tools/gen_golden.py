@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Capture golden vectors from the REFERENCE itself (build container only).
 
-Runs /root/reference's CraftingWorldEnvRay (imported under tools/gym_stub) from injected
+Runs /root/reference's CraftingWorldEnvRay / ...AltObs / ...Flat / ...OneHot (imported under tools/gym_stub) from injected
 numpy RandomState states and writes small .npz fixtures to tests/golden/.  A fixture is data
 only: config kwargs, the initial MT19937 state, the action sequence, and what the reference
 returned / held after every step and every reset.  tests/test_oracle_golden.py replays them
 through the C oracle; tests/test_hip_parity.py (gpu) replays them through the HIP engine.
 
     python tools/gen_golden.py            # regenerate every fixture
+    python tools/gen_golden.py flat8_random onehot5_random   # only these
 """
 import json
 import os
@@ -51,24 +52,57 @@ ALT_SCENARIOS = [
 ]
 
 
+# The other two REGISTERED classes, captured through their own return conventions:
+# CraftingWorldEnvFlat (craftingworld_flat.py: reset()/step() return the bare frame, 8x8 / 100-step defaults, no
+# fixed_init_state kwarg) and CraftingWorldEnvOneHot (carftingworld_onehot.py: every observation is an (S,S,12) one-hot
+# state, desired_goal = imagine_obs' final state un-rendered).  `{}` kwargs = the class's own defaults.
+FLAT_SCENARIOS = [
+    ('flat8_random',      dict(),                                                 808,   4000, 'random',   2),
+    ('flat8_scripted',    dict(),                                                 818,   4000, 'scripted', 1),
+    ('flat5_subset',      dict(size=(5, 5), max_steps=40, reward_style='subset'), 505,   4000, 'random',   1),
+]
+ONEHOT_SCENARIOS = [
+    ('onehot21_scripted', dict(size=(21, 21)),                                    2112,  2000, 'scripted', 1),
+    ('onehot5_random',    dict(size=(5, 5), max_steps=50),                        515,   5000, 'random',   2),
+    ('onehot8_subset',    dict(size=(8, 8), max_steps=80, reward_style='subset',
+                               selected_tasks=['BuildHouse', 'ChopTree', 'MoveSticks', 'EatBread']), 838, 4000, 'scripted', 1),
+    ('onehot6_fixedinit', dict(size=(6, 6), max_steps=40, fixed_init_state=2),    626,   2500, 'random',   1),
+]
+
+
 def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWorldEnvRay'):
     rng = np.random.RandomState(seed)
     st = rng.get_state()
     key0, pos0 = st[1].copy(), int(st[2])
     env = make_ref_env(cls, rng, **kwargs)
+    flat, onehot = env_name == 'CraftingWorldEnvFlat', env_name == 'CraftingWorldEnvOneHot'
+
+    def views(ret):
+        """(observation, desired_goal, init_observation) as the class hands them out"""
+        if flat:
+            assert ret is env.obs_image
+            return ret, env.desired_goal, env.INIT_OBS
+        assert ret['achieved_goal'] is ret['observation']
+        return ret['observation'], ret['desired_goal'], ret['init_observation']
     pol_rng = np.random.RandomState(seed ^ 0x5EED)
     size = env.STATE_W
 
     R = dict(desired=[], grid=[], agent=[], rng_pos=[], rng_crc=[], obs_crc=[], desired_img_crc=[],
-             init_img_crc=[], at_step=[], ep_no=[])
+             init_img_crc=[], at_step=[], ep_no=[], goal_grid=[], goal_agent=[])
     S = dict(action=[], reward=[], done=[], achieved=[], agent=[], hold=[], step_num=[], grid_crc=[],
              obs_crc=[], grid=[])
     imgs_desired, imgs_obs = [], []
 
     def record_reset(t):
-        obs = env.reset()
+        o_obs, o_goal, o_init = views(env.reset())
+        obs = {'observation': o_obs, 'desired_goal': o_goal, 'init_observation': o_init}
         codes, agent, hold = codes_from_onehot(env.obs_one_hot)
         assert hold == 0
+        if onehot:                                    # the goal STATE itself is the observation here
+            g_codes, g_agent, g_hold = codes_from_onehot(o_goal)
+            assert g_hold == 0
+            R['goal_grid'].append(g_codes)
+            R['goal_agent'].append(g_agent)
         R['desired'].append(bits(env.desired_goal_vector))
         R['grid'].append(codes)
         R['agent'].append(agent)
@@ -80,7 +114,6 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
         R['init_img_crc'].append(crc(obs['init_observation'].astype(np.uint8)))
         R['at_step'].append(t)
         R['ep_no'].append(env.ep_no)
-        assert obs['achieved_goal'] is obs['observation']
         if len(imgs_desired) < keep_images:
             imgs_desired.append(obs['desired_goal'].astype(np.uint8))
             imgs_obs.append(obs['observation'].astype(np.uint8))
@@ -92,7 +125,8 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
             a = int(pol_rng.randint(6))
         else:
             a = scripted_action(env, pol_rng)
-        obs, reward, done, info = env.step(a)
+        ret, reward, done, info = env.step(a)
+        obs = {'observation': views(ret)[0]}
         codes, agent, hold = codes_from_onehot(env.obs_one_hot)
         S['action'].append(a)
         S['reward'].append(int(reward))
@@ -110,11 +144,17 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
             record_reset(t + 1)
 
     kw = dict(kwargs)
+    meta = dict(kwargs=kw, seed=seed, steps=steps, policy=policy, n_success=n_success, n_resets=len(R['desired']), env=env_name)
+    if flat or onehot:            # what the ctor was given (maybe nothing: the class defaults) beside the effective values
+        ck = dict(kwargs)
+        if 'size' in ck:
+            ck['size'] = list(ck['size'])
+        meta['ctor_kwargs'] = ck
+        kw.setdefault('size', (env.STATE_W, env.STATE_H))
+        kw.setdefault('max_steps', env.MAX_STEPS)
     kw['size'] = list(kw['size'])
     out = dict(
-        meta=np.frombuffer(json.dumps(dict(kwargs=kw, seed=seed, steps=steps, policy=policy,
-                                           n_success=n_success, n_resets=len(R['desired']),
-                                           env=env_name)).encode(), dtype=np.uint8),
+        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
         key0=key0.astype(np.uint32), pos0=np.int32(pos0),
         action=np.array(S['action'], np.int8), reward=np.array(S['reward'], np.int32),
         done=np.array(S['done'], np.uint8), achieved=np.array(S['achieved'], np.uint16),
@@ -132,13 +172,19 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
     )
     if size <= 8:
         out['grid'] = np.array(S['grid'], np.uint8)
+    if onehot:
+        out['r_goal_grid'] = np.array(R['goal_grid'], np.uint8)
+        out['r_goal_agent'] = np.array(R['goal_agent'], np.uint8)
     return out, n_success
 
 
 def main():
     classes = import_reference()
     os.makedirs(OUT, exist_ok=True)
-    todo = [(sc, 'ray', 'CraftingWorldEnvRay') for sc in SCENARIOS] + [(sc, 'altobs', 'CraftingWorldEnvAltObs') for sc in ALT_SCENARIOS]
+    todo = ([(sc, 'ray', 'CraftingWorldEnvRay') for sc in SCENARIOS] + [(sc, 'altobs', 'CraftingWorldEnvAltObs') for sc in ALT_SCENARIOS] +
+            [(sc, 'flat', 'CraftingWorldEnvFlat') for sc in FLAT_SCENARIOS] + [(sc, 'onehot', 'CraftingWorldEnvOneHot') for sc in ONEHOT_SCENARIOS])
+    only = set(sys.argv[1:])
+    todo = [t for t in todo if not only or t[0][0] in only]
     for (name, kwargs, seed, steps, policy, keep), key, env_name in todo:
         out, n_success = capture(classes[key], kwargs, seed, steps, policy, keep, env_name)
         path = os.path.join(OUT, name + '.npz')
