@@ -207,16 +207,23 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
 {
     CwTuning &tn = e->tune;
     const char *forced = getenv("CW_TUNE_RENDER_PACE");
-    if (forced) { tn.render_pace = atoi(forced) < 0 ? 0 : atoi(forced); return CW_OK; }      // (256 + n: with the sleep inside each job)
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || !tn.render_linear || e->P.grp_rows == 0 || e->P.raster != CW_RASTER_RAY)
+    if (forced) {                                         // (256 + n: with the sleep inside each job)
+        tn.render_pace = atoi(forced) < 0 ? 0 : atoi(forced);
+        if (e->P.raster == CW_RASTER_ALT) e->P.alt_pace = tn.render_pace & 0xFF;
+        return CW_OK;
+    }
+    const bool alt = e->P.raster == CW_RASTER_ALT;       // the AltObs painter's pace lives in P.alt_pace (every kernel that paints frames reads it)
+    if (alt) e->P.alt_pace = 2;                           // (engines that are not calibrated: mid-range)
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (!alt && (!tn.render_linear || e->P.grp_rows == 0)))
         return CW_OK;
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return fail(CW_ERR_HIP, "cw_create: event creation failed");
     int blocks = 0, wpb = 0, rc = CW_OK;
     auto median_ms = [&](int pace, double *out) -> int {
-        const int saved = tn.render_pace;
+        const int saved = tn.render_pace, saved_alt = e->P.alt_pace;
         tn.render_pace = pace;
+        if (alt) e->P.alt_pace = pace;
         float ms[5];
         for (int rep = 0; rep < 6; rep++) {                                      // first launch discarded
             if (hipEventRecord(ev0, nullptr) != hipSuccess ||
@@ -224,10 +231,12 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
                 hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
                 (rep > 0 && hipEventElapsedTime(&ms[rep - 1], ev0, ev1) != hipSuccess)) {
                 tn.render_pace = saved;
+                e->P.alt_pace = saved_alt;
                 return fail(CW_ERR_HIP, "cw_create: render pace calibration failed");
             }
         }
         tn.render_pace = saved;
+        e->P.alt_pace = saved_alt;
         for (int i = 1; i < 5; i++) for (int j = i; j > 0 && ms[j] < ms[j - 1]; j--) { const float t = ms[j]; ms[j] = ms[j - 1]; ms[j - 1] = t; }
         *out = ms[2];
         return CW_OK;
@@ -241,7 +250,10 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
         if (rc == CW_OK && (best_ms == 0 || t < best_ms)) { best_ms = t; best = pace; }
         if (len < sizeof(log) - 24) len += (size_t)snprintf(log + len, sizeof(log) - len, " %s%d:%.4f", (pace & 0x100) ? "m+" : "", pace & 0xFF, t);
     };
-    if (!refine) {
+    if (alt) {
+        if (!refine) for (int pp = 0; pp <= 6 && rc == CW_OK; pp++) try_pace(pp);
+        else best = e->P.alt_pace;
+    } else if (!refine) {
         static const int cand[] = {0x100, 0x101, 0x102, 0x103, 0x104, 0, 1, 2, 3, 4, 6};
         for (size_t i = 0; i < sizeof(cand) / sizeof(cand[0]) && rc == CW_OK; i++) try_pace(cand[i]);
     } else {                                                                    // after the shares are known: the neighbours once more
@@ -251,7 +263,8 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     if (rc != CW_OK) return rc;
-    tn.render_pace = best;
+    if (alt) e->P.alt_pace = best;
+    else tn.render_pace = best;
     if (getenv("CW_TUNE_VERBOSE"))
         fprintf(stderr, "[craftingworld] render pace%s: ms per launch by sleeps per pair of jobs (m+: and one inside each job)%s -> %s%d\n",
                 refine ? " (with shares)" : "", log, (best & 0x100) ? "m+" : "", best & 0xFF);

@@ -178,21 +178,65 @@ __device__ __forceinline__ void alt_paint_strip(uint8_t *frame, int S, uint32_t 
         for (uint32_t j = first; j < 27u; j += step) p[(j / 9u) * row_bytes + 9u + (j % 9u)] = hold ? 255 : 0;
     }
 }
+// A whole AltObs frame by one wavefront.  The frame is almost all zeros: each of the <= 10 items lights ONE pixel (3 bytes)
+// of its cell's tile, and the "holding" flag is 9 more pixels.  So a frame is a zero FILL -- 16-byte chunks aligned in
+// memory (frames are 27*S*(S+1) bytes: even, not a multiple of 4, so every frame starts at another alignment; the <= 15
+// bytes before the first and after the last aligned chunk go out as single bytes, one lane each) -- followed by the <= 19
+// three-byte pixels, lane p = pixel p, three byte stores.  The pixel stores come after the fill stores of the same wave to
+// the same addresses: one wave's stores to one address are performed in program order.  Two items on one pixel give
+// 2 x colour in the reference's int image (sticks held over sticks, altobs.py:527-543), here modulo 256: the only pixels
+// that can coincide are the held item's and an object's, and they are merged before they are stored.
+// (The tile-by-tile form, 27 byte stores per cell, reached 4.3 TB/s on L2 write combining.)
 __device__ __forceinline__ void render_frame_alt(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
                                                  uint32_t div_magic, const uint32_t sp[8], uint32_t codes,
-                                                 uint32_t agent_cell, uint32_t hold, int lane)
+                                                 uint32_t agent_cell, uint32_t hold, int lane, int pace)
 {
-    for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
-        const uint32_t r = __umulhi(cell, div_magic);
-        const uint32_t c = cell - r * S;
-        uint32_t code = 0;
+    const uint32_t row_bytes = 9u * S, FB = 27u * S * (uint32_t)(S + 1);
+    // ---- the frame's lit pixels, lane p = pixel p: byte offset in the frame (none: 0xFFFFFFFF) and R | G<<8 | B<<16
+    uint32_t pos = 0xFFFFFFFFu, item = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) code = (cell == sp[k]) ? ((codes >> (4 * k)) & 15u) : code;
-        alt_paint_tile(dst0, S, r, c, code, cell == agent_cell, hold);
-        if (dst1) alt_paint_tile(dst1, S, r, c, code, cell == agent_cell, hold);
+    for (int q = 0; q < 8; q++) {                             // lanes 0..7: object slots (pixel = code - 1 of the slot's cell)
+        pos = (lane == q) ? sp[q] : pos;
+        item = (lane == q) ? ((codes >> (4 * q)) & 15u) : item;
     }
-    alt_paint_strip(dst0, S, hold, lane, CW_WAVE, true);
-    if (dst1) alt_paint_strip(dst1, S, hold, lane, CW_WAVE, true);
+    if (lane == 8) { pos = agent_cell; item = 9u; }          // the agent: pixel 8 (altobs.py:536)
+    if (lane == 9) { pos = agent_cell; item = hold; }        // the held item, on its own object pixel at the agent's cell
+    uint32_t p_off = 0xFFFFFFFFu, p_val = 0;
+    if (lane < 10 && item != 0 && pos < (uint32_t)ncell) {
+        const uint32_t r = __umulhi(pos, div_magic), c = pos - r * S, k = item - 1u;
+        const uint32_t k3 = (k >= 6u) ? 2u : (k >= 3u) ? 1u : 0u;
+        p_off = (3u * r + k3) * row_bytes + 9u * c + 3u * (k - 3u * k3);
+        p_val = cpv_color((int)k);
+    } else if (lane >= 10 && lane < 19 && hold != 0) {      // the strip's flag: pixels 3..5 of its three rows (altobs.py:557-559)
+        const uint32_t j = (uint32_t)lane - 10u, jr = (j >= 6u) ? 2u : (j >= 3u) ? 1u : 0u;
+        p_off = (3u * S + jr) * row_bytes + 9u + 3u * (j - 3u * jr);
+        p_val = 0x00FFFFFFu;
+    }
+    // the held item's pixel on top of an object's: one store of the sum, byte-wise modulo 256
+    const uint32_t held_off = __builtin_amdgcn_readlane(p_off, 9);
+    const bool twice = lane < 8 && p_off != 0xFFFFFFFFu && p_off == held_off;
+    if (twice) p_val = ((2u * (p_val & 0xFFu)) & 0xFFu) | ((2u * (p_val & 0xFF00u)) & 0xFF00u) | ((2u * (p_val & 0xFF0000u)) & 0xFF0000u);
+    if (CW_BALLOT(twice) && lane == 9) p_off = 0xFFFFFFFFu;
+    const bool p_any = p_off != 0xFFFFFFFFu;
+    for (int which = 0; which < 2; which++) {
+        uint8_t *const dst = which ? dst1 : dst0;
+        if (!dst) break;
+        const uint32_t head = (uint32_t)(-(intptr_t)dst) & 15u;               // bytes before the first aligned chunk
+        const uint32_t n_body = (FB - head) >> 4;                              // aligned 16-B chunks inside the frame
+        const uint32_t tail0 = head + 16u * n_body;                            // first byte after them
+        if ((uint32_t)lane < head) dst[lane] = 0;
+        if (tail0 + (uint32_t)lane < FB) dst[tail0 + lane] = 0;
+        for (uint32_t j = (uint32_t)lane; j < n_body; j += CW_WAVE) {
+            *(uint4 *)(dst + head + 16u * j) = make_uint4(0, 0, 0, 0);
+            // PACING (see render_groups): 1 KiB stores back to back run at 3.0 TB/s, with 64-192 idle clocks after each at 5.2-5.4
+            for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
+        }
+        if (p_any) {
+            dst[p_off] = (uint8_t)p_val;
+            dst[p_off + 1] = (uint8_t)(p_val >> 8);
+            dst[p_off + 2] = (uint8_t)(p_val >> 16);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ step
@@ -707,8 +751,8 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
         grgb[k] = rgb_of_code((r.goal_codes >> (4 * k)) & 15u);
     }
     if (P.raster == 1) {
-        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane);
-        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane);
+        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, P.alt_pace);
+        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, P.alt_pace);
     } else {
         render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
         render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
@@ -894,7 +938,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
             const uint32_t hold = (hx >> 16) & 0xFFu;
             uint8_t *dst = P.terminal_img + (size_t)env_l * P.frame_bytes;
             if (P.raster == 1) {
-                render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, tp, codes, acell, hold, lane);
+                render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, tp, codes, acell, hold, lane, P.alt_pace);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
@@ -1020,7 +1064,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     const size_t off = (size_t)cur_env * P.frame_bytes;
     uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
-    if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane);
+    if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane, P.alt_pace);
     else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
     if (MODE == 5) {                                         // restored checkpoint: INIT_OBS from the reset-time state
         uint32_t ip[8], irgb[8];
@@ -1030,7 +1074,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
         const uint32_t ia = (iaw >> (16 * (cur_env & 1))) & 0xFFFFu;
 #pragma unroll
         for (int k = 0; k < 8; k++) irgb[k] = rgb_of_code((uint32_t)k + 1u);
-        if (P.raster == 1) render_frame_alt(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, CW_CODES_INITIAL, ia, 0u, lane);
+        if (P.raster == 1) render_frame_alt(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, CW_CODES_INITIAL, ia, 0u, lane, P.alt_pace);
         else render_frame(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, irgb, ia, 0x00FFFFFFu, lane);
     }
     if (goal_too) {                                          // desired_goal = render(final_state), ray.py:299
@@ -1042,7 +1086,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
         const uint32_t ga = (gaw >> (16 * (cur_env & 1))) & 0xFFFFu;
 #pragma unroll
         for (int k = 0; k < 8; k++) grgb[k] = rgb_of_code((gc >> (4 * k)) & 15u);
-        if (P.raster == 1) render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, gc, ga, 0u, lane);
+        if (P.raster == 1) render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, gc, ga, 0u, lane, P.alt_pace);
         else render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
     }
 }

@@ -99,6 +99,7 @@ struct CwParams {
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
     int32_t tune_reset_prio; // 1: reset waves raise their priority (s_setprio 3)
+    int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
     int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
     int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)
 };
