@@ -175,7 +175,12 @@ def main():
                     help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
+    ap.add_argument('--quick', action='store_true',
+                    help='profiling runs (rocprofv3 / PMC passes serialise kernels): only the contract regions -- no repeats, no metric '
+                         'window, no other modes, no single env, no CPU baseline')
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_other_modes = args.no_single_env = True
 
     # Plain `python bench.py --gpus N`: become the parent of N fresh ranks BEFORE anything touches torch or HIP (a
     # process that has initialised the GPU must never be replaced or forked on this pool).  launch.py is loaded by
@@ -278,7 +283,7 @@ def main():
 
     elapsed = timed_region(K, W)                     # THE timed region of the contract: exactly K steps after W warm-up steps
     # ... and twice more (the driver's K may be tiny: 20 steps are 5 ms); `value` stays the first region
-    repeats_s = [elapsed] + [timed_region(K, W + (r + 1) * K) for r in range(2)]
+    repeats_s = [elapsed] + ([] if args.quick else [timed_region(K, W + (r + 1) * K) for r in range(2)])
     t_next = W + 3 * K
 
     # second, identical K-step region with the library's HIP events around each kernel (eager launches:
@@ -300,29 +305,31 @@ def main():
     # SURVEY 8d's metric window, whatever --steps was: 2*max_steps consecutive steps, so both steps on which (nearly)
     # every env times out at once are inside.  One clean pass for the rate; a second one with an event after every step
     # (on the stream the step joins back into) for the per-step durations.
-    KW_ = 2 * args.max_steps
-    ep0 = int(env.counters[1].item())
-    win_elapsed = timed_region(KW_, t_next)
-    win_episodes = int(env.counters[1].item()) - ep0
-    t_next += KW_
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(KW_ + 1)]
-    env.profile_begin(KW_)
-    barrier()
-    evs[0].record()
-    for t in range(KW_):
-        env.step_async(actions[(t_next + t) % rows])
-        evs[t + 1].record()
-    barrier()
-    win_prof = env.profile_end()
-    t_next += KW_
-    step_ms = sorted((evs[t].elapsed_time(evs[t + 1]) for t in range(KW_)), reverse=True)
-    window = {'steps': KW_, 'value': float(N) * world * KW_ / win_elapsed, 'unit': 'env-steps/s',
-              'ms_per_step': win_elapsed / KW_ * 1e3, 'episodes_finished': win_episodes,
-              'slowest_step_ms': step_ms[:2], 'median_step_ms': step_ms[KW_ // 2],
-              'render_kernel_ms_avg': win_prof['ms_render_kernel'] or None,
-              'launch': 'eager',
-              'note': 'same process, after the K-step regions; value from a pass without events (max over ranks), per-step '
-                      'figures from a second pass with one event per step (rank 0)'}
+    window = None
+    if not args.quick:
+        KW_ = 2 * args.max_steps
+        ep0 = int(env.counters[1].item())
+        win_elapsed = timed_region(KW_, t_next)
+        win_episodes = int(env.counters[1].item()) - ep0
+        t_next += KW_
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(KW_ + 1)]
+        env.profile_begin(KW_)
+        barrier()
+        evs[0].record()
+        for t in range(KW_):
+            env.step_async(actions[(t_next + t) % rows])
+            evs[t + 1].record()
+        barrier()
+        win_prof = env.profile_end()
+        t_next += KW_
+        step_ms = sorted((evs[t].elapsed_time(evs[t + 1]) for t in range(KW_)), reverse=True)
+        window = {'steps': KW_, 'value': float(N) * world * KW_ / win_elapsed, 'unit': 'env-steps/s',
+                  'ms_per_step': win_elapsed / KW_ * 1e3, 'episodes_finished': win_episodes,
+                  'slowest_step_ms': step_ms[:2], 'median_step_ms': step_ms[KW_ // 2],
+                  'render_kernel_ms_avg': win_prof['ms_render_kernel'] or None,
+                  'launch': 'eager',
+                  'note': 'same process, after the K-step regions; value from a pass without events (max over ranks), per-step '
+                          'figures from a second pass with one event per step (rank 0)'}
 
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per

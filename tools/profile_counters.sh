@@ -12,7 +12,7 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum TA_TA_BUSY_sum" \
          "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python bench.py --no-cpu-baseline --no-other-modes --steps 60 --warmup 5 > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python bench.py --quick --steps 60 --warmup 5 > $OUT/g$i.json 2> $OUT/g$i.err || echo "group $i failed"
 done
 python - <<'PY'
 import csv, glob, os, collections, json

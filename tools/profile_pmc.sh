@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 # the calibration kernel is built from its source here (no binary is committed)
 make -B -C tools/microbench store_variants > $OUT/build_calib.log 2>&1
 for C in WRITE_SIZE FETCH_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/bench_$C -- python bench.py --no-cpu-baseline --steps 60 --warmup 5 > $OUT/bench_$C.json 2> $OUT/bench_$C.err
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/bench_$C -- python bench.py --quick --steps 60 --warmup 5 > $OUT/bench_$C.json 2> $OUT/bench_$C.err
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/calib_$C -- ./tools/microbench/store_variants > $OUT/calib_$C.txt 2> $OUT/calib_$C.err
 done
 python tools/summarize_pmc.py $OUT > $OUT/summary.json

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -- python bench.py --no-cpu-baseline --no-other-modes > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof -- python bench.py --quick > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 cp $OUT/rocprof/*/*kernel_stats.csv $OUT/kernel_stats.csv
 bash tools/profile_pmc.sh > $OUT/pmc.log 2>&1
 cp $GRAFT_REPO_ROOT/gpurun_out/pmc/summary.json $OUT/pmc_traffic.json

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise tools/profile_pmc.sh output into profiles/r01_pmc_traffic.json content (stdout)."""
+"""Summarise tools/profile_pmc.sh output into profiles/profiles/rNN_pmc_traffic.json content (stdout)."""
 import csv
 import glob
 import json
