@@ -251,10 +251,12 @@ def main():
             for t in range(G):
                 env.step_async(actions[t])
         torch.cuda.current_stream(dev).wait_stream(side)
+        env.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):                    # G steps, each reading its own action row
             for t in range(G):
                 env.step_async(actions[t])
+            env.lookahead_join()                         # (look-ahead engines: every forked refill joins the graph's end)
 
     if args.rollout and args.obs_mode != 'state':
         raise SystemExit('--rollout needs --obs-mode state')

@@ -79,6 +79,7 @@ ABI = {
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
     'cw_synchronize': (C.c_int, [_VP, _VP]),
+    'cw_lookahead_join': (C.c_int, [_VP, _VP]),
     'cw_num_envs': (C.c_int, [_VP]),
     'cw_abi_version': (C.c_int, []),
     'cw_last_error': (C.c_char_p, []),

@@ -222,6 +222,11 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out);
 /* Blocks the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize): the one host
  * synchronisation of the single-env loop, where step() returns Python scalars (ray.py:376-378). */
 int cw_synchronize(cw_engine *e, cw_stream_t stream);
+/* Look-ahead engines only (experiment knob CW_TUNE_LOOKAHEAD=1: state / dirty-cell modes generate every env's next two
+ * episodes ahead on an engine-owned stream and promote finished envs instead of resetting them; results are identical).
+ * Makes `stream` wait for the refills still in flight -- enqueue only.  Needed before ending a HIP-graph capture of cw_step
+ * calls (an even number of them); a no-op on other engines. */
+int cw_lookahead_join(cw_engine *e, cw_stream_t stream);
 int cw_num_envs(const cw_engine *e);
 int cw_abi_version(void);
 const char *cw_last_error(void);   /* thread-local text of the last failing call */
