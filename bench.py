@@ -173,6 +173,9 @@ def main():
                          'holds two steps on which every env times out at once, as SURVEY 8d defines the metric)')
     ap.add_argument('--graph-steps', type=int, default=0,
                     help='capture this many consecutive steps into one HIP graph and replay it (0 = eager launches)')
+    ap.add_argument('--mixed-menus', action='store_true',
+                    help='BASELINE configs[3] shape: env i uses ordered task list i mod 8 of a fixed menu of eight (heterogeneous selected_tasks / '
+                         'number_of_tasks / stacking / reward_style per env)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
     ap.add_argument('--quick', action='store_true',
@@ -225,8 +228,16 @@ def main():
     # [lo, hi) and env e's stream is numpy RandomState(e) whatever rank owns it
     lo, hi = shard_range(rank, world, args.envs_per_gpu * world)
     N = hi - lo
+    menu_kw = {}
+    if args.mixed_menus:
+        T = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoToHouse', 'MoveAxe', 'MoveHammer', 'MoveSticks']
+        menu_kw = dict(task_menus=[dict(), dict(selected_tasks=T[::-1]), dict(selected_tasks=T[:4], number_of_tasks=2),
+                                   dict(selected_tasks=['GoToHouse', 'MoveAxe', 'EatBread'], stacking=False),
+                                   dict(selected_tasks=T[3:], reward_style='subset'), dict(selected_tasks=['ChopTree', 'BuildHouse'], number_of_tasks=1),
+                                   dict(selected_tasks=T[1::2]), dict(selected_tasks=T[::2], number_of_tasks=3, reward_style='subset')],
+                       env_menu=(np.arange(lo, hi) % 8).astype(np.uint8))
     env = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=args.obs_mode,
-                              device=dev, seed=lo, raster=args.raster)
+                              device=dev, seed=lo, raster=args.raster, **menu_kw)
     env.reset()
     if args.desync:
         env.set_state(step_num=((np.arange(lo, hi) * 7) % args.max_steps).astype(np.int32))
@@ -405,6 +416,7 @@ def main():
                                                                         'state': 'state-only'}[args.obs_mode], args.max_steps),
                        'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
                        'sharding': 'contiguous env ranges per rank, no data-path collective',
+                       'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)',
                        'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

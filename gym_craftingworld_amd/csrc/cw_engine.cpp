@@ -16,6 +16,7 @@
 extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev, int la_parity);
+int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity, int all_envs, hipStream_t st);
 hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
@@ -87,7 +88,19 @@ struct cw_engine {
     bool la_refill_pending[2] = {false, false};
     bool la_capturing = false;         // the cw_step calls currently being made are recorded into a HIP graph
     unsigned la_capture_step0 = 0;
+    // online tuner of the render pace (full-frame mode, linear sweep): see adapt_tick
+    struct Adapt {
+        bool on = false;
+        hipEvent_t ev[64] = {nullptr};         // ev[w % 64] is recorded on the caller's stream when window w begins
+        unsigned seq = 0;                      // steps taken in the tuned mode
+        unsigned next_window = 0;              // first window whose duration has not been read yet
+        int cur = 1;                           // sleeps per pair of jobs currently held (the sleep inside each job is always on)
+        signed char pace_of_window[64] = {0};  // what each recent window ran at; negative: a settling window, not counted
+        float stat[16] = {0};                  // per pace: running mean step time of its counted windows (ms; 0: unknown)
+        unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
+    } adapt;
 };
+enum { CW_ADAPT_W = 16, CW_ADAPT_MAX = 8 };
 
 // Look-ahead engines keep mt[] two episodes ahead of the reference's timeline.  Every entry point that reads or replaces the
 // RNG streams, or resets outside cw_step, first returns to the canonical form (mt[e] = snapshot of e's next slot); the next
@@ -294,6 +307,61 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     return CW_OK;
 }
 
+// Online tuner of the render pace.  Where the write path's optimum lies depends on what else runs -- with all episodes in phase
+// the render kernel is alone on 598 of 600 steps, with the phases spread out ~0.3 % of the envs are being reset beside it on every
+// step -- and on the box; launches timed back to back at cw_create do not predict it (profiles/r02_render_linear.txt, section L).
+// So cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and
+// the time between two consecutive ones, read whenever both have completed -- however far the host runs ahead of the GPU -- is what
+// CW_ADAPT_W whole steps took.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the first
+// window after a change of pace settles and is not counted; a window holding a step on which every env was reset is an outlier and
+// is not counted either); each counted window updates the running figure of its pace, and `cur` moves to a neighbour whose figure
+// is 0.7 % better (figures older than three cycles do not count).  Only performance depends on any of it.
+static void adapt_tick(cw_engine *e, hipStream_t st)
+{
+    cw_engine::Adapt &a = e->adapt;
+    const unsigned w = a.seq / CW_ADAPT_W;           // the window about to start
+    if (hipEventRecord(a.ev[w % 64], st) != hipSuccess) return;
+    bool moved = false;
+    while (a.next_window + 1 <= w) {                 // window next_window lies between ev[next_window] and ev[next_window + 1]
+        const unsigned cw = a.next_window;
+        if (w - cw >= 63) { a.next_window++; continue; }                         // (its events have been reused)
+        if (cw + 1 == w) break;                                                  // its closing event was recorded just now
+        if (hipEventQuery(a.ev[(cw + 1) % 64]) != hipSuccess) break;
+        float ms = 0.f;
+        const int p = a.pace_of_window[cw % 64];
+        a.next_window++;
+        if (p < 0 || hipEventElapsedTime(&ms, a.ev[cw % 64], a.ev[(cw + 1) % 64]) != hipSuccess || ms <= 0.f) continue;
+        ms /= (float)CW_ADAPT_W;
+        const bool known = a.stat[p] > 0 && cw - a.stat_window[p] < 80;
+        if (known && ms > 1.06f * a.stat[p]) continue;                           // a reset storm inside the window
+        a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
+        a.stat_window[p] = cw;
+        moved = true;
+    }
+    if (moved) {                                     // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
+        const int c = a.cur;
+        auto fresh = [&](int p) { return p >= 0 && p <= CW_ADAPT_MAX && a.stat[p] > 0 && a.next_window - a.stat_window[p] < 80; };
+        if (fresh(c)) {
+            int best = c;
+            if (fresh(c + 1) && a.stat[c + 1] < a.stat[best] * 0.993f) best = c + 1;
+            if (fresh(c - 1) && a.stat[c - 1] < a.stat[best] * (best == c ? 0.993f : 1.0f)) best = c - 1;
+            if (best != c) {
+                if (getenv("CW_TUNE_VERBOSE"))
+                    fprintf(stderr, "[craftingworld] render pace (online, window %u): m+%d %.4f ms/step | m+%d %.4f | m+%d %.4f -> m+%d\n", w, c,
+                            a.stat[c], c + 1, fresh(c + 1) ? a.stat[c + 1] : 0.0, c - 1, fresh(c - 1) ? a.stat[c - 1] : 0.0, best);
+                a.cur = best;
+            }
+        }
+    }
+    // the cycle: 0-19 cur | 20 (settle), 21 cur + 1 | 22 (settle), 23 cur - 1; window 0 of the cycle settles too
+    const unsigned pos = w % 24;
+    int p = a.cur;
+    const bool settle = (pos == 0 || pos == 20 || pos == 22);
+    if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
+    else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
+    a.pace_of_window[w % 64] = (signed char)(settle ? -1 - p : p);
+}
+
 // XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
 // than their neighbours' (workgroups go round-robin over the 8 XCDs, so it shows as even vs odd workgroup index), and a
 // launch lasts as long as its slowest wave.  Measure it instead of assuming it: a few equal-share launches with the waves'
@@ -448,7 +516,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.grp_per_frame = P.grp_rows ? (e->S + P.grp_rows - 1) / P.grp_rows : 0;
     {   // experiment knobs; the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
-        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 1);
+        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);   // 2: the render waves raise their priority, the reset kernel beside them does not
+        P.reset_paint_pace = geti("CW_TUNE_RESET_PAINT_PACE", 0);
         CwTuning &tn = e->tune;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
@@ -556,6 +625,16 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (rc == CW_OK) rc = calibrate_render_pace(e, false);
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
+    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
+        !getenv("CW_TUNE_RENDER_PACE") && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) &&
+        (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
+        cw_engine::Adapt &a = e->adapt;
+        for (hipEvent_t &ev : a.ev)
+            if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: pace tuner set-up failed");
+        a.cur = e->tune.render_pace & 0xFF;
+        if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
+        a.on = rc == CW_OK;
+    }
     if (rc != CW_OK) {
         cw_destroy(e);
         *out = nullptr;
@@ -575,6 +654,7 @@ int cw_destroy(cw_engine *e)
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_la_step) (void)hipEventDestroy(e->ev_la_step);
     for (hipEvent_t ev : e->ev_la_refill) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->adapt.ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
@@ -695,6 +775,17 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         e->la_step++;
         if (ev) e->prof_n++;
         return CW_OK;
+    }
+    if (e->adapt.on) {                               // full-frame mode: the render pace follows what the steps measure (adapt_tick)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
+            if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
+            const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
+            e->tune.render_pace = 0x100 | (pw < 0 ? -1 - pw : pw);
+            e->adapt.seq++;
+        } else {
+            e->tune.render_pace = 0x100 | e->adapt.cur;                           // a captured graph keeps the pace it was captured with
+        }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
                             e->ev_fork, e->ev_join, ev, -1));

@@ -744,7 +744,7 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
 
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
                                              uint32_t div_magic, const uint32_t sp[8], const uint32_t rgb[8],
-                                             uint32_t agent_cell, uint32_t hold_rgb, int lane);
+                                             uint32_t agent_cell, uint32_t hold_rgb, int lane, int pace = 0);
 
 // the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the
 // wave that just reset it: no second kernel has to wait for the reset and re-read its records
@@ -763,8 +763,8 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
         render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, P.alt_pace);
         render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, P.alt_pace);
     } else {
-        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
-        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
+        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane, P.reset_paint_pace);
+        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane, P.reset_paint_pace);
     }
 }
 
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
     // few, latency-critical waves sharing CUs with the render kernel's store-bound waves: win arbitration
-    if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
+    if (P.tune_reset_prio == 1) __builtin_amdgcn_s_setprio(3);
     // the wave's first list entry is fetched together with the count (entries past the count are stale but in bounds)
     const int first = (!all_envs && wave < P.n_envs) ? P.done_list[wave] : 0;
     const int count = all_envs ? P.n_envs : P.done_count[0];
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwPara
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
                                              int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
                                              const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
-                                             int lane)
+                                             int lane, int pace)
 {
     const uint32_t row_bytes = 12u * S;
     for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
@@ -1145,15 +1145,19 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
         uint8_t *q = dst0 + off;
         *(u32x3_a4 *)(q) = d;
         *(u32x3_a4 *)(q + row_bytes) = d1;
+        for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);           // (PACING, see render_groups)
         *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
         *(u32x3_a4 *)(q + 3 * row_bytes) = d;
         if (dst1) {
             uint8_t *q1 = dst1 + off;
+            for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
             *(u32x3_a4 *)(q1) = d;
             *(u32x3_a4 *)(q1 + row_bytes) = d1;
+            for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
             *(u32x3_a4 *)(q1 + 2 * row_bytes) = d2;
             *(u32x3_a4 *)(q1 + 3 * row_bytes) = d;
         }
+        for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -1345,6 +1349,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     const uint32_t v_off = 4u * r_local * row_bytes + 12u * c_local;
     const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
     uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
+    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);               // (experiment) the render wave wins the SIMD it shares with a resetting wave
     const int pace_pair = pace & 0xFF;                                       // sleeps of 64 clocks per pair of jobs
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
     CW_WAVE_CLOCK(t_start);
@@ -1511,10 +1516,17 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// linear sweep only where the geometry allows it: Ray raster, S <= 64, job ids fit an int
+// linear sweep where the geometry allows it (Ray raster, S <= 64) and where it is the faster one: its waves are in step only at
+// the start of a launch, and over thousands of rounds they drift apart (the write window smears, the slower XCDs' waves trail) --
+// measured at 21x21: 0.69 vs 0.665 of the HBM peak for frame-per-wave at 262 144 envs (1 792 rounds per wave), 0.676 vs 0.725 at
+// 524 288, 0.62 vs 0.71 at 2^20 (profiles/r02_other_configs.txt).  CW_TUNE_RENDER_LINEAR=2 forces it whatever the batch.
 static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
 {
-    return tn.render_linear && P.raster == 0 && P.grp_rows > 0 && (long long)P.n_envs * P.grp_per_frame < (1ll << 30);
+    if (!tn.render_linear || P.raster != 0 || P.grp_rows <= 0) return 0;
+    const long long jobs = (long long)P.n_envs * P.grp_per_frame;
+    if (jobs >= (1ll << 30)) return 0;
+    const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
+    return tn.render_linear >= 2 || jobs <= 2560 * waves;
 }
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
@@ -1673,6 +1685,7 @@ hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStre
     return hipGetLastError();
 }
 
+int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
 int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)

@@ -112,6 +112,7 @@ struct CwParams {
     uint8_t *la_next;        // [N] slot the env consumes at its next reset
     int32_t *la_queue;       // [2][N] consumed (env | slot << 30) entries of the steps of each parity, for the refill kernel
     int32_t *la_qcount;      // [4] entries of parity 0 / 1, release tickets of parity 0 / 1
+    int32_t reset_paint_pace; // sleeps of 64 clocks between the store pairs of a resetting wave's three frames (experiment knob)
     int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
     int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
     int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)
