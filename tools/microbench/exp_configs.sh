@@ -12,6 +12,6 @@ run "65536 envs state-only, persistent rollout kernel" --obs-mode state --rollou
 run "65536 envs full frames, phases spread out (--desync)" --desync
 run "65536 envs dirty-cell, phases spread out" --obs-mode pixels_dirty --desync
 run "65536 envs state-only, phases spread out" --obs-mode state --desync
-run "65536 envs 8x8 full frames (Flat's default grid)" --size 8 --max-steps 100
+run "65536 envs 8x8 full frames (the Flat class default grid)" --size 8 --max-steps 100
 run "65536 envs 5x5 full frames" --size 5 --max-steps 50
 run "65536 envs 64x64 full frames (196 KB each)" --size 64 --steps 100 --warmup 10
