@@ -517,7 +517,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     {   // experiment knobs; the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);   // 2: the render waves raise their priority, the reset kernel beside them does not
-        P.reset_paint_pace = geti("CW_TUNE_RESET_PAINT_PACE", 0);
         CwTuning &tn = e->tune;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;

@@ -744,7 +744,7 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
 
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
                                              uint32_t div_magic, const uint32_t sp[8], const uint32_t rgb[8],
-                                             uint32_t agent_cell, uint32_t hold_rgb, int lane, int pace = 0);
+                                             uint32_t agent_cell, uint32_t hold_rgb, int lane);
 
 // the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the
 // wave that just reset it: no second kernel has to wait for the reset and re-read its records
@@ -763,8 +763,8 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
         render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, P.alt_pace);
         render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, P.alt_pace);
     } else {
-        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane, P.reset_paint_pace);
-        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane, P.reset_paint_pace);
+        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
+        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
     }
 }
 
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwPara
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
                                              int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
                                              const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
-                                             int lane, int pace)
+                                             int lane)
 {
     const uint32_t row_bytes = 12u * S;
     for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
@@ -1145,19 +1145,15 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
         uint8_t *q = dst0 + off;
         *(u32x3_a4 *)(q) = d;
         *(u32x3_a4 *)(q + row_bytes) = d1;
-        for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);           // (PACING, see render_groups)
         *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
         *(u32x3_a4 *)(q + 3 * row_bytes) = d;
         if (dst1) {
             uint8_t *q1 = dst1 + off;
-            for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
             *(u32x3_a4 *)(q1) = d;
             *(u32x3_a4 *)(q1 + row_bytes) = d1;
-            for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
             *(u32x3_a4 *)(q1 + 2 * row_bytes) = d2;
             *(u32x3_a4 *)(q1 + 3 * row_bytes) = d;
         }
-        for (int z = 0; z < pace; z++) __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -1349,7 +1345,9 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     const uint32_t v_off = 4u * r_local * row_bytes + 12u * c_local;
     const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
     uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
-    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);               // (experiment) the render wave wins the SIMD it shares with a resetting wave
+    // a render wave shares its SIMD with at most a few resetting waves (side stream): it wins the issue slot, they have the whole
+    // launch to finish (with the reset waves raised instead, as in round 1, the spread-out-phases step is 3-8 % slower)
+    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
     const int pace_pair = pace & 0xFF;                                       // sleeps of 64 clocks per pair of jobs
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
     CW_WAVE_CLOCK(t_start);

@@ -52,7 +52,7 @@ struct CwTuning {
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
-    int render_linear = 1;          // full-frame render as ONE linear sweep: job = a run of whole grid rows (<= 64 cells, contiguous bytes)
+    int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
     int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job;
                                     //   cw_create calibrates it (cw_kernels.hip: PACING)
 };
@@ -99,7 +99,7 @@ struct CwParams {
     uint32_t div_magic;      // floor(2^32 / S) + 1 : x / S == mulhi(x, magic) for x < 2^18
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
-    int32_t tune_reset_prio; // 1: reset waves raise their priority (s_setprio 3)
+    int32_t tune_reset_prio; // s_setprio 3 for: 2 the render waves and the resets inlined in the fused / rollout kernels (default), 1 every resetting wave, 0 nobody
     // look-ahead resets (CW_TUNE_LOOKAHEAD=1, state / dirty-cell modes; null otherwise): two pre-generated episodes per env
     // ("slots"; slot s of env e at index s*N + e) and the env's MT19937 state as it was BEFORE each was generated
     uint4 *la_init_pos;      // [2][N]
@@ -112,7 +112,6 @@ struct CwParams {
     uint8_t *la_next;        // [N] slot the env consumes at its next reset
     int32_t *la_queue;       // [2][N] consumed (env | slot << 30) entries of the steps of each parity, for the refill kernel
     int32_t *la_qcount;      // [4] entries of parity 0 / 1, release tickets of parity 0 / 1
-    int32_t reset_paint_pace; // sleeps of 64 clocks between the store pairs of a resetting wave's three frames (experiment knob)
     int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
     int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
     int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)
