@@ -216,7 +216,25 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend_used = args.dist_backend
         if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))   # RCCL; timing barrier / max only
+            # RCCL carries only the timing barrier and the max-over-ranks (no data-path collective exists).  If it cannot come up
+            # on this node, every rank sees the failure and the same two collectives go over gloo instead -- a scaling run is not
+            # lost to the barrier's transport; the JSON line says which one was used.
+            try:
+                dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write('[bench] rank %d: RCCL process group failed (%s: %s); using gloo for the timing barrier\n'
+                                 % (rank, type(exc).__name__, str(exc).splitlines()[0] if str(exc) else ''))
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
+                dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
+                args.dist_backend = 'gloo'
+                backend_used = 'gloo (RCCL process group failed: %s)' % type(exc).__name__
         else:
             dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
 
