@@ -250,8 +250,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     }
     const bool alt = e->P.raster == CW_RASTER_ALT;       // the AltObs painter's pace lives in P.alt_pace (every kernel that paints frames reads it)
     if (alt) e->P.alt_pace = 2;                           // (engines that are not calibrated: mid-range)
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (!alt && (!tn.render_linear || e->P.grp_rows == 0)))
-        return CW_OK;
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions) return CW_OK;      // (the Ray raster is paced in both of its kernels)
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return fail(CW_ERR_HIP, "cw_create: event creation failed");

@@ -744,7 +744,7 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
 
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
                                              uint32_t div_magic, const uint32_t sp[8], const uint32_t rgb[8],
-                                             uint32_t agent_cell, uint32_t hold_rgb, int lane);
+                                             uint32_t agent_cell, uint32_t hold_rgb, int lane, int pace = 0);
 
 // the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the
 // wave that just reset it: no second kernel has to wait for the reset and re-read its records
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwPara
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
                                              int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
                                              const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
-                                             int lane)
+                                             int lane, int pace)
 {
     const uint32_t row_bytes = 12u * S;
     for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
@@ -1145,8 +1145,10 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
         uint8_t *q = dst0 + off;
         *(u32x3_a4 *)(q) = d;
         *(u32x3_a4 *)(q + row_bytes) = d1;
+        if (pace & 0x100) __builtin_amdgcn_s_sleep(1);                        // (PACING, see render_groups)
         *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
         *(u32x3_a4 *)(q + 3 * row_bytes) = d;
+        if ((cell >> 6) & 1u) for (int z = 0; z < (pace & 0xFF); z++) __builtin_amdgcn_s_sleep(1);   // per pair of 64-cell groups
         if (dst1) {
             uint8_t *q1 = dst1 + off;
             *(u32x3_a4 *)(q1) = d;
@@ -1185,7 +1187,7 @@ __device__ __forceinline__ void unpack_pos_s(const u32x4s &v, uint32_t sp[8])
 }
 
 template <int MODE>
-__device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cur, bool want_done, uint8_t *ext_out, int lane)
+__device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cur, bool want_done, uint8_t *ext_out, int lane, int pace)
 {
     if (cur.env < 0) return;
     const int cur_env = cur.env;
@@ -1204,7 +1206,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
     uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
     uint8_t *d1 = three ? P.init_img + off : nullptr;
     if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane, P.alt_pace);
-    else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane);
+    else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane, pace);
     if (MODE == 5) {                                         // restored checkpoint: INIT_OBS from the reset-time state
         uint32_t ip[8], irgb[8];
         const u32x4s ipp = cload((const u32x4s *)(P.init_pos + cur_env));
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // calibration at cw_create (cw_engine.cpp).  fast_parity < 0: no classes, q_all covers everything.  The partition
 // depends on workgroup indices only, never on where a workgroup actually runs: coverage is exact either way.
 template <int MODE>
-__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
+__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace = 0)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
@@ -1292,7 +1294,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
             cur.pp.z = __builtin_amdgcn_readlane(v_p.z, k);
             cur.pp.w = __builtin_amdgcn_readlane(v_p.w, k);
             cur.done_word = __builtin_amdgcn_readlane(v_done, k) << (8 * (cur.env & 3));
-            render_one<MODE>(P, cur, want_done, ext_out, lane);            // (env < 0: nothing to paint)
+            render_one<MODE>(P, cur, want_done, ext_out, lane, pace);      // (env < 0: nothing to paint)
         }
     }
     CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
@@ -1423,10 +1425,10 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
     else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace);
 }
 // the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
-__global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity)
+__global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
 {
-    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity);
-    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity);
+    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity, pace);
+    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity, pace);
 }
 // off the per-step path: the three frames of every env after cw_reset (mode 0), or the last frames of the
 // done list's envs before their reset (mode 4, keep_terminal_obs)
@@ -1548,7 +1550,7 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
     if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
-    else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity);
+    else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
