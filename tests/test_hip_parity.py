@@ -1577,3 +1577,24 @@ def test_lookahead_resets_equal_inline_resets(obs_mode, pool, terminal, monkeypa
     assert torch.equal(plain.hdr, third.hdr) and torch.equal(plain.slot_pos, third.slot_pos)
     rng_same('end')
     plain.close(); ahead.close(); third.close()
+
+
+def test_bench_self_launched_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` started plainly (no torchrun): the parent starts two fresh ranks before touching HIP, both ranks
+    run their env shard on this one GPU (--rehearse-on-one-gpu; gloo carries the timing barrier), rank 0's single JSON line comes
+    back through the parent with n_gpus 2 and the whole-job rate.  Three processes use the GPU at most (two ranks + this test)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-on-one-gpu', '--dist-backend', 'gloo',
+                        '--quick', '--steps', '12', '--warmup', '3', '--envs-per-gpu', '4096', '--max-steps', '20'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 12 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['dist_backend'] == 'gloo'
+    assert d['config']['envs_per_gpu'] == 4096 and d['value'] > 0
+    assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
