@@ -67,6 +67,7 @@ ABI = {
     'cw_step': (C.c_int, [_VP, _VP, C.c_int, _VP]),
     'cw_rollout': (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP]),
     'cw_render': (C.c_int, [_VP, _VP, _VP]),
+    'cw_render_onehot': (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP]),
     'cw_export_grid': (C.c_int, [_VP, _VP, _VP]),
     'cw_export_onehot': (C.c_int, [_VP, _VP, _VP]),
     'cw_export_onehot_of': (C.c_int, [_VP, C.c_int, _VP, _VP]),

@@ -22,6 +22,7 @@ hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStrea
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
+hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, int n_states, uint16_t *out, hipStream_t st);
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
@@ -812,6 +813,16 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, out_frames, (hipStream_t)stream));
+    return CW_OK;
+}
+
+int cw_render_onehot(cw_engine *e, const uint8_t *onehot, int32_t n_states, uint16_t *out_frames, cw_stream_t stream)
+{
+    if (!e || !onehot || !out_frames) return fail(CW_ERR_INVALID, "cw_render_onehot: null argument");
+    if (n_states < 1) return fail(CW_ERR_INVALID, "cw_render_onehot: n_states must be >= 1");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    HIP_TRY(cwk_launch_render_onehot(&e->P, onehot, n_states, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
 

@@ -1482,6 +1482,58 @@ __global__ __launch_bounds__(256) void cw_export_onehot_kernel(CwParams P, uint8
     }
 }
 
+// ------------------------------------------------------------------------------------ render(state) for ANY one-hot state
+// render(state=...) of ray.py:442-486 on caller-supplied (S,S,12) one-hot states, whatever they hold (several objects in a cell,
+// more than eight objects, hold flags away from the agent): img = sum over object channels of COLORS_N (the reference's tensordot;
+// uint16 here, the sums reach 8 x 255), x4 upscale, agent = the FIRST cell (row-major) with channel 8 set: centre 2x2 := 255, and if
+// any cell has a hold channel set, row 4r+2 of that centre := COLORS_N[max over cells of (first set hold channel + 1)].  One
+// wavefront per state; off the hot path (the engine's own states are sparse slots and take cw_render).
+__global__ __launch_bounds__(256) void cw_render_onehot_kernel(const uint8_t *__restrict__ oh, int n_states, int S, uint32_t div_magic,
+                                                               uint16_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE;
+    const int n_waves = gridDim.x * blockDim.x / CW_WAVE;
+    const int ncell = S * S;
+    for (int f = wave; f < n_states; f += n_waves) {
+        const uint8_t *st = oh + (size_t)f * ncell * 12;
+        uint32_t agent = 0xFFFFFFFFu, hold = 0;
+        for (int cell = lane; cell < ncell; cell += CW_WAVE) {
+            const uint8_t *c = st + 12 * cell;
+            if (c[8] == 1) agent = min(agent, (uint32_t)cell);
+            const uint32_t hv = c[9] >= c[10] && c[9] >= c[11] ? (c[9] ? 1u : 0u) : (c[10] >= c[11] ? 2u : 3u);   // argmax([0, h9, h10, h11])
+            hold = max(hold, hv);
+        }
+        for (int off = 32; off; off >>= 1) {
+            agent = min(agent, (uint32_t)__shfl_xor((int)agent, off));
+            hold = max(hold, (uint32_t)__shfl_xor((int)hold, off));
+        }
+        const uint32_t hold_rgb = rgb_of_code(hold);
+        uint16_t *img = out + (size_t)f * ncell * 48;
+        const uint32_t row_px = 4u * S;
+        for (int cell = lane; cell < ncell; cell += CW_WAVE) {
+            const uint8_t *c = st + 12 * cell;
+            uint32_t r = 0, g = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t col = rgb_of_code((uint32_t)k + 1u), v = c[k];
+                r += v * (col & 0xFFu); g += v * ((col >> 8) & 0xFFu); b += v * (col >> 16);
+            }
+            const uint32_t cr = __umulhi((uint32_t)cell, div_magic), cc = (uint32_t)cell - cr * S;
+            for (uint32_t dy = 0; dy < 4; dy++)
+                for (uint32_t dx = 0; dx < 4; dx++) {
+                    uint32_t pr = r, pg = g, pb = b;
+                    if ((uint32_t)cell == agent && (dy == 1 || dy == 2) && (dx == 1 || dx == 2)) {
+                        pr = pg = pb = 255u;
+                        if (dy == 2 && hold) { pr = hold_rgb & 0xFFu; pg = (hold_rgb >> 8) & 0xFFu; pb = hold_rgb >> 16; }
+                    }
+                    uint16_t *px = img + ((size_t)(4u * cr + dy) * row_px + 4u * cc + dx) * 3;
+                    px[0] = (uint16_t)pr; px[1] = (uint16_t)pg; px[2] = (uint16_t)pb;
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ seeding
 // seed() (ray.py:145-147) at batch scale, one lane per env: numpy RandomState(seed) is init_genrand -- 623 dependent
 // multiplies, embarrassingly parallel over envs -- and leaves pos = 624; an injected RandomState state (key, pos) is
@@ -1658,6 +1710,15 @@ hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity
 hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st)
 {
     hipLaunchKernelGGL(cw_la_rollback_kernel, dim3(T->n_cu * 4), dim3(256), 0, st, *P);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, int n_states, uint16_t *out, hipStream_t st)
+{
+    int blocks = (n_states + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cw_render_onehot_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
     return hipGetLastError();
 }
 

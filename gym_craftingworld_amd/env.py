@@ -212,9 +212,10 @@ class CraftingWorldEnv:
         return self._obs_dict(), int(self._h_reward[0]), bool(self._h_done[0]), info
 
     def render(self, state=None, mode='Non', tile_size=4):
-        """render() of ray.py:442-520: the current state, or a caller-supplied (S,S,12) one-hot `state` (agent = the
-        cell with channel 8 set, held item = channels 9-11 there).  A one-hot cell may name at most one object (the
-        engine's state space, SURVEY 8: the reference's own states never hold more)."""
+        """render() of ray.py:442-520: the current state, or a caller-supplied (S,S,12) one-hot `state` of any content -- the image
+        is the sum of the colours of the objects in each cell, the agent the first cell with channel 8 set, the held item's colour
+        comes from the hold channels (cw_render_onehot).  With the default uint8 dtype sums above 255 wrap; reference_dtypes=True
+        returns the reference's int64 image exactly."""
         if mode == 'human':
             raise NotImplementedError('mode="human" (matplotlib popup) is out of scope')
         if state is None:
@@ -223,30 +224,18 @@ class CraftingWorldEnv:
         S = self.STATE_W
         if st.shape != (S, S, 12):
             raise ValueError('state must be a (%d, %d, 12) one-hot array' % (S, S))
-        if (st[:, :, :8].sum(axis=2) > 1).any():
-            raise ValueError('a cell holds more than one object: outside the reference\'s reachable states')
-        ar, ac = np.where(st[:, :, 8] == 1)
-        if len(ar) == 0:
+        if not (st[:, :, 8] == 1).any():
             raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # state_idxs[0][0], ray.py:454
-        grid = (st[:, :, :8] * np.arange(1, 9)).sum(axis=2).astype(np.uint8)
-        hold_vec = st[ar[0], ac[0], 9:]
-        hold = int(np.argmax(hold_vec)) + 1 if hold_vec.any() else 0
-        if getattr(self, '_scratch', None) is None:      # a second one-env engine, so the env's own state is untouched
-            self._scratch = CraftingWorldVecEnv(1, size=(S, S), obs_mode='state', device=self._vec.device, seed=0,
-                                                auto_reset=False, raster=self._raster)
-            self._scratch.reset()
-        # rendering needs only (grid, agent, hold); the scratch engine's init records are irrelevant -- and a reachable state
-        # may hold two sticks / breads / houses, which no init grid can (sample_state places one of each)
-        self._scratch.set_state(grid=grid[None], agent_rc=np.array([[ar[0], ac[0]]]), hold=np.array([hold]))
-        return self._scratch.render()[0].cpu().numpy().astype(self._dtype)
+        if st.min() < 0 or st.max() > 1:
+            raise ValueError('state must be a one-hot (0/1) array')
+        img = self._vec.render_states(st.astype(np.uint8)[None])[0].cpu().numpy()
+        return img.astype(self._dtype)
 
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         return self._vec.compute_reward(achieved_goal, desired_goal, info)
 
     def close(self):
         self._vec.close()
-        if getattr(self, '_scratch', None) is not None:
-            self._scratch.close()
 
 
 class CraftingWorldEnvFlat(CraftingWorldEnv):

@@ -176,6 +176,12 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
  * every obs_mode; ray.py:442-520). */
 int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);
 
+/* render(state) (ray.py:442-486) for caller-supplied one-hot states of ANY content: onehot is a DEVICE array [n_states][S][S][12]
+ * uint8 (S = the engine's size), out_frames a DEVICE array [n_states][4S][4S][3] uint16 -- the reference's image is the SUM of the
+ * colours of the objects in a cell (int; up to 8 x 255), the agent is the first cell (row-major) with channel 8 set and must exist,
+ * the held item's colour comes from the largest hold channel set anywhere.  Does not touch the engine's own state. */
+int cw_render_onehot(cw_engine *e, const uint8_t *onehot, int32_t n_states, uint16_t *out_frames, cw_stream_t stream);
+
 /* Dense state views written to caller-supplied DEVICE buffers (observation_vector_space,
  * ray.py:94-110): cw_export_grid -> [N][S][S] uint8 codes; cw_export_onehot -> [N][S][S][12]
  * uint8 0/1 (channels 0-7 objects, 8 agent, 9-11 held item at the agent cell). */

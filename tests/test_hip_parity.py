@@ -1598,3 +1598,56 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert d['n_gpus'] == 2 and d['steps'] == 12 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['dist_backend'] == 'gloo'
     assert d['config']['envs_per_gpu'] == 4096 and d['value'] > 0
     assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
+
+
+def _reference_render_of_any_state(state):
+    """ray.py:442-486 restated in numpy for a caller-supplied one-hot state (test-side oracle): sum of object colours per cell,
+    x4 upscale, agent = first cell with channel 8 set -> centre 2x2 white, bottom row of it in the colour of the largest hold
+    channel set anywhere."""
+    colors = np.array([(0, 0, 0), (110, 69, 39), (255, 105, 180), (100, 100, 200), (100, 100, 100), (0, 128, 0),
+                       (205, 133, 63), (197, 91, 97), (240, 230, 140)], dtype=np.int64)          # COLORS_N, ray.py:28-30
+    idx = np.where(state[:, :, 8] == 1)
+    ax, ay = idx[0][0], idx[1][0]
+    h, w = state.shape[:2]
+    objects_n = np.concatenate((np.zeros((h, w, 1), dtype=int), state[:, :, :8]), axis=2)
+    holding = np.concatenate((np.zeros((h, w, 1), dtype=int), state[:, :, 9:]), axis=2)
+    img = np.tensordot(objects_n, colors, axes=1)
+    img = np.repeat(np.repeat(img, 4, axis=0), 4, axis=1)
+    img[ax * 4 + 1:ax * 4 + 3, ay * 4 + 1:ay * 4 + 3, :] = 255
+    hold = np.max(np.argmax(holding, axis=2))
+    if hold != 0:
+        img[ax * 4 + 2:ax * 4 + 3, ay * 4 + 1:ay * 4 + 3] = colors[hold]
+    return img
+
+
+def test_render_of_arbitrary_one_hot_states():
+    """render(state) accepts ANY one-hot state, as the reference's does (ray.py:442-486): several objects in one cell (their
+    colours add), more than eight objects, several agent cells (the first counts), hold flags anywhere.  int64 façade: the
+    reference's image exactly; uint8 façade: modulo 256; batch entry point on the device."""
+    import gym_craftingworld_amd as cw
+    S = 9
+    rng = np.random.RandomState(12)
+    exact = cw.CraftingWorldEnv(size=(S, S), reference_dtypes=True)
+    wrap = cw.CraftingWorldEnv(size=(S, S))
+    states = []
+    for trial in range(40):
+        st = (rng.rand(S, S, 12) < [0.02, 0.3, 0.08][trial % 3]).astype(int)
+        st[:, :, 8] = 0
+        for _ in range(1 + trial % 3):
+            st[rng.randint(S), rng.randint(S), 8] = 1
+        if trial % 4 == 0:
+            st[:, :, 9:] = 0
+        states.append(st)
+        ref = _reference_render_of_any_state(st)
+        got = exact.render(state=st)
+        assert got.dtype == np.int64 and np.array_equal(got, ref), trial
+        assert np.array_equal(wrap.render(state=st), (ref % 256).astype(np.uint8)), trial
+    assert max(int(_reference_render_of_any_state(s).max()) for s in states) > 255          # sums above one byte were exercised
+    batch = exact._vec.render_states(np.stack(states)).cpu().numpy().astype(np.int64)
+    for i, st in enumerate(states):
+        assert np.array_equal(batch[i], _reference_render_of_any_state(st)), i
+    with pytest.raises(IndexError):
+        exact.render(state=np.zeros((S, S, 12), int))                                         # no agent: ray.py:454 raises too
+    with pytest.raises(ValueError):
+        exact.render(state=np.zeros((S + 1, S, 12), int))
+    exact.close(); wrap.close()
