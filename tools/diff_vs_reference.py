@@ -4,7 +4,7 @@ step, on many seeds and configs -- a wider net than the committed fixtures.  Com
 achieved/desired vectors, one-hot state, observation / desired_goal / init_observation images and
 the MT19937 state after every reset.  Prints a summary; exits non-zero on the first mismatch.
 
-    python tools/diff_vs_reference.py [n_seeds]
+    python tools/diff_vs_reference.py [n_seeds [ray|alt|flat|onehot ...]]
 """
 import os
 import sys
@@ -29,6 +29,19 @@ CONFIGS = [
     (dict(size=(12, 12), max_steps=100, reward_style='subset', selected_tasks=['EatBread', 'MakeBread'], number_of_tasks=1), 300),
 ]
 # the same through CraftingWorldEnvAltObs (3x3-px CPV rasteriser); images compared as uint8 views
+# CraftingWorldEnvFlat (bare frame returned; no fixed_init_state kwarg; {} = its own 8x8 / 100-step defaults) and
+# CraftingWorldEnvOneHot (every observation a one-hot state; desired_goal = imagine_obs' final state, un-rendered)
+FLAT_CONFIGS = [
+    (dict(), 400),
+    (dict(size=(5, 5), max_steps=30, reward_style='subset'), 400),
+    (dict(size=(11, 11), max_steps=80, selected_tasks=T[2:7], number_of_tasks=3), 300),
+]
+ONEHOT_CONFIGS = [
+    (dict(size=(21, 21), max_steps=150), 300),
+    (dict(size=(5, 5), max_steps=30), 500),
+    (dict(size=(7, 7), max_steps=40, fixed_init_state=3, reward_style='subset'), 400),
+    (dict(size=(8, 8), max_steps=60, stacking=False, selected_tasks=T[::-1]), 300),
+]
 ALT_CONFIGS = [
     (dict(size=(21, 21), max_steps=120), 300),
     (dict(size=(5, 5), max_steps=30), 500),
@@ -36,13 +49,30 @@ ALT_CONFIGS = [
 ]
 
 
-def compare(env, ora, tag):
+def one_hot(grid, agent, hold=0):
+    oh = np.zeros(grid.shape + (12,), dtype=np.uint8)
+    r, c = np.nonzero(grid)
+    oh[r, c, grid[r, c] - 1] = 1
+    oh[agent[0], agent[1], 8] = 1
+    if hold:
+        oh[agent[0], agent[1], 8 + hold] = 1
+    return oh
+
+
+def compare(env, ora, tag, variant='ray', returned=None):
     codes, agent, hold = codes_from_onehot(env.obs_one_hot)
     s = ora.state()
     assert np.array_equal(codes, s['grid']), (tag, 'grid')
     assert agent == s['agent'] and hold == s['hold'], (tag, 'agent/hold')
     assert bits(env.achieved_goal_vector) == s['achieved'] and bits(env.desired_goal_vector) == s['desired'], (tag, 'goals')
-    assert np.array_equal(env.obs_image.astype(np.uint8), s['obs']), (tag, 'obs image')
+    if variant == 'onehot':        # obs_image IS obs_one_hot there (carftingworld_onehot.py:203)
+        assert np.array_equal(env.obs_image.astype(np.uint8), one_hot(s['grid'], s['agent'], s['hold'])), (tag, 'one-hot observation')
+        if returned is not None:
+            assert np.array_equal(returned['observation'].astype(np.uint8), one_hot(s['grid'], s['agent'], s['hold'])), (tag, 'returned one-hot')
+    else:
+        assert np.array_equal(env.obs_image.astype(np.uint8), s['obs']), (tag, 'obs image')
+        if variant == 'flat' and returned is not None:
+            assert returned is env.obs_image, (tag, 'flat returns the frame itself')
     assert env.step_num == s['step_num'] and env.ep_no == s['ep_no'], (tag, 'counters')
 
 
@@ -50,43 +80,56 @@ def main(n_seeds):
     classes = import_reference()
     total_steps = total_resets = successes = 0
     t0 = time.time()
-    todo = [(classes['ray'], False, kw, steps) for kw, steps in CONFIGS] + [(classes['altobs'], True, kw, steps) for kw, steps in ALT_CONFIGS]
-    for ci, (cls, alt, kw, steps) in enumerate(todo):
+    todo = ([(classes['ray'], 'ray', kw, steps) for kw, steps in CONFIGS] + [(classes['altobs'], 'alt', kw, steps) for kw, steps in ALT_CONFIGS] +
+            [(classes['flat'], 'flat', kw, steps) for kw, steps in FLAT_CONFIGS] + [(classes['onehot'], 'onehot', kw, steps) for kw, steps in ONEHOT_CONFIGS])
+    only = set(sys.argv[2:])
+    for ci, (cls, variant, kw, steps) in enumerate(todo):
+        if only and variant not in only:
+            continue
+        alt = variant == 'alt'
         for seed in range(n_seeds):
             rng = np.random.RandomState(10_000 * ci + seed)
             st = rng.get_state()
             env = make_ref_env(cls, rng, **kw)
-            ora = OracleEnv(rng_state=(st[1].copy(), int(st[2])), alt_obs=alt, **kw)
+            okw = dict(kw)
+            okw.setdefault('size', (env.STATE_W, env.STATE_H))       # (Flat's own defaults when none were given)
+            okw.setdefault('max_steps', env.MAX_STEPS)
+            ora = OracleEnv(rng_state=(st[1].copy(), int(st[2])), alt_obs=alt, **okw)
             pol = np.random.RandomState(seed)
 
             def do_reset():
                 o = env.reset()
                 oo = ora.reset()
                 s = ora.state()
-                assert np.array_equal(o['desired_goal'].astype(np.uint8), oo['desired_goal']), (ci, seed, 'desired_goal image')
-                assert np.array_equal(o['init_observation'].astype(np.uint8), oo['init_observation'])
+                if variant == 'onehot':
+                    assert np.array_equal(o['desired_goal'].astype(np.uint8), one_hot(s['goal_grid'], s['goal_agent'])), (ci, seed, 'goal state')
+                    assert np.array_equal(o['init_observation'].astype(np.uint8), one_hot(s['init_grid'], s['init_agent'])), (ci, seed, 'init state')
+                else:
+                    d_img, i_img = (env.desired_goal, env.INIT_OBS) if variant == 'flat' else (o['desired_goal'], o['init_observation'])
+                    assert np.array_equal(d_img.astype(np.uint8), oo['desired_goal']), (ci, seed, 'desired_goal image')
+                    assert np.array_equal(i_img.astype(np.uint8), oo['init_observation'])
                 icodes, iagent, _ = codes_from_onehot(env.INIT_OBS_VECTOR)
                 assert np.array_equal(icodes, s['init_grid'])
                 k, p = ora.get_rng()
                 rs = env.np_random.get_state()
                 assert p == rs[2] and np.array_equal(k, rs[1]), (ci, seed, 'rng state')
-                compare(env, ora, (ci, seed, 'reset'))
+                compare(env, ora, (ci, seed, 'reset'), variant, o)
 
             do_reset()
             total_resets += 1
             for t in range(steps):
                 a = int(pol.randint(6)) if (seed % 2 == 0 or pol.rand() < 0.2) else scripted_action(env, pol)
-                _, r, d, info = env.step(a)
+                ret, r, d, info = env.step(a)
                 _, r2, d2, info2 = ora.step(a)
                 assert (r, d) == (r2, d2), (ci, seed, t, 'reward/done', r, r2, d, d2)
-                compare(env, ora, (ci, seed, t))
+                compare(env, ora, (ci, seed, t), variant, ret)
                 successes += int(r == env.MAX_STEPS)
                 total_steps += 1
                 if d:
                     do_reset()
                     total_resets += 1
     print('reference == oracle on %d steps, %d resets, %d successful episodes, %d configs x %d seeds (%.1f s)' % (
-        total_steps, total_resets, successes, len(todo), n_seeds, time.time() - t0))
+        total_steps, total_resets, successes, len([t for t in todo if not only or t[1] in only]), n_seeds, time.time() - t0))
 
 
 if __name__ == '__main__':
