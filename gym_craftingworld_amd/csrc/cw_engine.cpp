@@ -29,6 +29,7 @@ hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
 int cwk_render_jobs(const CwParams *P, const CwTuning *T);
+hipError_t cwk_launch_idle(hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
 
@@ -237,9 +238,17 @@ static void prof_free(cw_engine *e)
 }
 
 // Pace of the linear-sweep render (cw_kernels.hip: render_groups): idle clocks per pair of jobs.  The write path is less
-// efficient saturated than kept just short of saturation, and where that point lies depends on the box (memory clocks, the
-// XCDs' relative speed) and on the shape (job size, batch): so it is measured here, on the engine's own buffers -- the median of
-// a few launches per candidate, 0..12 sleeps of 64 clocks -- and only performance depends on the outcome.
+// efficient saturated than kept just short of saturation.
+//
+// Ray raster: the pace is FIXED at m+1 (one s_sleep inside every job, one more per pair of jobs).  Round 2 measured it at cw_create
+// (median launch time per candidate) and followed it with an online tuner; later in round 2 both were compared with forced paces, alternating on
+// one box, several boxes (profiles/r02_pace.txt): inside a step sequence m+0 and m+1 are the two best everywhere and within 0.5 % of
+// each other (0.2343-0.2360 vs 0.2349-0.2363 ms), m+0 is bistable on some boxes (0.235 or 0.25-0.26), m+2 costs 3.5 %; the
+// launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace (0.2298-0.2455 ms for m+0) -- more than
+// the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the processes, and the tuner, hill-climbing
+// on a bistable neighbour, sat 3-7 % above fixed m+1 (0.2419-0.2522 vs 0.2352 ms).  CW_TUNE_RENDER_CALIBRATE=1 brings the
+// measurement back (other shapes, other hardware), CW_TUNE_RENDER_ADAPT=1 the tuner, CW_TUNE_RENDER_PACE=n forces a pace.
+// AltObs raster: measured here as before (0..6 sleeps per 1-KiB store; the optimum is flat and broad there).
 static int calibrate_render_pace(cw_engine *e, bool refine)
 {
     CwTuning &tn = e->tune;
@@ -253,34 +262,48 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     if (alt) e->P.alt_pace = 2;                           // (engines that are not calibrated: mid-range)
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions) return CW_OK;      // (the Ray raster is paced in both of its kernels)
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return fail(CW_ERR_HIP, "cw_create: event creation failed");
+    if (!alt && !(getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0)) {
+        tn.render_pace = 0x101;
+        return CW_OK;
+    }
+    // The launches of one candidate are queued back to back and the host waits once, at the end: a host round trip after every
+    // launch lets the card idle for tens of microseconds each time, and what is measured then is a memory system that keeps
+    // leaving and re-entering its busy state (the same kernel on the same buffer reads 0.225 or 0.28 ms that way,
+    // tools/microbench/time_render.py placement) -- not the regime a step sequence runs in.
+    enum { CALIB_LAUNCHES = 9, CALIB_SKIP = 3 };
+    hipEvent_t evs[2 * CALIB_LAUNCHES] = {};
+    for (hipEvent_t &ev : evs)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            for (hipEvent_t &d : evs) if (d) (void)hipEventDestroy(d);
+            return fail(CW_ERR_HIP, "cw_create: event creation failed");
+        }
     int blocks = 0, wpb = 0, rc = CW_OK;
     auto median_ms = [&](int pace, double *out) -> int {
         const int saved = tn.render_pace, saved_alt = e->P.alt_pace;
         tn.render_pace = pace;
         if (alt) e->P.alt_pace = pace;
-        float ms[5];
-        for (int rep = 0; rep < 6; rep++) {                                      // first launch discarded
-            if (hipEventRecord(ev0, nullptr) != hipSuccess ||
-                cwk_launch_render_calib(&e->P, &tn, nullptr, tn.render_q_all, tn.render_fast_parity, &blocks, &wpb) != hipSuccess ||
-                hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
-                (rep > 0 && hipEventElapsedTime(&ms[rep - 1], ev0, ev1) != hipSuccess)) {
-                tn.render_pace = saved;
-                e->P.alt_pace = saved_alt;
-                return fail(CW_ERR_HIP, "cw_create: render pace calibration failed");
-            }
-        }
+        bool ok = true;
+        for (int rep = 0; rep < CALIB_LAUNCHES && ok; rep++)             // (a short idle kernel between launches, like the step kernel)
+            ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess &&
+                 cwk_launch_render_calib(&e->P, &tn, nullptr, tn.render_q_all, tn.render_fast_parity, &blocks, &wpb) == hipSuccess &&
+                 hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
+        ok = ok && hipDeviceSynchronize() == hipSuccess;
         tn.render_pace = saved;
         e->P.alt_pace = saved_alt;
-        for (int i = 1; i < 5; i++) for (int j = i; j > 0 && ms[j] < ms[j - 1]; j--) { const float t = ms[j]; ms[j] = ms[j - 1]; ms[j - 1] = t; }
-        *out = ms[2];
+        float ms[CALIB_LAUNCHES];
+        for (int rep = 0; rep < CALIB_LAUNCHES && ok; rep++) ok = hipEventElapsedTime(&ms[rep], evs[2 * rep], evs[2 * rep + 1]) == hipSuccess;
+        if (!ok) return fail(CW_ERR_HIP, "cw_create: render pace calibration failed");
+        float *m = ms + CALIB_SKIP;                                             // (the first launches bring the card up to speed)
+        const int n = CALIB_LAUNCHES - CALIB_SKIP;
+        for (int i = 1; i < n; i++) for (int j = i; j > 0 && m[j] < m[j - 1]; j--) { const float t = m[j]; m[j] = m[j - 1]; m[j - 1] = t; }
+        *out = m[n / 2];
         return CW_OK;
     };
     int best = tn.render_pace;
     double best_ms = 0, t = 0;
     char log[400] = "";
     size_t len = 0;
+    if (!refine) for (int i = 0; i < 3 && rc == CW_OK; i++) rc = median_ms(alt ? 2 : 0x101, &t);   // the card up to speed before the first candidate is timed
     auto try_pace = [&](int pace) {
         rc = median_ms(pace, &t);
         if (rc == CW_OK && (best_ms == 0 || t < best_ms)) { best_ms = t; best = pace; }
@@ -296,8 +319,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
         const int mid = tn.render_pace & 0x100, p0 = tn.render_pace & 0xFF;
         for (int pp = (p0 > 0 ? p0 - 1 : 0); pp <= p0 + 1 && rc == CW_OK; pp++) try_pace(mid | pp);
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+    for (hipEvent_t &ev : evs) (void)hipEventDestroy(ev);
     if (rc != CW_OK) return rc;
     if (alt) e->P.alt_pace = best;
     else tn.render_pace = best;
@@ -374,6 +396,9 @@ static int calibrate_render_shares(cw_engine *e)
     tn.render_fast_parity = -1;
     const char *off = getenv("CW_TUNE_RENDER_SHARES");
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (off && atoi(off) == 0)) return CW_OK;   // (host-mapped frames: PCIe-bound anyway)
+    // the paced linear sweep does not profit (m+1: 0.2349 / 0.2349 / 0.2356 ms with shares, 0.2355 / 0.2353 / 0.2349 with equal ones,
+    // alternating on one box, profiles/r02_pace.txt): the shares are for the frame-per-wave kernel; CW_TUNE_RENDER_SHARES=1 forces them
+    if (cwk_render_is_linear(&e->P, &tn) && !(off && atoi(off) != 0)) return CW_OK;
     if (const char *q = getenv("CW_TUNE_RENDER_QALL")) {          // forced (experiments): "q_all,parity"
         int qa = 0, par = -1;
         if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
@@ -384,17 +409,19 @@ static int calibrate_render_shares(cw_engine *e)
     if (rc != CW_OK) return rc;
     int blocks = 0, wpb = 0;
     e->P.render_stats = stats;
-    // busy[c] = summed busy time of the waves of workgroup-index parity c over 3 launches (after one warm-up launch)
+    // busy[c] = summed busy time of the waves of workgroup-index parity c over 3 launches, after 3 warm-up launches, all queued
+    // back to back (see calibrate_render_pace: no host round trip between launches)
     auto measure = [&](int q_all, int parity, double busy[2]) -> int {
-        busy[0] = busy[1] = 0;
-        for (int rep = 0; rep < 4; rep++) {
-            unsigned long long h[2] = {0, 0};
-            if (hipMemset(stats, 0, sizeof(h)) != hipSuccess ||
-                cwk_launch_render_calib(&e->P, &tn, nullptr, q_all, parity, &blocks, &wpb) != hipSuccess ||
-                hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(CW_ERR_HIP, "cw_create: render calibration failed");
-            if (rep > 0) { busy[0] += (double)h[0]; busy[1] += (double)h[1]; }
+        unsigned long long h[2] = {0, 0};
+        bool ok = true;
+        for (int rep = 0; rep < 6 && ok; rep++) {
+            if (rep == 3) ok = hipMemsetAsync(stats, 0, sizeof(h), nullptr) == hipSuccess;
+            ok = ok && cwk_launch_render_calib(&e->P, &tn, nullptr, q_all, parity, &blocks, &wpb) == hipSuccess;
         }
+        if (!ok || hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(CW_ERR_HIP, "cw_create: render calibration failed");
+        busy[0] = (double)h[0];
+        busy[1] = (double)h[1];
         return CW_OK;
     };
     const int jobs = cwk_render_jobs(&e->P, &tn);              // frames, or (frame, row group) pairs of the linear sweep
@@ -530,6 +557,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
+        tn.render_shape = geti("CW_TUNE_RENDER_SHAPE", tn.render_shape);
+        tn.render_flat = geti("CW_TUNE_RENDER_FLAT", tn.render_flat);
+        tn.render_flat_blocks_per_cu = geti("CW_TUNE_RENDER_FLAT_BLOCKS_PER_CU", tn.render_flat_blocks_per_cu);
+        if (tn.render_flat_blocks_per_cu < 1) tn.render_flat_blocks_per_cu = 1;
+        if (tn.render_flat_blocks_per_cu > 8) tn.render_flat_blocks_per_cu = 8;
+        if (tn.render_shape != 3 && tn.render_shape != 4) tn.render_shape = 0;
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
         if (tn.list_blocks < 1) tn.list_blocks = 1;
     }
@@ -625,7 +658,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
     if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
-        !getenv("CW_TUNE_RENDER_PACE") && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) &&
+        !getenv("CW_TUNE_RENDER_PACE") && getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) != 0 &&   // (opt-in, see adapt_tick)
         (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
         for (hipEvent_t &ev : a.ev)
