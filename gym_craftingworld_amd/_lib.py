@@ -78,6 +78,7 @@ ABI = {
     'cw_checkpoint_load': (C.c_int, [_VP, _VP, C.c_size_t]),
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
+    'cw_render_kernel_name': (C.c_char_p, [_VP]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
     'cw_synchronize': (C.c_int, [_VP, _VP]),
     'cw_lookahead_join': (C.c_int, [_VP, _VP]),

@@ -29,6 +29,7 @@ hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
 int cwk_render_jobs(const CwParams *P, const CwTuning *T);
+int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset);
 hipError_t cwk_launch_idle(hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
@@ -240,21 +241,25 @@ static void prof_free(cw_engine *e)
 // Pace of the linear-sweep render (cw_kernels.hip: render_groups): idle clocks per pair of jobs.  The write path is less
 // efficient saturated than kept just short of saturation.
 //
-// Ray raster: the pace is FIXED at m+1 (one s_sleep inside every job, one more per pair of jobs).  Round 2 measured it at cw_create
-// (median launch time per candidate) and followed it with an online tuner; later in round 2 both were compared with forced paces, alternating on
-// one box, several boxes (profiles/r02_pace.txt): inside a step sequence m+0 and m+1 are the two best everywhere and within 0.5 % of
-// each other (0.2343-0.2360 vs 0.2349-0.2363 ms), m+0 is bistable on some boxes (0.235 or 0.25-0.26), m+2 costs 3.5 %; the
-// launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace (0.2298-0.2455 ms for m+0) -- more than
-// the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the processes, and the tuner, hill-climbing
-// on a bistable neighbour, sat 3-7 % above fixed m+1 (0.2419-0.2522 vs 0.2352 ms).  CW_TUNE_RENDER_CALIBRATE=1 brings the
-// measurement back (other shapes, other hardware), CW_TUNE_RENDER_ADAPT=1 the tuner, CW_TUNE_RENDER_PACE=n forces a pace.
+// Ray raster: the pace is FIXED at m+0 (one s_sleep inside every job, none between jobs), and 3 per pair of jobs on top while envs
+// are being reset beside the sweep (cw_kernels.hip: render_groups).  Round 2 first measured it at cw_create (median launch time
+// per candidate) and followed it with an online tuner; then both were compared with forced paces, alternating on one box, several
+// boxes (profiles/r02_pace.txt): the launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace
+// (0.2298-0.2455 ms for m+0) -- more than the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the
+// processes, and the tuner, hill-climbing on such figures, sat 3-7 % above a fixed pace (0.2419-0.2522 vs 0.2352 ms).  Inside a
+// step sequence the order is the same on every box and shape tried: with the one-launch step m+0 beats m+1 by 2 % (0.2337 vs 0.2392,
+// 0.2475 vs 0.2528 ms on a slower box, five alternating runs each; 131 072 envs, 262 144 envs and 32x32 likewise), m+2 costs 2.5 %
+// more, unpaced 15 %; with resets beside every launch (episode phases spread out) the optimum is 2 or 3 sleeps per pair higher
+// depending on the box, and too few costs 8 % where too many costs 1.3 %.  CW_TUNE_RENDER_CALIBRATE=1 brings the measurement back
+// (other hardware), CW_TUNE_RENDER_ADAPT=1 the tuner, CW_TUNE_RENDER_PACE=n / CW_TUNE_RENDER_PACE_BESIDE=n force the two values.
 // AltObs raster: measured here as before (0..6 sleeps per 1-KiB store; the optimum is flat and broad there).
 static int calibrate_render_pace(cw_engine *e, bool refine)
 {
     CwTuning &tn = e->tune;
     const char *forced = getenv("CW_TUNE_RENDER_PACE");
     if (forced) {                                         // (256 + n: with the sleep inside each job)
-        tn.render_pace = atoi(forced) < 0 ? 0 : atoi(forced);
+        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
+        tn.render_pace = (atoi(forced) < 0 ? 0 : atoi(forced) & 0x1FF) | (((beside ? atoi(beside) : 3) & 15) << 12);
         if (e->P.raster == CW_RASTER_ALT) e->P.alt_pace = tn.render_pace & 0xFF;
         return CW_OK;
     }
@@ -263,7 +268,8 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions) return CW_OK;      // (the Ray raster is paced in both of its kernels)
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
     if (!alt && !(getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0)) {
-        tn.render_pace = 0x101;
+        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
+        tn.render_pace = 0x100 | (((beside ? atoi(beside) : 3) & 15) << 12);
         return CW_OK;
     }
     // The launches of one candidate are queued back to back and the host waits once, at the end: a host round trip after every
@@ -303,7 +309,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     double best_ms = 0, t = 0;
     char log[400] = "";
     size_t len = 0;
-    if (!refine) for (int i = 0; i < 3 && rc == CW_OK; i++) rc = median_ms(alt ? 2 : 0x101, &t);   // the card up to speed before the first candidate is timed
+    if (!refine) for (int i = 0; i < 3 && rc == CW_OK; i++) rc = median_ms(alt ? 2 : 0x100, &t);   // the card up to speed before the first candidate is timed
     auto try_pace = [&](int pace) {
         rc = median_ms(pace, &t);
         if (rc == CW_OK && (best_ms == 0 || t < best_ms)) { best_ms = t; best = pace; }
@@ -316,13 +322,13 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
         static const int cand[] = {0x100, 0x101, 0x102, 0x103, 0x104, 0, 1, 2, 3, 4, 6};
         for (size_t i = 0; i < sizeof(cand) / sizeof(cand[0]) && rc == CW_OK; i++) try_pace(cand[i]);
     } else {                                                                    // after the shares are known: the neighbours once more
-        const int mid = tn.render_pace & 0x100, p0 = tn.render_pace & 0xFF;
+        const int mid = tn.render_pace & 0x100, p0 = tn.render_pace & 0xFF;      // (bits 12-15, the extra beside resets, play no part here)
         for (int pp = (p0 > 0 ? p0 - 1 : 0); pp <= p0 + 1 && rc == CW_OK; pp++) try_pace(mid | pp);
     }
     for (hipEvent_t &ev : evs) (void)hipEventDestroy(ev);
     if (rc != CW_OK) return rc;
     if (alt) e->P.alt_pace = best;
-    else tn.render_pace = best;
+    else tn.render_pace = (best & 0x1FF) | (3 << 12);       // (+3 while envs are reset beside the launch, see render_groups)
     if (getenv("CW_TUNE_VERBOSE"))
         fprintf(stderr, "[craftingworld] render pace%s: ms per launch by sleeps per pair of jobs (m+: and one inside each job)%s -> %s%d\n",
                 refine ? " (with shares)" : "", log, (best & 0x100) ? "m+" : "", best & 0xFF);
@@ -557,12 +563,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
-        tn.render_shape = geti("CW_TUNE_RENDER_SHAPE", tn.render_shape);
-        tn.render_flat = geti("CW_TUNE_RENDER_FLAT", tn.render_flat);
-        tn.render_flat_blocks_per_cu = geti("CW_TUNE_RENDER_FLAT_BLOCKS_PER_CU", tn.render_flat_blocks_per_cu);
-        if (tn.render_flat_blocks_per_cu < 1) tn.render_flat_blocks_per_cu = 1;
-        if (tn.render_flat_blocks_per_cu > 8) tn.render_flat_blocks_per_cu = 8;
-        if (tn.render_shape != 3 && tn.render_shape != 4) tn.render_shape = 0;
+        tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
         if (tn.list_blocks < 1) tn.list_blocks = 1;
     }
@@ -813,10 +814,10 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
             const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
-            e->tune.render_pace = 0x100 | (pw < 0 ? -1 - pw : pw);
+            e->tune.render_pace = (e->tune.render_pace & 0xF000) | 0x100 | (pw < 0 ? -1 - pw : pw);
             e->adapt.seq++;
         } else {
-            e->tune.render_pace = 0x100 | e->adapt.cur;                           // a captured graph keeps the pace it was captured with
+            e->tune.render_pace = (e->tune.render_pace & 0xF000) | 0x100 | e->adapt.cur;                           // a captured graph keeps the pace it was captured with
         }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
@@ -930,6 +931,14 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     }
     prof_free(e);
     return CW_OK;
+}
+
+const char *cw_render_kernel_name(const cw_engine *e)
+{
+    if (!e || e->obs_mode == CW_OBS_STATE) return "";
+    if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
+    if (!cwk_render_is_linear(&e->P, &e->tune)) return "cw_render_frames_kernel";
+    return cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) ? "cw_render_step_kernel" : "cw_render_kernel";
 }
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out)

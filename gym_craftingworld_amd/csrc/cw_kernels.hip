@@ -443,12 +443,12 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
 // The done counter is zeroed for the next step by the LAST workgroup of the last kernel that reads
 // it (a ticket in done_count[1]) -- no host-side parity and no memset node, so one cw_step is a
 // fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is.
-__device__ __forceinline__ void release_done_list(const CwParams &P)
+__device__ __forceinline__ void release_done_list(const CwParams &P, int n_blocks)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         const int t = atomicAdd(&P.done_count[1], 1);
-        if (t == (int)gridDim.x - 1) {
+        if (t == n_blocks - 1) {
             P.done_count[0] = 0;
             P.done_count[1] = 0;
         }
@@ -768,13 +768,15 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
     }
 }
 
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs, int paint)
+// (bid of n_blocks: the workgroup's index among the resetting workgroups -- the whole grid for cw_reset_kernel, the grid's tail
+// for cw_render_step_kernel)
+__device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s_mt)[CW_MT_WORDS], int bid, int n_blocks,
+                                                 int last_reader, int all_envs, int paint)
 {
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
-    const int n_waves = gridDim.x * CW_RESET_WAVES;
+    const int wave = bid * CW_RESET_WAVES + wave_in_block;
+    const int n_waves = n_blocks * CW_RESET_WAVES;
     // few, latency-critical waves sharing CUs with the render kernel's store-bound waves: win arbitration
     if (P.tune_reset_prio == 1) __builtin_amdgcn_s_setprio(3);
     // the wave's first list entry is fetched together with the count (entries past the count are stale but in bounds)
@@ -798,7 +800,13 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
         }
         if (paint) paint_reset_frames(P, env, r, lane);
     }
-    if (!all_envs && last_reader) release_done_list(P);
+    if (!all_envs && last_reader) release_done_list(P, n_blocks);
+}
+
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs, int paint)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    reset_list_block(P, s_mt, (int)blockIdx.x, (int)gridDim.x, last_reader, all_envs, paint);
 }
 
 // T consecutive steps of every env in ONE persistent launch (state-only observation mode): each
@@ -1260,7 +1268,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
     const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform)
     const bool want_done = (MODE == 3) && skip_done;
-    if (want_done && (pace & 0x100) && cload(P.done_count) > 0) pace += 1;   // envs being reset beside this launch: see render_groups
+    if (want_done && cload(P.done_count) > 0) pace += (pace >> 12) & 15;     // envs being reset beside this launch: see render_groups
     const bool classes = (MODE == 2 || MODE == 3) && fast_parity >= 0;
     if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
     const int n_fast = (gridDim.x / 2) * wpb;                              // (classes only: the grid is even)
@@ -1321,66 +1329,24 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
 // (0.2407 vs 0.2471 ms) -- the smoother the stream of stores, the better.  So a wave sleeps 64 clocks in the middle of
 // a job's stores (`pace` bit 8) and `pace & 0xFF` x 64 clocks per pair of jobs; cw_create finds both on the box it runs on,
 // as it does the XCD shares.
-//
-// STORE SHAPE (template W).  W = 0: lane = cell, 4 stores of 12 B at the cell's 4 pixel rows (each instruction writes gr runs of
-// 12*S bytes).  W = 3 / 4: the job's 48*gr*S bytes as 12/W CONTIGUOUS stores of W dwords per lane -- lane l of store k writes
-// dwords [(k*L + l)*W, +W) of the job (L = gr*S lanes), exactly the shape of a plain fill.  Those dwords belong to one (W = 3) or
-// two (W = 4) cell pixel rows, fixed per (k, lane) for the whole launch: the cells' colours come from the lanes that computed
-// them with ds_bpermute (lane = cell, as before), the bytes are put in place with v_perm_b32 under per-lane constant selectors.
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-template <int W>
-struct CwContigLane {                       // constants of lane l for its k-th store of every job
-    static constexpr int NS = W ? 12 / W : 1;
-    uint32_t a4[NS], b4[NS];                // 4 x local cell index of the chunk's first / second cell pixel row (ds_bpermute address)
-    uint32_t pa[NS], pb[NS];                // their pixel rows 0..3
-    uint32_t sel[NS][W ? W : 1];            // v_perm_b32 selector of dword j: bytes 0-2 = the cell colour, 4-6 = the overlay colour
-    uint32_t use_b[NS];                     // bit j: dword j belongs to the second cell pixel row
-    uint32_t d0[NS];                        // the chunk's first dword within the job
-};
-template <int W>
-__device__ __forceinline__ void contig_lane_init(CwContigLane<W> &C, int lane, int S, int L)
-{
-    if constexpr (W != 0) {
-#pragma unroll
-    for (int k = 0; k < CwContigLane<W>::NS; k++) {
-        const uint32_t D0 = (uint32_t)(k * L + lane) * W;
-        C.d0[k] = D0;
-        const uint32_t ua = D0 / 3u, ub = ua + 1u;
-        auto cell_of = [&](uint32_t u, uint32_t &prow) {
-            const uint32_t r = u / (4u * S), rem = u - r * 4u * S;
-            prow = rem / (uint32_t)S;
-            return (r * S + (rem - prow * S)) * 4u;
-        };
-        C.a4[k] = cell_of(ua, C.pa[k]);
-        C.b4[k] = cell_of(ub, C.pb[k]);
-        C.use_b[k] = 0;
-#pragma unroll
-        for (int j = 0; j < (W ? W : 1); j++) {
-            const uint32_t D = D0 + j, ph = D - (D / 3u) * 3u;
-            if (D / 3u != ua) C.use_b[k] |= 1u << j;
-            C.sel[k][j] = ph == 0 ? 0x04020100u : ph == 1 ? 0x05040605u : 0x02010006u;   // R G B r | g b r g | b R G B (capitals: cell colour)
-        }
-    }
-    }
-}
-
-template <int MODE, int W>
-__device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
+template <int MODE>
+__device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
+                                              int bid, int n_blocks)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * wpb + wave_in_block;
-    const int n_waves = gridDim.x * wpb;
+    const int wave = bid * wpb + wave_in_block;
+    const int n_waves = n_blocks * wpb;
     const int S = P.size, gr = P.grp_rows, G = P.grp_per_frame;
     const int n_jobs = P.n_envs * G;                                         // (the launcher checked that this fits)
     if (wave >= n_jobs) return;
     const bool want_done = (MODE == 3) && skip_done;
     const bool classes = fast_parity >= 0;
     if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
-    const int n_fast = (gridDim.x / 2) * wpb;
-    const bool fast = classes && (int)(blockIdx.x & 1u) == fast_parity;
-    const int fast_rank = (int)(blockIdx.x >> 1) * wpb + wave_in_block;
+    const int n_fast = (n_blocks / 2) * wpb;
+    const bool fast = classes && (bid & 1) == fast_parity;
+    const int fast_rank = (bid >> 1) * wpb + wave_in_block;
     const int tail0 = q_all * n_waves;
     const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
     // lane -> cell of the group, once
@@ -1391,16 +1357,15 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     const uint32_t v_off = 4u * r_local * row_bytes + 12u * c_local;
     const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
     uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
-    CwContigLane<W> C;
-    contig_lane_init<W>(C, lane, S, gr * S);
     // a render wave shares its SIMD with at most a few resetting waves (side stream): it wins the issue slot, they have the whole
     // launch to finish (with the reset waves raised instead, as in round 1, the spread-out-phases step is 3-8 % slower)
     if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    // sleeps of 64 clocks per pair of jobs; one more while envs are being reset beside this launch (side stream): with the resetting
-    // waves' traffic in the memory system the optimum moves up by one -- phases spread out, m+1 vs m+2: 0.276-0.281 vs 0.255 ms on one
-    // box, 0.253 vs 0.255 on another (profiles/r02_pace.txt).  (done_count is zeroed by the reset kernel's last workgroup: a wave that
-    // starts after that paces like a launch with nothing beside it, which is what it then is.)
-    const int pace_pair = (pace & 0xFF) + ((want_done && (pace & 0x100) && cload(P.done_count) > 0) ? 1 : 0);
+    // sleeps of 64 clocks per pair of jobs (pace bits 0-7), and `pace` bits 12-15 more while envs are being reset beside this sweep
+    // (the launch's resetting workgroups, or the reset kernel on the side stream): their unpaced bursts push a write path that sits
+    // just short of saturation over the edge -- phases spread out, 2 / 3 / 4 sleeps per pair in all: 0.268 / 0.248 ms on one box,
+    // 0.2518 / 0.2549 / 0.259 on another (profiles/r02_pace.txt, r02_fused_render.txt).  (done_count is zeroed by the last resetting
+    // workgroup: a wave that starts after that paces like a launch with nothing beside it, which is what it then is.)
+    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) > 0) ? ((pace >> 12) & 15) : 0);
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
     CW_WAVE_CLOCK(t_start);
     if (MODE == 3) CW_WAVE_STAMP(wave, 0);
@@ -1450,232 +1415,41 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
             const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
             const uint32_t hold = (hx >> 16) & 0xFFu;
             const uint32_t hold_rgb = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;
-            if constexpr (W == 0) {
-                const u32x3 d = cell_row_dwords(col);
-                const bool ag = (cell == agent_cell);
-                const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
-                const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
-                if (lane_in_group && row0 + r_local < (uint32_t)S) {
-                    uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes + v_off;
-                    *(u32x3_a4 *)(q) = d;
-                    *(u32x3_a4 *)(q + row_bytes) = d1;
-                    if (pace_mid) __builtin_amdgcn_s_sleep(1);                // (see PACING above)
-                    *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
-                    *(u32x3_a4 *)(q + 3 * row_bytes) = d;
-                }
-            } else {
-                const uint32_t agent4 = (agent_cell - row0 * S) << 2;          // (wraps far out of range when the agent is in another group)
-                const uint32_t valid_dw = 12u * S * (uint32_t)min(gr, S - (int)row0);
-                uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes;
-#pragma unroll
-                for (int s = 0; s < CwContigLane<W>::NS; s++) {
-                    const uint32_t ca = (uint32_t)__builtin_amdgcn_ds_bpermute((int)C.a4[s], (int)col);
-                    const bool mid_a = C.pa[s] == 1u || C.pa[s] == 2u;
-                    const uint32_t oa = (C.a4[s] == agent4 && mid_a) ? (C.pa[s] == 1u ? 0x00FFFFFFu : hold_rgb) : ca;   // ray.py:483-486
-                    uint32_t dw[W ? W : 1];
-                    if constexpr (W == 3) {
-#pragma unroll
-                        for (int j = 0; j < 3; j++) dw[j] = __builtin_amdgcn_perm(oa, ca, C.sel[s][j]);
-                    } else {
-                        const uint32_t cb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)C.b4[s], (int)col);
-                        const bool mid_b = C.pb[s] == 1u || C.pb[s] == 2u;
-                        const uint32_t ob = (C.b4[s] == agent4 && mid_b) ? (C.pb[s] == 1u ? 0x00FFFFFFu : hold_rgb) : cb;
-#pragma unroll
-                        for (int j = 0; j < W; j++) {
-                            const bool ub = (C.use_b[s] >> j) & 1u;
-                            const uint32_t cx = ub ? cb : ca, ox = ub ? ob : oa;
-                            dw[j] = __builtin_amdgcn_perm(ox, cx, C.sel[s][j]);
-                        }
-                    }
-                    if (lane_in_group && C.d0[s] < valid_dw) {
-                        if constexpr (W == 3) {
-                            u32x3 v; v.x = dw[0]; v.y = dw[1]; v.z = dw[2];
-                            *(u32x3_a4 *)(q + 4u * C.d0[s]) = v;
-                        } else {
-                            u32x4_a4 v; v.x = dw[0]; v.y = dw[1]; v.z = dw[2]; v.w = dw[3];
-                            *(u32x4_a4 *)(q + 4u * C.d0[s]) = v;
-                        }
-                    }
-                    if (s == 1 && pace_mid) __builtin_amdgcn_s_sleep(1);     // (see PACING above)
-                }
+            const u32x3 d = cell_row_dwords(col);
+            const bool ag = (cell == agent_cell);
+            const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
+            const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
+            if (lane_in_group && row0 + r_local < (uint32_t)S) {
+                uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes + v_off;
+                *(u32x3_a4 *)(q) = d;
+                *(u32x3_a4 *)(q + row_bytes) = d1;
+                if (pace_mid) __builtin_amdgcn_s_sleep(1);                // (see PACING above)
+                *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
+                *(u32x3_a4 *)(q + 3 * row_bytes) = d;
             }
         }
     }
-    CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
+    CW_WAVE_BUSY(P, t_start, bid & 1);
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
-}
-
-// ---- FLAT SWEEP: the frame array as ONE byte stream cut into 128-B-aligned chunks ---------------------------------------------
-// What the write path rewards (tools/microbench/sweep_shapes.hip, profiles/r02_flat_sweep.txt): store instructions whose 768 bytes
-// start on a 128-B line -- 6.47 TB/s against 5.86 for the cell-row stores of render_groups and 5.99 for contiguous but unaligned
-// 756-B runs, same launch, same bytes; shifted by 16 or 32 B the aligned shape falls to the others' rate.  A frame is 48*S*S bytes
-// (21x21: 21 168 = 165.4 lines), so no partition by frames or grid rows can be aligned: the partition here ignores frames.  The
-// array is a sequence of UNITS of 12 B (one cell's 4 pixels on one pixel row; frames are whole numbers of units), a job is 256
-// consecutive units = 3072 B = 4 stores of 64 lanes x 12 B, job j starts at byte 3072*j, jobs go round-robin over the waves in
-// address order as in render_groups.  A job lies in one frame or straddles two (S >= 8, so a frame holds at least one job).
-//
-// Who paints what.  Nearly all units are black; the others belong to the <= 8 objects and the agent: 34 (cell, pixel row) pairs per
-// frame.  So the lanes do not look their colour up (8 compares per unit, 4 units per lane per job: 140 VALU instructions a job,
-// measured 7 % on the launch); the 34 pairs are SCATTERED instead: lane 4q+p takes object q's pixel row p (lanes 32, 33: the
-// agent's two marked rows on an empty cell), finds the unit's index t within the job, and if it is one of the job's 256 writes
-// colour | mark << 24 into word t of the wave's 1-KB LDS row (all zero otherwise).  Then every lane reads its 4 words, turns each
-// into the unit's 3 dwords with v_perm_b32 (mark 1: white on pixels 1-2, ray.py:483; mark 2: the held object's colour,
-// ray.py:484-486) and stores; the scattered words are zeroed again.  ~50 VALU + 5 LDS instructions a job.  A job over two
-// frames scatters twice (second frame's units start at t = split).  DS instructions of a wave execute in order: no barrier.
-template <int MODE>
-__device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                            uint32_t *__restrict__ row /* this wave's 256 LDS words */)
-{
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wpb = blockDim.x / CW_WAVE;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * wpb + wave_in_block;
-    const int n_waves = gridDim.x * wpb;
-    const uint32_t S = (uint32_t)P.size, UF = 4u * S * S;                     // units per frame
-    const uint32_t total_units = (uint32_t)P.n_envs * UF;                     // (the launcher checked that this fits 31 bits)
-    const int n_jobs = (int)((total_units + 255u) >> 8);
-    if (wave >= n_jobs) return;
-    const bool want_done = (MODE == 3) && skip_done;
-    const bool classes = fast_parity >= 0;
-    if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
-    const int n_fast = (gridDim.x / 2) * wpb;
-    const bool fast = classes && (int)(blockIdx.x & 1u) == fast_parity;
-    const int fast_rank = (int)(blockIdx.x >> 1) * wpb + wave_in_block;
-    const int tail0 = q_all * n_waves;
-    const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
-    uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
-    const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
-    // the scatter lanes' constants
-    const uint32_t sq = (uint32_t)lane >> 2;                                 // object slot (lanes 0..31)
-    const uint32_t sprow = lane < 32 ? ((uint32_t)lane & 3u) : (uint32_t)lane - 31u;   // pixel row; the agent's lanes 32, 33: rows 1, 2
-    const bool s_obj = lane < 32, s_agent = lane == 32 || lane == 33;
-    const bool s_marked = sprow == 1u || sprow == 2u;
-    for (int i = 0; i < 4; i++) row[lane + 64 * i] = 0u;
-    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    const int pace_pair = pace & 0xFF;
-    const bool pace_mid = (pace & 0x100) != 0;
-    CW_WAVE_CLOCK(t_start);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
-    struct Rec { int env; uint32_t base_f, hx0, hw0, done0, hx1, hw1, done1; uint4 p0, p1; };
-    auto fetch = [&](int base) {
-        Rec r;
-        const int i = base + lane;
-        const int id = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
-        r.env = -1; r.base_f = 0; r.hx0 = r.hw0 = r.done0 = r.hx1 = r.hw1 = r.done1 = 0;
-        r.p0 = r.p1 = make_uint4(0, 0, 0, 0);
-        if (i < q_mine && id < n_jobs) {
-            const uint32_t u0 = (uint32_t)id << 8;
-            r.env = (int)(u0 / UF);
-            r.base_f = u0 - (uint32_t)r.env * UF;
-            const int e1 = min(r.env + 1, P.n_envs - 1);                     // (read whether or not the job reaches it: no divergence, ~1 % of the traffic)
-            const uint32_t *h0 = (const uint32_t *)(P.hdr + r.env), *h1 = (const uint32_t *)(P.hdr + e1);
-            r.hx0 = h0[0]; r.hw0 = h0[3]; r.p0 = P.pos[r.env];
-            r.hx1 = h1[0]; r.hw1 = h1[3]; r.p1 = P.pos[e1];
-            if (want_done) { r.done0 = P.done[r.env]; r.done1 = P.done[e1]; }   // (envs that finished are left to the resetting wave on the side stream)
-        }
-        return r;
-    };
-    // one frame's 34 (cell, pixel row) pairs into the LDS row; returns the word index written by this lane (or -1)
-    auto scatter = [&](uint32_t hx, uint32_t codes, const u32x4s &pp, int off) -> int {
-        const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
-        const uint32_t word = (sq >> 1) == 0u ? pp.x : (sq >> 1) == 1u ? pp.y : (sq >> 1) == 2u ? pp.z : pp.w;   // slots 2k, 2k+1 live in word k
-        const uint32_t cell_q = (word >> (16u * (sq & 1u))) & 0xFFFFu;
-        const uint32_t code = (codes >> (4u * (sq & 7u))) & 15u;
-        const uint32_t rgb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);
-        const bool on_agent = s_obj && cell_q == agent_cell;
-        const bool covered = CW_BALLOT(on_agent) != 0ull;                     // an object under the agent: its lanes carry the marks
-        const uint32_t cell = s_obj ? cell_q : agent_cell;
-        const bool live = s_obj ? cell_q < (uint32_t)P.ncell : (s_agent && !covered);
-        const uint32_t mark = (cell == agent_cell && s_marked) ? sprow : 0u;
-        const uint32_t r = __umulhi(cell, P.div_magic);
-        const int t = (int)(cell + (3u * r + sprow) * S) + off;               // unit index within the frame, then within the job
-        const bool in = live && (uint32_t)t < 256u;
-        if (in) row[t] = (s_obj ? rgb : 0u) | (mark << 24);
-        return in ? t : -1;
-    };
-    Rec nxt = fetch(0);
-    for (int base = 0; base < q_mine; base += CW_WAVE) {
-        const Rec cur = nxt;
-        if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
-        const int in_batch = min(q_mine - base, CW_WAVE);
-        for (int k = 0; k < in_batch; k++) {
-            if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
-            const int env = __builtin_amdgcn_readlane(cur.env, k);
-            if (env < 0) continue;
-            const uint32_t base_f = __builtin_amdgcn_readlane(cur.base_f, k);
-            const uint32_t split = UF - base_f;                               // first unit of the next frame, within the job (>= 256: none)
-            const bool two = split < 256u && env + 1 < P.n_envs;
-            const bool skip0 = want_done && __builtin_amdgcn_readlane(cur.done0, k) != 0u;
-            const bool skip1 = !two || (want_done && __builtin_amdgcn_readlane(cur.done1, k) != 0u);
-            if (skip0 && skip1) continue;
-            const uint32_t hx0 = __builtin_amdgcn_readlane(cur.hx0, k);
-            uint32_t hold_rgb0 = 0x00FFFFFFu, hold_rgb1 = 0x00FFFFFFu;
-            int t0 = -1, t1 = -1;
-            if (!skip0) {
-                u32x4s pp;
-                pp.x = __builtin_amdgcn_readlane(cur.p0.x, k);
-                pp.y = __builtin_amdgcn_readlane(cur.p0.y, k);
-                pp.z = __builtin_amdgcn_readlane(cur.p0.z, k);
-                pp.w = __builtin_amdgcn_readlane(cur.p0.w, k);
-                const uint32_t hold = (hx0 >> 16) & 0xFFu;
-                if (hold) hold_rgb0 = (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u);
-                t0 = scatter(hx0, __builtin_amdgcn_readlane(cur.hw0, k), pp, -(int)base_f);
-            }
-            if (!skip1) {
-                u32x4s pp;
-                pp.x = __builtin_amdgcn_readlane(cur.p1.x, k);
-                pp.y = __builtin_amdgcn_readlane(cur.p1.y, k);
-                pp.z = __builtin_amdgcn_readlane(cur.p1.z, k);
-                pp.w = __builtin_amdgcn_readlane(cur.p1.w, k);
-                const uint32_t hx1 = __builtin_amdgcn_readlane(cur.hx1, k);
-                const uint32_t hold = (hx1 >> 16) & 0xFFu;
-                if (hold) hold_rgb1 = (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u);
-                t1 = scatter(hx1, __builtin_amdgcn_readlane(cur.hw1, k), pp, (int)split);
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t w[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) w[s4] = row[lane + 64 * s4];
-            __builtin_amdgcn_wave_barrier();
-            if (t0 >= 0) row[t0] = 0u;
-            if (t1 >= 0) row[t1] = 0u;
-            const uint32_t u0 = (uint32_t)env * UF + base_f;                 // the job's first unit in the array
-            uint8_t *q = dst_base + (size_t)u0 * 12u + (uint32_t)lane * 12u;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                const uint32_t t = (uint32_t)lane + 64u * s4;
-                const bool second = t >= split;
-                const uint32_t mark = w[s4] >> 24;
-                const uint32_t held = second ? hold_rgb1 : hold_rgb0;
-                const uint32_t ov = mark == 0u ? w[s4] : (mark == 1u ? 0x00FFFFFFu : held);
-                u32x3 v;
-                v.x = __builtin_amdgcn_perm(ov, w[s4], 0x04020100u);         // R G B r | g b r g | b R G B  (capitals: the cell's colour)
-                v.y = __builtin_amdgcn_perm(ov, w[s4], 0x05040605u);
-                v.z = __builtin_amdgcn_perm(ov, w[s4], 0x02010006u);
-                const bool skip = second ? skip1 : skip0;
-                if (!skip && u0 + t < total_units) *(u32x3_a4 *)(q + 768u * s4) = v;
-                if (s4 == 1 && pace_mid) __builtin_amdgcn_s_sleep(1);        // (see PACING above)
-            }
-        }
-    }
-    CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
-}
-
-__global__ __launch_bounds__(256) void cw_render_flat_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
-{
-    __shared__ uint32_t s_row[4][256];
-    uint32_t *row = s_row[__builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE)];
-    if (mode == 3) render_flat<3>(P, skip_done, ext_out, q_all, fast_parity, pace, row);
-    else render_flat<2>(P, skip_done, ext_out, q_all, fast_parity, pace, row);
 }
 
 // the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
-template <int W>
 __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
 {
-    if (mode == 3) render_groups<3, W>(P, skip_done, ext_out, q_all, fast_parity, pace);
-    else render_groups<2, W>(P, skip_done, ext_out, q_all, fast_parity, pace);
+    if (mode == 3) render_groups<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
+    else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The FULL pixel step's render AND its auto-resets in one launch: the first render_blocks workgroups are the linear sweep over
+// the envs that go on (mode 3, skip_done), the rest are resetting workgroups over the done list (one wave per finished env, its
+// three frames painted by that wave) -- the pair that cwk_launch_step otherwise runs as two kernels on two streams with an event
+// fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
+// barrier packets: the render's part runs 3-6 % shorter without them (profiles/r02_fused_render.txt).
+__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    if ((int)blockIdx.x < render_blocks) render_groups<3>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
+    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
 // the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
 __global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
@@ -1833,15 +1607,7 @@ static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
     const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
     return tn.render_linear >= 2 || jobs <= 2560 * waves;
 }
-// flat sweep (render_flat): Ray raster, frames of at least one job (S >= 8), unit indices in 31 bits
-static inline int cw_render_flat(const CwParams &P, const CwTuning &tn)
-{
-    if (!tn.render_flat || P.raster != 0 || P.size < 8) return 0;
-    return (long long)P.n_envs * 4ll * P.size * P.size < (1ll << 31);
-}
-static inline int cw_render_flat_jobs(const CwParams &P) { return (int)(((long long)P.n_envs * 4ll * P.size * P.size + 255) >> 8); }
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
-static inline int cw_render_flat_grid(const CwParams &P, const CwTuning &tn);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
                                     int fast_parity, hipStream_t st);
 static inline int cw_render_grid(const CwTuning &tn, int jobs)
@@ -1862,24 +1628,8 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_render_flat(P, tn)) {
-        hipLaunchKernelGGL(cw_render_flat_kernel, dim3(cw_render_flat_grid(P, tn)), dim3(256), 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
-    } else if (cw_render_linear(P, tn)) {
-        auto k = tn.render_shape == 4 ? cw_render_kernel<4> : tn.render_shape == 3 ? cw_render_kernel<3> : cw_render_kernel<0>;
-        hipLaunchKernelGGL(k, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
-    }
+    if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
     else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
-}
-
-static inline int cw_render_flat_grid(const CwParams &P, const CwTuning &tn)
-{
-    // 4 waves per block, persistent; render_flat_blocks_per_cu blocks per CU (default 4 = half the wave slots: the reset kernel
-    // beside it needs the rest), an even number of blocks for the two XCD classes
-    const int jobs = cw_render_flat_jobs(P);
-    int blocks = (jobs + 3) / 4;
-    if (blocks > tn.n_cu * tn.render_flat_blocks_per_cu) blocks = tn.n_cu * tn.render_flat_blocks_per_cu;
-    if (blocks < 1) blocks = 1;
-    return blocks;
 }
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
@@ -1901,6 +1651,12 @@ static int cw_envs_per_wave(int n)
 }
 
 extern "C" {
+
+// FULL pixel step: render + auto-resets as one launch (cw_render_step_kernel)?
+int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset)
+{
+    return auto_reset && T->overlap && T->fused_render && !P->terminal_img && T->render_threads == 256 && cw_render_linear(*P, *T);
+}
 
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
 // while the side stream resets the done envs, the resetting waves painting their three frames; both join back into
@@ -1927,6 +1683,13 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev_all) (void)hipEventRecord(ev[1], st);
+    if (obs_mode == 1 && cwk_step_renders_fused(P, T, auto_reset)) {
+        if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
+        const int render_blocks = cw_render_grid(tn, n);
+        hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        if (ev) (void)hipEventRecord(ev[5], st);
+        return hipGetLastError();
+    }
     if (obs_mode == 1 && auto_reset && tn.overlap) {
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
@@ -2017,9 +1780,8 @@ hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStre
                                    int *waves_per_block)
 {
     const CwTuning &tn = *T;
-    const bool flat = cw_render_flat(*P, tn);
-    *blocks = flat ? cw_render_flat_grid(*P, tn) : cw_render_grid(tn, P->n_envs);
-    *waves_per_block = flat ? 4 : tn.render_threads / CW_WAVE;
+    *blocks = cw_render_grid(tn, P->n_envs);
+    *waves_per_block = tn.render_threads / CW_WAVE;
     cw_launch_render(*P, tn, 3, 0, nullptr, q_all, fast_parity, st);
     return hipGetLastError();
 }
@@ -2035,11 +1797,8 @@ hipError_t cwk_launch_idle(hipStream_t st)
     return hipGetLastError();
 }
 
-int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_flat(*P, *T) || cw_render_linear(*P, *T); }   // (a paced sweep)
-int cwk_render_jobs(const CwParams *P, const CwTuning *T)
-{
-    return cw_render_flat(*P, *T) ? cw_render_flat_jobs(*P) : cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs;
-}
+int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
+int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {

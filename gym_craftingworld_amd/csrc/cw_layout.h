@@ -53,11 +53,9 @@ struct CwTuning {
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
     int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
-    int render_flat = 0;            // full-frame render as a FLAT sweep (128-B-aligned 3072-B jobs that ignore frame boundaries; render_flat in cw_kernels.hip)
-    int render_flat_blocks_per_cu = 4;
-    int render_shape = 0;           // linear sweep's stores: 0 lane = cell, 4 x 12 B at the cell's pixel rows; 3 / 4: contiguous 12-B / 16-B chunks per lane
-    int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job;
-                                    //   cw_create calibrates it (cw_kernels.hip: PACING)
+    int fused_render = 1;           // FULL pixel step: render + auto-resets in ONE launch (cw_render_step_kernel) instead of two kernels on two streams
+    int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job,
+                                    // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x3100)
 };
 
 // Everything the kernels need, passed by value.

@@ -479,6 +479,10 @@ class CraftingWorldVecEnv:
         """Bracket each kernel of the following step() calls with HIP events on the launch stream."""
         L.check(self._lib.cw_profile_begin(self._h, int(max_steps)), 'cw_profile_begin')
 
+    def render_kernel_name(self):
+        """Name of the kernel `profile_end()['ms_render_kernel']` brackets (as a rocprofv3 kernel trace lists it)."""
+        return (self._lib.cw_render_kernel_name(self._h) or b'').decode()
+
     def profile_end(self):
         """-> dict of average per-launch kernel durations (ms) since profile_begin."""
         p = L.cw_profile()

@@ -158,8 +158,10 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
  * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
  * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
  * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues, in CW_OBS_PIXELS_FULL: step kernel,
- * then the render kernel with the reset kernel (ballot-compacted done list) beside it on an engine-owned stream that
- * forks from and joins back into `stream`; in the other modes one kernel that steps and resets inline.
+ * then ONE launch whose first workgroups render every env that goes on and whose last workgroups reset the finished envs
+ * (ballot-compacted done list) and paint their three frames (keep_terminal_obs engines and grids wider than 64 cells: the same
+ * two parts as two kernels, the resets on an engine-owned stream that forks from and joins back into `stream`); in the other
+ * modes one kernel that steps and resets inline.
  * With cw_config.host_outputs `actions` may be cw_buffer_table.host_actions. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
 
@@ -223,6 +225,10 @@ typedef struct cw_profile {
 } cw_profile;
 int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
+/* Name of the kernel that ms_render_kernel brackets for this engine (what a rocprofv3 kernel trace of the same run lists it as):
+ * "cw_render_step_kernel" (full-frame render + the auto-resets beside it, one launch), "cw_render_kernel" (linear sweep alone),
+ * "cw_render_frames_kernel" (frame per wave) or "" (CW_OBS_STATE: no render kernel).  A static string. */
+const char *cw_render_kernel_name(const cw_engine *e);
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out);
 /* Blocks the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize): the one host

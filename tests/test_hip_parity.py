@@ -1068,6 +1068,53 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,size', [(3000, 21), (65536, 21), (4099, 8), (2000, 32)])
+def test_full_pixel_step_launch_arrangements_agree(N, size, monkeypatch):
+    """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
+    sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
+    arrangements stay selectable -- two kernels on two streams (CW_TUNE_FUSED_RENDER=0), one stream with the resets first
+    (CW_TUNE_OVERLAP=0) -- and all three must leave exactly the frames, results and random streams of the dirty-cell engine,
+    with episodes ending on every step (phases spread out) and all at once."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    kw = dict(size=(size, size), max_steps=7, seed=29)
+    engines = {}
+    for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
+        if var:
+            monkeypatch.setenv(var, '0')
+        engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+        if var:
+            monkeypatch.delenv(var)
+    assert engines['one launch'].render_kernel_name() == 'cw_render_step_kernel'
+    assert engines['two streams'].render_kernel_name() == 'cw_render_kernel'
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    for e in list(engines.values()) + [dirty]:
+        e.reset()
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for t in range(20):
+        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen)
+        if t == 9:                                         # from here on the phases are spread out: env i has taken i % 7 steps
+            for e in list(engines.values()) + [dirty]:
+                e.set_state(step_num=(np.arange(N) % 7).astype(np.int32))
+        od, rd, dd, _ = dirty.step(a)
+        for name, e in engines.items():
+            o, r, d, _ = e.step(a)
+            assert torch.equal(o['observation'], od['observation']), (name, t, 'observation')
+            assert torch.equal(o['desired_goal'], od['desired_goal']), (name, t, 'desired_goal')
+            assert torch.equal(o['init_observation'], od['init_observation']), (name, t, 'init_observation')
+            assert torch.equal(r, rd) and torch.equal(d, dd), (name, t)
+        if t == 12:
+            for e in engines.values():
+                e._obs.fill_(9)                           # poison: a frame nobody paints would keep this value
+    kd, pd = dirty.get_rng_states()
+    for name, e in engines.items():
+        k, p_ = e.get_rng_states()
+        assert np.array_equal(k, kd) and np.array_equal(p_, pd), name
+        assert torch.equal(e.counters, dirty.counters), name
+        e.close()
+    dirty.close()
+
+
+@pytest.mark.gpu
 def test_long_reset_chains_on_one_stream_vs_oracle():
     """3 000 consecutive episodes on each of 256 MT19937 streams (max_steps=1: every step ends an episode), so that
     the lazily regenerated state is entered at every alignment and wraps hundreds of times per stream; state, goal

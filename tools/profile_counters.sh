@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box only: where do cw_render_kernel's cycles go?  One --pmc pass per counter group (SQ: 8 slots,
+# GPU box only: where do the render kernel's cycles go (cw_render_step_kernel; cw_render_kernel with CW_TUNE_FUSED_RENDER=0)?  One --pmc pass per counter group (SQ: 8 slots,
 # TCC: 4 slots per pass), kernel-trace only beside it.
 set -e -o pipefail
 export TMPDIR=/tmp

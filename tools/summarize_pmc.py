@@ -39,11 +39,13 @@ def main(out):
                 kern.setdefault(name, {})[c] = {'launches': len(v), 'mean_bytes': sum(v) / len(v) * 1024.0,
                                                 'median_bytes': v2[len(v2) // 2] * 1024.0}
     res['kernels'] = kern
-    r = kern.get('cw_render_kernel', {})
+    # the kernel of the full-frame render: one launch with the auto-resets (default) or the linear sweep alone
+    dom = 'cw_render_step_kernel' if 'cw_render_step_kernel' in kern else 'cw_render_kernel'
+    r = kern.get(dom, {})
     if 'WRITE_SIZE' in r and 'FETCH_SIZE' in r:
         w, f = r['WRITE_SIZE']['median_bytes'], r['FETCH_SIZE']['median_bytes']
         res['hbm_bytes_per_launch'] = w + 2.0 * f
-        res['hbm_bytes_per_launch_note'] = 'cw_render_kernel, median launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 read correction)'
+        res['hbm_bytes_per_launch_note'] = dom + ', median launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 read correction)'
         res['algorithmic_bytes_per_launch'] = 65536 * (441 + 21168.0)
     print(json.dumps(res, indent=1))
 
