@@ -937,8 +937,9 @@ const char *cw_render_kernel_name(const cw_engine *e)
 {
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
-    if (!cwk_render_is_linear(&e->P, &e->tune)) return "cw_render_frames_kernel";
-    return cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) ? "cw_render_step_kernel" : "cw_render_kernel";
+    const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+    if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
+    return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
 }
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out)

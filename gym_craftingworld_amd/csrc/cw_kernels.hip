@@ -1258,22 +1258,23 @@ __device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cu
 // calibration at cw_create (cw_engine.cpp).  fast_parity < 0: no classes, q_all covers everything.  The partition
 // depends on workgroup indices only, never on where a workgroup actually runs: coverage is exact either way.
 template <int MODE>
-__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace = 0)
+__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
+                                            int bid, int n_blocks)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * wpb + wave_in_block;
-    const int n_waves = gridDim.x * wpb;
+    const int wave = bid * wpb + wave_in_block;
+    const int n_waves = n_blocks * wpb;
     const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform)
     const bool want_done = (MODE == 3) && skip_done;
     if (want_done && cload(P.done_count) > 0) pace += (pace >> 12) & 15;     // envs being reset beside this launch: see render_groups
     const bool classes = (MODE == 2 || MODE == 3) && fast_parity >= 0;
     if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
-    const int n_fast = (gridDim.x / 2) * wpb;                              // (classes only: the grid is even)
-    const bool fast = classes && (int)(blockIdx.x & 1u) == fast_parity;
-    const int fast_rank = (int)(blockIdx.x >> 1) * wpb + wave_in_block;
+    const int n_fast = (n_blocks / 2) * wpb;                               // (classes only: the grid is even)
+    const bool fast = classes && (bid & 1) == fast_parity;
+    const int fast_rank = (bid >> 1) * wpb + wave_in_block;
     const int tail0 = q_all * n_waves;                                     // first frame of the fast class's extra rounds
     const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
     CW_WAVE_CLOCK(t_start);
@@ -1306,7 +1307,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
             render_one<MODE>(P, cur, want_done, ext_out, lane, pace);      // (env < 0: nothing to paint)
         }
     }
-    CW_WAVE_BUSY(P, t_start, blockIdx.x & 1u);
+    CW_WAVE_BUSY(P, t_start, bid & 1);
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
@@ -1451,19 +1452,26 @@ __global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int ren
     if ((int)blockIdx.x < render_blocks) render_groups<3>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
+// the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
+__global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    if ((int)blockIdx.x < render_blocks) render_jobs<3>(P, 1, nullptr, q_all, fast_parity, pace, (int)blockIdx.x, render_blocks);
+    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
+}
 // the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
 __global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
 {
-    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity, pace);
-    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity, pace);
+    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
+    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
 }
 // off the per-step path: the three frames of every env after cw_reset (mode 0), or the last frames of the
 // done list's envs before their reset (mode 4, keep_terminal_obs)
 __global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
 {
-    if (mode == 0) render_jobs<0>(P, 0, nullptr, 0, -1);
-    else if (mode == 5) render_jobs<5>(P, 0, nullptr, 0, -1);    // cw_set_state: all three frames of every env from its restored state
-    else render_jobs<4>(P, 0, nullptr, 0, -1);
+    if (mode == 0) render_jobs<0>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);
+    else if (mode == 5) render_jobs<5>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);    // cw_set_state: all three frames of every env from its restored state
+    else render_jobs<4>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1655,7 +1663,7 @@ extern "C" {
 // FULL pixel step: render + auto-resets as one launch (cw_render_step_kernel)?
 int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset)
 {
-    return auto_reset && T->overlap && T->fused_render && !P->terminal_img && T->render_threads == 256 && cw_render_linear(*P, *T);
+    return auto_reset && T->overlap && T->fused_render && !P->terminal_img && T->render_threads == 256;
 }
 
 // One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
@@ -1686,7 +1694,11 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (obs_mode == 1 && cwk_step_renders_fused(P, T, auto_reset)) {
         if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
         const int render_blocks = cw_render_grid(tn, n);
-        hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        if (cw_render_linear(*P, tn))
+            hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        else
+            hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks,
+                               tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
         if (ev) (void)hipEventRecord(ev[5], st);
         return hipGetLastError();
     }

@@ -226,8 +226,9 @@ typedef struct cw_profile {
 int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
 /* Name of the kernel that ms_render_kernel brackets for this engine (what a rocprofv3 kernel trace of the same run lists it as):
- * "cw_render_step_kernel" (full-frame render + the auto-resets beside it, one launch), "cw_render_kernel" (linear sweep alone),
- * "cw_render_frames_kernel" (frame per wave) or "" (CW_OBS_STATE: no render kernel).  A static string. */
+ * "cw_render_step_kernel" / "cw_render_frames_step_kernel" (full-frame render + the auto-resets beside it, one launch; linear
+ * sweep / frame per wave), "cw_render_kernel" / "cw_render_frames_kernel" (the render alone), the step kernel's name in
+ * CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out);

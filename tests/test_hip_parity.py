@@ -1068,15 +1068,16 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,size', [(3000, 21), (65536, 21), (4099, 8), (2000, 32)])
-def test_full_pixel_step_launch_arrangements_agree(N, size, monkeypatch):
+@pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
+                                           (3000, 21, 'alt'), (5000, 9, 'alt')])
+def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
     sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
     arrangements stay selectable -- two kernels on two streams (CW_TUNE_FUSED_RENDER=0), one stream with the resets first
     (CW_TUNE_OVERLAP=0) -- and all three must leave exactly the frames, results and random streams of the dirty-cell engine,
     with episodes ending on every step (phases spread out) and all at once."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
-    kw = dict(size=(size, size), max_steps=7, seed=29)
+    kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
     engines = {}
     for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
         if var:
@@ -1084,8 +1085,9 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, monkeypatch):
         engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
         if var:
             monkeypatch.delenv(var)
-    assert engines['one launch'].render_kernel_name() == 'cw_render_step_kernel'
-    assert engines['two streams'].render_kernel_name() == 'cw_render_kernel'
+    sweep = raster == 'ray' and size <= 64               # linear sweep; else the frame-per-wave painter
+    assert engines['one launch'].render_kernel_name() == ('cw_render_step_kernel' if sweep else 'cw_render_frames_step_kernel')
+    assert engines['two streams'].render_kernel_name() == ('cw_render_kernel' if sweep else 'cw_render_frames_kernel')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     for e in list(engines.values()) + [dirty]:
         e.reset()
