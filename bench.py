@@ -397,7 +397,7 @@ def main():
             # (cw_render_step_kernel: + the 2 extra frames of every env reset inside the launch, see below)
             alg_bytes = float(N) * (S * S + frame)
             dominant, ms = render_kernel, prof['ms_render_kernel']
-            if dominant in ('cw_render_step_kernel', 'cw_render_frames_step_kernel'):
+            if dominant.endswith('_step_kernel'):
                 # the fused launch also resets the finished envs and paints their observation, desired-goal and init frames:
                 # two frames more than the one an env that goes on gets (averaged over the profiled launches)
                 alg_bytes += 2.0 * frame * resets_in_prof / max(K, 1)
