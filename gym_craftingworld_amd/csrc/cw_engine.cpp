@@ -564,6 +564,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
+        tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
+        if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
+        if (tn.reset_blocks_per_cu > 8) tn.reset_blocks_per_cu = 8;
+        tn.fused_reset_blocks_per_cu = geti("CW_TUNE_FUSED_RESET_BLOCKS_PER_CU", tn.fused_reset_blocks_per_cu);
+        if (tn.fused_reset_blocks_per_cu < 1) tn.fused_reset_blocks_per_cu = 1;
+        if (tn.fused_reset_blocks_per_cu > 8) tn.fused_reset_blocks_per_cu = 8;
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
         if (tn.list_blocks < 1) tn.list_blocks = 1;
     }

@@ -782,6 +782,9 @@ __device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s
     // the wave's first list entry is fetched together with the count (entries past the count are stale but in bounds)
     const int first = (!all_envs && wave < P.n_envs) ? P.done_list[wave] : 0;
     const int count = all_envs ? P.n_envs : P.done_count[0];
+    // nothing finished on this step (most steps): nothing to reset and nothing to release, no ticket either.  Every workgroup reads
+    // the same count: the counter only changes when the last of n_blocks tickets has been drawn, i.e. after all of them have read it.
+    if (!all_envs && count == 0) return;
     for (int job = wave; job < count; job += n_waves) {
         const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : (job == wave ? first : P.done_list[job]));
         const uint32_t v_hx = P.hdr[env].x, v_hz = P.hdr[env].z;     // in flight beside the MT state
@@ -1642,9 +1645,9 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
 {
-    // persistent: one wave per env in flight, 2 workgroups (8 waves) per CU at most
+    // persistent: one wave per env in flight, reset_blocks_per_cu workgroups (x 4 waves) per CU at most
     int blocks = (jobs + CW_RESET_WAVES - 1) / CW_RESET_WAVES;
-    if (blocks > tn.n_cu * 2) blocks = tn.n_cu * 2;
+    if (blocks > tn.n_cu * tn.reset_blocks_per_cu) blocks = tn.n_cu * tn.reset_blocks_per_cu;
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -1694,10 +1697,15 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (obs_mode == 1 && cwk_step_renders_fused(P, T, auto_reset)) {
         if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
         const int render_blocks = cw_render_grid(tn, n);
+        // resetting workgroups: one per CU.  Each costs the launch ~12 ns whether or not anything finished (+1.2 % per 256 of them on
+        // every step), and a step on which every env finishes at once is rare: 1 / 2 / 4 per CU = 2.62 / 2.60 / 2.55 x 10^8 env-steps/s
+        // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/r02_fused_render.txt H)
+        int reset_blocks = (int)reset_grid.x;
+        if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
         if (cw_render_linear(*P, tn))
-            hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+            hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
         else
-            hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + (int)reset_grid.x), dim3(256), 0, st, *P, render_blocks,
+            hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
                                tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
         if (ev) (void)hipEventRecord(ev[5], st);
         return hipGetLastError();

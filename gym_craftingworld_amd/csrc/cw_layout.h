@@ -53,6 +53,8 @@ struct CwTuning {
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
     int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
+    int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset kernels
+    int fused_reset_blocks_per_cu = 1;   // ... and the resetting tail of the one-launch full-frame step (cwk_launch_step)
     int fused_render = 1;           // FULL pixel step: render + auto-resets in ONE launch (cw_render_step_kernel) instead of two kernels on two streams
     int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job,
                                     // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x3100)
