@@ -395,14 +395,14 @@ def main():
             # A_pix = 48 + S*S (grid read) + frame write; the render kernel's share is
             # S*S + frame bytes per env, and one launch paints N envs (+2 more frames for each env reset that step)
             # (cw_render_step_kernel: + the 2 extra frames of every env reset inside the launch, see below)
-            alg_bytes = float(N) * (S * S + frame)
+            alg_bytes = plain_alg_bytes = float(N) * (S * S + frame)
             dominant, ms = render_kernel, prof['ms_render_kernel']
             if dominant.endswith('_step_kernel'):
                 # the fused launch also resets the finished envs and paints their observation, desired-goal and init frames:
                 # two frames more than the one an env that goes on gets (averaged over the profiled launches)
                 alg_bytes += 2.0 * frame * resets_in_prof / max(K, 1)
         else:
-            alg_bytes = float(N) * 48.0
+            alg_bytes = plain_alg_bytes = float(N) * 48.0
             # state-only / dirty-cell: the whole auto-reset step is one launch (step + inline resets), latency-bound
             fused = os.environ.get('CW_TUNE_FUSED_STEP', '1') != '0'
             dominant, ms = ('cw_step_fused_kernel' if fused else 'cw_step_kernel'), prof['ms_step_kernel']
@@ -448,6 +448,11 @@ def main():
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
                          'launch_ms_min_max': [prof['ms_render_kernel_min'], prof['ms_render_kernel_max']],
+                         # the average above includes the launches on which every env is reset inside the kernel (2 of 600 with
+                         # synchronized phases, ~4x a plain launch, latency-bound): the median launch and its plain byte count beside it
+                         'median_launch_ms': prof['ms_render_kernel_median'] or None,
+                         'frac_at_median_launch': (plain_alg_bytes / (prof['ms_render_kernel_median'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                   if args.obs_mode == 'pixels' and prof['ms_render_kernel_median'] > 0 else None),
                          'events': 'hipEventRecord on the launch stream around every kernel, %d launches' % prof['steps']},
             # full-pixel mode brackets only the dominant render kernel (each event record costs a pipeline bubble,
             # side-stream events perturb the overlap); CW_PROFILE_SIDE_STREAM=1 brackets all three

@@ -51,7 +51,8 @@ class cw_state_view(C.Structure):
 
 class cw_profile(C.Structure):
     _fields_ = [('steps', C.c_int32), ('ms_step_kernel', C.c_float), ('ms_reset_kernel', C.c_float),
-                ('ms_render_kernel', C.c_float), ('ms_render_kernel_max', C.c_float), ('ms_render_kernel_min', C.c_float)]
+                ('ms_render_kernel', C.c_float), ('ms_render_kernel_max', C.c_float), ('ms_render_kernel_min', C.c_float),
+                ('ms_render_kernel_median', C.c_float)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)

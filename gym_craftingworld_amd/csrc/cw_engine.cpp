@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/craftingworld.h"
@@ -920,13 +921,15 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
             if (side_recorded || k >= 4) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
         double acc[3] = {0, 0, 0};
         float rmax = 0.f, rmin = 1e30f;
+        std::vector<float> render_ms;
+        render_ms.reserve((size_t)n);
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 3; k++) {
                 if (k != 2 && !side_recorded) continue;      // overlapped full-pixel step: only the render kernel is bracketed
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[(size_t)i * 6 + 2 * k], e->prof_ev[(size_t)i * 6 + 2 * k + 1]));
                 acc[k] += ms;
-                if (k == 2) { rmax = ms > rmax ? ms : rmax; rmin = ms < rmin ? ms : rmin; }
+                if (k == 2) { rmax = ms > rmax ? ms : rmax; rmin = ms < rmin ? ms : rmin; render_ms.push_back(ms); }
             }
         out->steps = n;
         out->ms_step_kernel = (float)(acc[0] / n);
@@ -934,6 +937,8 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
         out->ms_render_kernel = (float)(acc[2] / n);
         out->ms_render_kernel_max = rmax;
         out->ms_render_kernel_min = rmin;
+        std::sort(render_ms.begin(), render_ms.end());
+        out->ms_render_kernel_median = render_ms.empty() ? 0.f : render_ms[render_ms.size() / 2];
     }
     prof_free(e);
     return CW_OK;

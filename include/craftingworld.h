@@ -222,6 +222,7 @@ typedef struct cw_profile {
     float ms_render_kernel;  /* 0 in CW_OBS_STATE */
     float ms_render_kernel_max;
     float ms_render_kernel_min;
+    float ms_render_kernel_median;   /* (the one-launch step's average includes the launches on which every env is reset) */
 } cw_profile;
 int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
