@@ -98,13 +98,13 @@ struct cw_engine {
         hipEvent_t ev[64] = {nullptr};         // ev[w % 64] is recorded on the caller's stream when window w begins
         unsigned seq = 0;                      // steps taken in the tuned mode
         unsigned next_window = 0;              // first window whose duration has not been read yet
-        int cur = 1;                           // sleeps per pair of jobs currently held (the sleep inside each job is always on)
+        int cur = 2;                           // extra sleeps per pair of jobs while envs are reset beside the sweep, currently held
         signed char pace_of_window[64] = {0};  // what each recent window ran at; negative: a settling window, not counted
         float stat[16] = {0};                  // per pace: running mean step time of its counted windows (ms; 0: unknown)
         unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
     } adapt;
 };
-enum { CW_ADAPT_W = 16, CW_ADAPT_MAX = 8 };
+enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8 };
 
 // Look-ahead engines keep mt[] two episodes ahead of the reference's timeline.  Every entry point that reads or replaces the
 // RNG streams, or resets outside cw_step, first returns to the canonical form (mt[e] = snapshot of e's next slot); the next
@@ -242,17 +242,18 @@ static void prof_free(cw_engine *e)
 // Pace of the linear-sweep render (cw_kernels.hip: render_groups): idle clocks per pair of jobs.  The write path is less
 // efficient saturated than kept just short of saturation.
 //
-// Ray raster: the pace is FIXED at m+0 (one s_sleep inside every job, none between jobs), and 3 per pair of jobs on top while envs
-// are being reset beside the sweep (cw_kernels.hip: render_groups).  Round 2 first measured it at cw_create (median launch time
-// per candidate) and followed it with an online tuner; then both were compared with forced paces, alternating on one box, several
-// boxes (profiles/r02_pace.txt): the launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace
-// (0.2298-0.2455 ms for m+0) -- more than the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the
-// processes, and the tuner, hill-climbing on such figures, sat 3-7 % above a fixed pace (0.2419-0.2522 vs 0.2352 ms).  Inside a
-// step sequence the order is the same on every box and shape tried: with the one-launch step m+0 beats m+1 by 2 % (0.2337 vs 0.2392,
-// 0.2475 vs 0.2528 ms on a slower box, five alternating runs each; 131 072 envs, 262 144 envs and 32x32 likewise), m+2 costs 2.5 %
-// more, unpaced 15 %; with resets beside every launch (episode phases spread out) the optimum is 2 or 3 sleeps per pair higher
-// depending on the box, and too few costs 8 % where too many costs 1.3 %.  CW_TUNE_RENDER_CALIBRATE=1 brings the measurement back
-// (other hardware), CW_TUNE_RENDER_ADAPT=1 the tuner, CW_TUNE_RENDER_PACE=n / CW_TUNE_RENDER_PACE_BESIDE=n force the two values.
+// Ray raster: the pace is FIXED at m+0 (one s_sleep inside every job, none between jobs); on top of it come extra sleeps per pair of
+// jobs while at least CW_BESIDE_MIN envs are being reset beside the sweep (cw_kernels.hip: render_groups), and THAT number is what
+// the online tuner (adapt_tick) follows.  Round 2 first measured the pace at cw_create (median launch time per candidate) and let
+// the tuner follow it; then both were compared with forced paces, alternating on one box, several boxes (profiles/r02_pace.txt):
+// the launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace (0.2298-0.2455 ms for m+0) -- more
+// than the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the processes.  Inside a step sequence
+// the order is the same on every box and shape tried: m+0 0.2333, one sleep per pair without the inner one 0.2332-0.2345, unpaced
+// 0.2350, m+1 0.2365, m+2 0.2418 ms (one-launch step, no resets beside; 131 072 envs, 262 144 envs and 32x32 likewise).  With
+// resets beside every launch (episode phases spread out) the best extra is box-dependent -- 0 to 3 more sleeps per pair, and being
+// off by two costs 3-8 % -- hence the tuner there.  CW_TUNE_RENDER_CALIBRATE=1 brings the cw_create measurement back (other
+// hardware), CW_TUNE_RENDER_PACE=n forces the base pace, CW_TUNE_RENDER_PACE_BESIDE=n the extra (tuner off), CW_TUNE_RENDER_ADAPT=0
+// keeps the extra at its start value 2.
 // AltObs raster: measured here as before (0..6 sleeps per 1-KiB store; the optimum is flat and broad there).
 static int calibrate_render_pace(cw_engine *e, bool refine)
 {
@@ -260,7 +261,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     const char *forced = getenv("CW_TUNE_RENDER_PACE");
     if (forced) {                                         // (256 + n: with the sleep inside each job)
         const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = (atoi(forced) < 0 ? 0 : atoi(forced) & 0x1FF) | (((beside ? atoi(beside) : 3) & 15) << 12);
+        tn.render_pace = (atoi(forced) < 0 ? 0 : atoi(forced) & 0x1FF) | (((beside ? atoi(beside) : 2) & 15) << 12);
         if (e->P.raster == CW_RASTER_ALT) e->P.alt_pace = tn.render_pace & 0xFF;
         return CW_OK;
     }
@@ -270,7 +271,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
     if (!alt && !(getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0)) {
         const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = 0x100 | (((beside ? atoi(beside) : 3) & 15) << 12);
+        tn.render_pace = 0x100 | (((beside ? atoi(beside) : 2) & 15) << 12);
         return CW_OK;
     }
     // The launches of one candidate are queued back to back and the host waits once, at the end: a host round trip after every
@@ -329,22 +330,22 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     for (hipEvent_t &ev : evs) (void)hipEventDestroy(ev);
     if (rc != CW_OK) return rc;
     if (alt) e->P.alt_pace = best;
-    else tn.render_pace = (best & 0x1FF) | (3 << 12);       // (+3 while envs are reset beside the launch, see render_groups)
+    else tn.render_pace = (best & 0x1FF) | (2 << 12);       // (+2 while envs are reset beside the launch, see render_groups)
     if (getenv("CW_TUNE_VERBOSE"))
         fprintf(stderr, "[craftingworld] render pace%s: ms per launch by sleeps per pair of jobs (m+: and one inside each job)%s -> %s%d\n",
                 refine ? " (with shares)" : "", log, (best & 0x100) ? "m+" : "", best & 0xFF);
     return CW_OK;
 }
 
-// Online tuner of the render pace.  Where the write path's optimum lies depends on what else runs -- with all episodes in phase
-// the render kernel is alone on 598 of 600 steps, with the phases spread out ~0.3 % of the envs are being reset beside it on every
-// step -- and on the box; launches timed back to back at cw_create do not predict it (profiles/r02_render_linear.txt, section L).
-// So cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and
-// the time between two consecutive ones, read whenever both have completed -- however far the host runs ahead of the GPU -- is what
-// CW_ADAPT_W whole steps took.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the first
-// window after a change of pace settles and is not counted; a window holding a step on which every env was reset is an outlier and
-// is not counted either); each counted window updates the running figure of its pace, and `cur` moves to a neighbour whose figure
-// is 0.7 % better (figures older than three cycles do not count).  Only performance depends on any of it.
+// Online tuner of the sweep's extra sleeps beside resets.  How much the sweep has to slow down while envs are being reset beside it
+// depends on the box and on how many are reset per step (profiles/r02_pace.txt, r02_fused_render.txt), and launches timed at
+// cw_create do not predict it.  So cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every
+// CW_ADAPT_W steps (a "window"), and the time between two consecutive ones, read whenever both have completed -- however far the host
+// runs ahead of the GPU -- is what CW_ADAPT_W whole steps took.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1,
+// two at cur - 1 (the first window after a change settles and is not counted; a window holding a step on which every env was reset
+// is an outlier and is not counted either); each counted window updates the running figure of its value, and `cur` moves to a
+// neighbour whose figure is 0.7 % better (figures older than three cycles do not count).  With fewer than CW_BESIDE_MIN resets per
+// step the value is never used by the kernel and its drift is harmless.  Only performance depends on any of it.
 static void adapt_tick(cw_engine *e, hipStream_t st)
 {
     cw_engine::Adapt &a = e->adapt;
@@ -376,7 +377,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             if (fresh(c - 1) && a.stat[c - 1] < a.stat[best] * (best == c ? 0.993f : 1.0f)) best = c - 1;
             if (best != c) {
                 if (getenv("CW_TUNE_VERBOSE"))
-                    fprintf(stderr, "[craftingworld] render pace (online, window %u): m+%d %.4f ms/step | m+%d %.4f | m+%d %.4f -> m+%d\n", w, c,
+                    fprintf(stderr, "[craftingworld] sleeps beside resets (online, window %u): +%d %.4f ms/step | +%d %.4f | +%d %.4f -> +%d\n", w, c,
                             a.stat[c], c + 1, fresh(c + 1) ? a.stat[c + 1] : 0.0, c - 1, fresh(c - 1) ? a.stat[c - 1] : 0.0, best);
                 a.cur = best;
             }
@@ -666,12 +667,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
     if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
-        !getenv("CW_TUNE_RENDER_PACE") && getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) != 0 &&   // (opt-in, see adapt_tick)
+        !getenv("CW_TUNE_RENDER_PACE_BESIDE") && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) &&
         (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
         for (hipEvent_t &ev : a.ev)
             if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: pace tuner set-up failed");
-        a.cur = e->tune.render_pace & 0xFF;
+        a.cur = (e->tune.render_pace >> 12) & 15;
         if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
         a.on = rc == CW_OK;
     }
@@ -816,15 +817,15 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         if (ev) e->prof_n++;
         return CW_OK;
     }
-    if (e->adapt.on) {                               // full-frame mode: the render pace follows what the steps measure (adapt_tick)
+    if (e->adapt.on) {                               // full-frame mode: the sweep's extra sleeps beside resets follow what the steps measure (adapt_tick)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
             const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
-            e->tune.render_pace = (e->tune.render_pace & 0xF000) | 0x100 | (pw < 0 ? -1 - pw : pw);
+            e->tune.render_pace = (e->tune.render_pace & 0x1FF) | ((pw < 0 ? -1 - pw : pw) << 12);
             e->adapt.seq++;
         } else {
-            e->tune.render_pace = (e->tune.render_pace & 0xF000) | 0x100 | e->adapt.cur;                           // a captured graph keeps the pace it was captured with
+            e->tune.render_pace = (e->tune.render_pace & 0x1FF) | (e->adapt.cur << 12);     // a captured graph keeps the value it was captured with
         }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,

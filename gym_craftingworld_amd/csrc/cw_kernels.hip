@@ -581,6 +581,10 @@ __device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint3
 #define CW_SET_LANE(v, idx, val) v = ((int)lane == (idx)) ? (val) : v
 
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
+// the sweep slows down (pace bits 12-15) only beside at least this many resetting waves: with uniform random actions a handful of the
+// 65 536 envs succeed on almost every step, and 1-5 resetting waves do not disturb the sweep -- reacting to them cost 15 us on most
+// launches of the synchronized benchmark (the "two launch modes" of profiles/r02_pace.txt H)
+#define CW_BESIDE_MIN 32
 
 // One env's reset() (ray.py:156-218) by one wavefront; every value in the result is wave-uniform.
 struct CwResetOut {
@@ -1272,7 +1276,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
     const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
     if (wave >= n_jobs) return;   // (wave-uniform)
     const bool want_done = (MODE == 3) && skip_done;
-    if (want_done && cload(P.done_count) > 0) pace += (pace >> 12) & 15;     // envs being reset beside this launch: see render_groups
+    if (want_done && cload(P.done_count) >= CW_BESIDE_MIN) pace += (pace >> 12) & 15;     // envs being reset beside this launch: see render_groups
     const bool classes = (MODE == 2 || MODE == 3) && fast_parity >= 0;
     if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
     const int n_fast = (n_blocks / 2) * wpb;                               // (classes only: the grid is even)
@@ -1364,12 +1368,13 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // a render wave shares its SIMD with at most a few resetting waves (side stream): it wins the issue slot, they have the whole
     // launch to finish (with the reset waves raised instead, as in round 1, the spread-out-phases step is 3-8 % slower)
     if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    // sleeps of 64 clocks per pair of jobs (pace bits 0-7), and `pace` bits 12-15 more while envs are being reset beside this sweep
-    // (the launch's resetting workgroups, or the reset kernel on the side stream): their unpaced bursts push a write path that sits
-    // just short of saturation over the edge -- phases spread out, 2 / 3 / 4 sleeps per pair in all: 0.268 / 0.248 ms on one box,
-    // 0.2518 / 0.2549 / 0.259 on another (profiles/r02_pace.txt, r02_fused_render.txt).  (done_count is zeroed by the last resetting
-    // workgroup: a wave that starts after that paces like a launch with nothing beside it, which is what it then is.)
-    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) > 0) ? ((pace >> 12) & 15) : 0);
+    // sleeps of 64 clocks per pair of jobs (pace bits 0-7), and `pace` bits 12-15 more while at least CW_BESIDE_MIN envs are being
+    // reset beside this sweep (the launch's resetting workgroups, or the reset kernel on the side stream): their unpaced bursts push a
+    // write path that sits just short of saturation over the edge -- phases spread out, 0 / 2 / 3 / 4 extra: 0.263 / 0.245 / 0.248 /
+    // 0.252 ms on one box, 3 best and 1 at 0.267 on another (profiles/r02_pace.txt, r02_fused_render.txt; cw_step tunes the number
+    // online).  (done_count is zeroed by the last resetting workgroup: a wave that starts after that paces like a launch with nothing
+    // beside it, which is what it then is.)
+    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
     CW_WAVE_CLOCK(t_start);
     if (MODE == 3) CW_WAVE_STAMP(wave, 0);
