@@ -9,13 +9,13 @@
 
 Workload = BASELINE.json configs[2] (the config the metric is quoted on): 65 536 envs per GPU,
 21x21 grid, full-frame 4x4-pixel-cell uint8 observation every step, auto-reset, uniform random
-actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel, then the full-frame
-render kernel with the reset kernel over the ballot-compacted done list beside it on a forked stream).  Envs shard across
+actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel, then ONE launch whose first
+workgroups render every frame and whose last ones reset the envs of the ballot-compacted done list).  Envs shard across
 ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
 are the timing barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt), with
-  roofline     -- dominant kernel cw_render_kernel vs the HBM roof, from HIP events recorded by the
+  roofline     -- dominant kernel (cw_render_step_kernel) vs the HBM roof, from HIP events recorded by the
                   library on the launch stream (cw_profile_begin/end) over a second, identical
                   K-step region (the first region, without events, gives `value`);
   cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) on this host's cores,
