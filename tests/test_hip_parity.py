@@ -1649,6 +1649,41 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
 
 
+@pytest.mark.gpu
+def test_bench_json_line_carries_the_contract():
+    """One small `python bench.py` run on this GPU: exactly one JSON line with the contract's keys, the roofline object (dominant kernel
+    by the name a rocprofv3 trace lists it under, HIP-event launch times, average and median), the CPU baseline (kind "port", a described
+    sample, like for like with the headline), the repeats and the metric window."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '40', '--warmup', '5', '--envs-per-gpu', '8192',
+                        '--max-steps', '20', '--cpu-seconds', '0.5', '--no-other-modes', '--no-single-env'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 40 and d['warmup'] == 5 and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and d['dtype'] == 'u8' and d['unit'] == 'env-steps/s' and 'workload' in d['config']
+    assert abs(d['value'] - 8192 * 40 / (d['ms_per_step'] * 40e-3)) < 1e-6 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 'traffic' in r
+    assert r['kernel'] == 'cw_render_step_kernel'
+    assert r['avg_launch_ms'] > 0 and r['median_launch_ms'] > 0 and r['launch_ms_min_max'][0] <= r['median_launch_ms'] <= r['launch_ms_min_max'][1]
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1 and 0 < r['frac_at_median_launch'] < 1
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'env-steps/s' and isinstance(c['sample'], str)
+    assert d['repeats']['n'] == 3 and d['repeats']['value'][0] == d['value']
+    assert d['metric_window']['steps'] == 40 and d['metric_window']['value'] > 0 and len(d['metric_window']['slowest_step_ms']) == 2
+
+
 def _reference_render_of_any_state(state):
     """ray.py:442-486 restated in numpy for a caller-supplied one-hot state (test-side oracle): sum of object colours per cell,
     x4 upscale, agent = first cell with channel 8 set -> centre 2x2 white, bottom row of it in the colour of the largest hold
