@@ -1069,7 +1069,7 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
-                                           (3000, 21, 'alt'), (5000, 9, 'alt')])
+                                           (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt')])
 def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
     sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
@@ -1085,9 +1085,9 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch)
         engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
         if var:
             monkeypatch.delenv(var)
-    sweep = raster == 'ray' and size <= 64               # linear sweep; else the frame-per-wave painter
-    assert engines['one launch'].render_kernel_name() == ('cw_render_step_kernel' if sweep else 'cw_render_frames_step_kernel')
-    assert engines['two streams'].render_kernel_name() == ('cw_render_kernel' if sweep else 'cw_render_frames_kernel')
+    stem = 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_frames'      # linear sweep; else the frame-per-wave painter
+    assert engines['one launch'].render_kernel_name() == stem + '_step_kernel'
+    assert engines['two streams'].render_kernel_name() == stem + '_kernel'
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     for e in list(engines.values()) + [dirty]:
         e.reset()
