@@ -1396,6 +1396,8 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         }
         return r;
     };
+    // (PLACEMENT: this loop's launch time depends on where it lies in the code object, period 32 bytes -- profiles/r02_pace.txt O, DESIGN 4.3.
+    //  After any edit that changes the size of the code before this point: tools/microbench/exp_pad.sh.)
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
         const Rec cur = nxt;
