@@ -1396,8 +1396,12 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         }
         return r;
     };
-    // (PLACEMENT: this loop's launch time depends on where it lies in the code object, period 32 bytes -- profiles/r02_pace.txt O, DESIGN 4.3.
-    //  After any edit that changes the size of the code before this point: tools/microbench/exp_pad.sh.)
+    // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions read
+    // 0.2325 ms at this placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few clocks
+    // per job at the loop's branch targets, a pace finer than s_sleep's 64 clocks (profiles/r02_pace.txt N-P).  So the placement
+    // is pinned: a 32-byte boundary plus three s_nop (executed once per wave).  After editing the loop below, or to try a neighbour:
+    // tools/microbench/exp_align.sh.
+    asm volatile(".p2align 5");asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0");
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
         const Rec cur = nxt;
