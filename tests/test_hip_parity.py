@@ -1117,6 +1117,36 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_full_frame_soak_with_the_online_tuner_equals_dirty_cell_engine(monkeypatch):
+    """3 000 steps of 65 536 full-frame envs with the episode phases spread out (>= 32 resets beside every sweep, so the kernel uses
+    the extra sleeps and cw_step's online tuner keeps changing them): every 250 steps all three frames, and at the end results,
+    counters and random streams, must equal the dirty-cell engine's.  The tuner and the pace may only change the speed."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    monkeypatch.setenv('CW_TUNE_VERBOSE', '1')           # (the tuner's moves go to stderr: visible with -s)
+    N, T = 65536, 3000
+    kw = dict(size=(21, 21), max_steps=300, seed=77)
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    for e in (full, dirty):
+        e.reset()
+        e.set_state(step_num=((np.arange(N) * 7) % 300).astype(np.int32))
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    acts = torch.randint(0, 6, (64, N), device='cuda', dtype=torch.uint8, generator=gen)
+    for t in range(T):
+        of, rf, df, _ = full.step(acts[t % 64])
+        od, rd, dd, _ = dirty.step(acts[t % 64])
+        if t % 250 == 249 or t == T - 1:
+            assert torch.equal(rf, rd) and torch.equal(df, dd), t
+            for k in ('observation', 'desired_goal', 'init_observation'):
+                assert torch.equal(of[k], od[k]), (t, k)
+    assert torch.equal(full.counters, dirty.counters)
+    kf, pf = full.get_rng_states()
+    kd, pd_ = dirty.get_rng_states()
+    assert np.array_equal(kf, kd) and np.array_equal(pf, pd_)
+    full.close(); dirty.close()
+
+
+@pytest.mark.gpu
 def test_long_reset_chains_on_one_stream_vs_oracle():
     """3 000 consecutive episodes on each of 256 MT19937 streams (max_steps=1: every step ends an episode), so that
     the lazily regenerated state is entered at every alignment and wraps hundreds of times per stream; state, goal
