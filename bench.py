@@ -176,6 +176,8 @@ def main():
     ap.add_argument('--mixed-menus', action='store_true',
                     help='BASELINE configs[3] shape: env i uses ordered task list i mod 8 of a fixed menu of eight (heterogeneous selected_tasks / '
                          'number_of_tasks / stacking / reward_style per env)')
+    ap.add_argument('--prewarm-steps', type=int, default=200,
+                    help='untimed steps before the W warm-up steps, to bring a card that idled through set-up to its steady state (0: none)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
     ap.add_argument('--quick', action='store_true',
@@ -303,6 +305,12 @@ def main():
         for t in range(k):
             env.step_async(actions[(t_off + t) % rows])
 
+    # Device warm-up before the contract's W warm-up steps: the card has idled through env construction, and its first few hundred
+    # launches after that run 3-6 % slower than the steady state the K timed steps are meant to show (K=20, W=5 without it: 2.60-2.67 x 10^8
+    # in the first region, 2.74-2.77 in the next two; profiles/r02_pace.txt T).  Untimed, like the W steps that follow it.
+    if args.prewarm_steps > 0 and not args.rollout:
+        run((args.prewarm_steps // G) * G if G > 0 else args.prewarm_steps, 0)
+        torch.cuda.synchronize(dev)
     run(W, 0)
     red_dev = dev if args.dist_backend == 'nccl' else 'cpu'
 
@@ -458,7 +466,7 @@ def main():
             # side-stream events perturb the overlap); CW_PROFILE_SIDE_STREAM=1 brackets all three
             'kernels_ms': {'step': prof['ms_step_kernel'] or None, 'reset': prof['ms_reset_kernel'] or None,
                            'render': prof['ms_render_kernel'] or None, 'ms_per_step_with_events': elapsed_prof / K * 1e3},
-            'episodes_finished': episodes,
+            'episodes_finished': episodes, 'prewarm_steps': 0 if args.rollout else args.prewarm_steps,
             'repeats': {'n': len(repeats_s), 'ms_per_step': [x / K * 1e3 for x in repeats_s],
                         'value': [total_steps / x for x in repeats_s], 'value_min': total_steps / max(repeats_s),
                         'value_median': total_steps / sorted(repeats_s)[len(repeats_s) // 2],
