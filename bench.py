@@ -308,8 +308,9 @@ def main():
     # Device warm-up before the contract's W warm-up steps: the card has idled through env construction, and its first few hundred
     # launches after that run 3-6 % slower than the steady state the K timed steps are meant to show (K=20, W=5 without it: 2.60-2.67 x 10^8
     # in the first region, 2.74-2.77 in the next two; profiles/r02_pace.txt T).  Untimed, like the W steps that follow it.
-    if args.prewarm_steps > 0 and not args.rollout:
-        run((args.prewarm_steps // G) * G if G > 0 else args.prewarm_steps, 0)
+    prewarm_steps = 0 if args.rollout else max(args.prewarm_steps, 0)
+    if prewarm_steps > 0:
+        run((prewarm_steps // G) * G if G > 0 else prewarm_steps, 0)
         torch.cuda.synchronize(dev)
     run(W, 0)
     red_dev = dev if args.dist_backend == 'nccl' else 'cpu'
@@ -466,7 +467,7 @@ def main():
             # side-stream events perturb the overlap); CW_PROFILE_SIDE_STREAM=1 brackets all three
             'kernels_ms': {'step': prof['ms_step_kernel'] or None, 'reset': prof['ms_reset_kernel'] or None,
                            'render': prof['ms_render_kernel'] or None, 'ms_per_step_with_events': elapsed_prof / K * 1e3},
-            'episodes_finished': episodes, 'prewarm_steps': 0 if args.rollout else args.prewarm_steps,
+            'episodes_finished': episodes, 'prewarm_steps': prewarm_steps,
             'repeats': {'n': len(repeats_s), 'ms_per_step': [x / K * 1e3 for x in repeats_s],
                         'value': [total_steps / x for x in repeats_s], 'value_min': total_steps / max(repeats_s),
                         'value_median': total_steps / sorted(repeats_s)[len(repeats_s) // 2],
