@@ -18,6 +18,7 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev, int la_parity);
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
+int cwk_render_is_flat(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity, int all_envs, hipStream_t st);
 hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
@@ -565,6 +566,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
+        tn.render_flat = geti("CW_TUNE_RENDER_FLAT", tn.render_flat);
+        tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
         if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
@@ -666,7 +669,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (rc == CW_OK) rc = calibrate_render_pace(e, false);
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
-    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
+    if (rc == CW_OK) e->tune.render_pace |= (e->tune.render_pace_fine & 0xFF) << 16;
+    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
+        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_flat(&e->P, &e->tune)) &&
         !getenv("CW_TUNE_RENDER_PACE_BESIDE") && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) &&
         (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
@@ -822,10 +827,10 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
             const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
-            e->tune.render_pace = (e->tune.render_pace & 0x1FF) | ((pw < 0 ? -1 - pw : pw) << 12);
+            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | ((pw < 0 ? -1 - pw : pw) << 12);
             e->adapt.seq++;
         } else {
-            e->tune.render_pace = (e->tune.render_pace & 0x1FF) | (e->adapt.cur << 12);     // a captured graph keeps the value it was captured with
+            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | (e->adapt.cur << 12);     // a captured graph keeps the value it was captured with
         }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
@@ -950,6 +955,7 @@ const char *cw_render_kernel_name(const cw_engine *e)
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+    if (cwk_render_is_flat(&e->P, &e->tune)) return one_launch ? "cw_render_flat_step_kernel" : "cw_render_flat_kernel";
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
 }

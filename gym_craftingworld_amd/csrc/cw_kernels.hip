@@ -1376,6 +1376,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // beside it, which is what it then is.)
     const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
+    const int pace_fine = (pace >> 16) & 0xFF;                               // x ~16 clocks before every job (s_nop loop)
     CW_WAVE_CLOCK(t_start);
     if (MODE == 3) CW_WAVE_STAMP(wave, 0);
     struct Rec { int env, g; uint32_t hx, hw, done; uint4 p; };
@@ -1409,6 +1410,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         const int in_batch = min(q_mine - base, CW_WAVE);
         for (int k = 0; k < in_batch; k++) {
             if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
+            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 7");
             const int env = __builtin_amdgcn_readlane(cur.env, k);
             if (env < 0) continue;
             if (want_done && __builtin_amdgcn_readlane(cur.done, k)) continue;
@@ -1448,6 +1450,171 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
+// ---- FLAT sweep: the frame array as ONE BYTE STREAM, zero-filled with line-aligned 16-byte stores, then patched ----------
+// A Ray frame is almost all zeros: COLORS_N[0] is black and at most 8 objects + the agent are on the grid, so <= 9 of the S*S cells
+// (<= 36 twelve-byte cell rows) are not.  Job = CW_FLAT_JB bytes of the frame array starting at a multiple of CW_FLAT_JB, whatever
+// frames those bytes belong to (48*S*S is a multiple of 16 but not of 128: a frame starts anywhere in a cache line, and a job holds
+// the end of one frame and the start of the next 1 time in 7 at 21x21): the wave writes zeros, 64 lanes x 16 B = 1 KiB of whole
+// 128-B lines per store instruction -- the shape of a plain fill, no store shares a line with another wave's -- and then lanes 0..35
+// store the coloured cell rows of the job's frame(s) that lie inside the job: lane = (slot or agent, pixel row of the cell), 12 B each,
+// clipped to the job dword by dword where a cell row crosses its edge (rare: a scalar branch).  One wave's stores to one address are
+// performed in program order, so the patch lands on the fill; the line is still in L2 then, so HBM sees it once.  No load, no LDS in the
+// loop, records a batch ahead as in render_groups.  (Needs 48*S*S >= CW_FLAT_JB, i.e. S >= 8: at most two frames per job.)
+#ifndef CW_FLAT_JB
+#define CW_FLAT_JB 3072u
+#endif
+struct CwFlatLane {                  // per-lane constants of the patch
+    uint32_t sh16, sh4;              // 16 * (slot & 1), 4 * slot
+    uint32_t dy;
+    bool obj, agent, mid, row2;      // lane < 32 | lanes 32..35 | dy is 1 or 2 | dy == 2
+};
+__device__ __forceinline__ void flat_patch(uint8_t *__restrict__ jb, int rel_e, int lim, uint32_t hx, uint32_t codes, const u32x4s &pp,
+                                           const CwFlatLane &L, uint32_t v_table, int S, int ncell, uint32_t div_magic, int lane)
+{
+    const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+    const uint32_t hold = (hx >> 16) & 0xFFu;
+    const uint32_t o2 = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;    // ray.py:484-486
+    // the lane's slot: its u16 of the position record, its nibble of the codes
+    const uint32_t w = L.sh4 < 8u ? pp.x : L.sh4 < 16u ? pp.y : L.sh4 < 24u ? pp.z : pp.w;
+    uint32_t cell = (w >> L.sh16) & 0xFFFFu;
+    uint32_t code = (codes >> (L.sh4 & 31u)) & 15u;
+    const bool under = L.obj && L.dy == 0 && code != 0 && cell == agent_cell;                 // an object in the agent's cell: its lanes paint the overlay
+    const bool obj_under_agent = CW_BALLOT(under) != 0;
+    if (L.agent) { cell = agent_cell; code = 0; }
+    const bool valid = L.obj ? (code != 0 && cell < (uint32_t)ncell) : (L.agent && !obj_under_agent);
+    const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);
+    u32x3 d = cell_row_dwords(col);
+    if (cell == agent_cell && L.mid) d = overlay_dwords(d, L.row2 ? o2 : 0x00FFFFFFu);     // ray.py:483-486
+    const uint32_t r = __umulhi(cell, div_magic), c = cell - r * S;
+    const int rel = rel_e + (int)((4u * r + L.dy) * (12u * S) + 12u * c);         // first byte of the cell row, relative to the job
+    const bool inside = valid && rel >= 0 && rel + 12 <= lim;
+    if (inside) *(u32x3_a4 *)(jb + rel) = d;
+    const bool partial = valid && !inside && rel + 12 > 0 && rel < lim;           // crosses the job's edge: the dwords on this side
+    if (CW_BALLOT(partial)) {
+        if (partial && rel >= 0 && rel + 4 <= lim) *(uint32_t *)(jb + rel) = d.x;
+        if (partial && rel + 4 >= 0 && rel + 8 <= lim) *(uint32_t *)(jb + rel + 4) = d.y;
+        if (partial && rel + 8 >= 0 && rel + 12 <= lim) *(uint32_t *)(jb + rel + 8) = d.z;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int bid, int n_blocks)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wpb = blockDim.x / CW_WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = bid * wpb + wave_in_block;
+    const int n_waves = n_blocks * wpb;
+    const uint32_t FB = P.frame_bytes, JB = CW_FLAT_JB;
+    const unsigned long long total = (unsigned long long)P.n_envs * FB;
+    const int n_jobs = (int)((total + JB - 1) / JB);                           // (the launcher checked that this fits)
+    if (wave >= n_jobs) return;
+    const int q_mine = (n_jobs - wave + n_waves - 1) / n_waves;               // jobs wave, wave + n_waves, ...
+    const bool want_done = (MODE == 3) && skip_done;
+    const int S = P.size;
+    CwFlatLane L;
+    L.sh16 = 16u * (((uint32_t)lane >> 2) & 1u);
+    L.sh4 = 4u * ((uint32_t)lane >> 2);
+    L.dy = (uint32_t)lane & 3u;
+    L.obj = lane < 32;
+    L.agent = lane >= 32 && lane < 36;
+    L.mid = L.dy == 1u || L.dy == 2u;
+    L.row2 = L.dy == 2u;
+    const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
+    uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
+    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
+    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
+    const bool pace_mid = (pace & 0x100) != 0;
+    const int pace_fine = (pace >> 16) & 0xFF;                               // x ~16 clocks per job (s_nop loop)
+    CW_WAVE_CLOCK(t_start);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
+    // The records of a batch are fetched a batch ahead with loads the compiler does not see (inline asm): it would otherwise be free to
+    // wait for them before the job loop -- and does, depending on register allocation (SIInsertWaitcnts flushes vmcnt in a loop's
+    // preheader if the loop "uses" a register with a load pending, even one it redefines first) -- which puts a load round trip
+    // under the write storm on every batch boundary.  flat_wait() is the one place they are waited for; it names every loaded
+    // register as an in/out operand, so no use can be scheduled above it.  Every lane loads (clamped indices): no exec-masked region.
+    struct Rec { int rel, lim; uint32_t hx_a, hw_a, hx_b, hw_b, dn_a, dn_b; u32x4s p_a, p_b; };
+    auto fetch = [&](int base) {
+        Rec r;
+        const int i = base + lane;
+        const int id = min(i * n_waves + wave, n_jobs - 1);
+        const unsigned long long lo = (unsigned long long)id * JB;
+        const uint32_t env = (uint32_t)(lo / FB);
+        r.rel = (int)((long long)((unsigned long long)env * FB) - (long long)lo);          // -FB < rel <= 0: where frame `env` starts
+        r.lim = (int)(total - lo < JB ? total - lo : JB);
+        // the next frame may start inside the job (1 job in 7 at 21x21); its record is fetched regardless (the neighbour's: same lines)
+        const uint32_t env_b = min(env + 1u, (uint32_t)P.n_envs - 1u);
+        const uint4 *ha = P.hdr + env, *hb = P.hdr + env_b, *pa = P.pos + env, *pb = P.pos + env_b;
+        const uint8_t *da = P.done + env, *db = P.done + env_b;
+        r.dn_a = r.dn_b = 0;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.hx_a) : "v"(ha) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(r.hw_a) : "v"(ha) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.p_a) : "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.hx_b) : "v"(hb) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(r.hw_b) : "v"(hb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.p_b) : "v"(pb) : "memory");
+        if (want_done) {                                                       // (wave-uniform)
+            asm volatile("global_load_ubyte %0, %1, off" : "=v"(r.dn_a) : "v"(da) : "memory");
+            asm volatile("global_load_ubyte %0, %1, off" : "=v"(r.dn_b) : "v"(db) : "memory");
+        }
+        return r;
+    };
+    auto flat_wait = [&](Rec &r) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.hx_a), "+v"(r.hw_a), "+v"(r.p_a), "+v"(r.hx_b), "+v"(r.hw_b), "+v"(r.p_b), "+v"(r.dn_a), "+v"(r.dn_b) : : "memory");
+    };
+    Rec nxt = fetch(0);
+    for (int base = 0; base < q_mine; base += CW_WAVE) {
+        flat_wait(nxt);
+        const Rec cur = nxt;
+        if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
+        const int in_batch = min(q_mine - base, CW_WAVE);
+        for (int k = 0; k < in_batch; k++) {
+            if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
+            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 7");
+            const int rel_a = __builtin_amdgcn_readlane(cur.rel, k);
+            const int lim = __builtin_amdgcn_readlane(cur.lim, k);
+            const bool dn_a = want_done && __builtin_amdgcn_readlane(cur.dn_a, k) != 0;
+            const bool dn_b = want_done && __builtin_amdgcn_readlane(cur.dn_b, k) != 0;
+            const int rel_b = rel_a + (int)FB;
+            uint8_t *const jb = dst_base + (size_t)((base + k) * n_waves + wave) * JB;
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            if (!dn_a && !dn_b && lim == (int)JB) {                           // nearly always: the whole job, no finished env in it
+#pragma unroll
+                for (uint32_t c = 0; c < JB / 1024u; c++) {
+                    *(uint4 *)(jb + c * 1024u + 16u * lane) = z4;
+                    if (c == 1 && pace_mid) __builtin_amdgcn_s_sleep(1);
+                }
+            } else {                                                           // bytes of a finished env's frame belong to its resetting wave
+#pragma unroll
+                for (uint32_t c = 0; c < JB / 1024u; c++) {
+                    const int rel = (int)(c * 1024u + 16u * lane);
+                    const bool skip = (rel < rel_b) ? dn_a : dn_b;
+                    if (rel < lim && !skip) *(uint4 *)(jb + rel) = z4;
+                }
+            }
+            u32x4s pp;
+            if (!dn_a) {
+                pp.x = __builtin_amdgcn_readlane(cur.p_a.x, k);
+                pp.y = __builtin_amdgcn_readlane(cur.p_a.y, k);
+                pp.z = __builtin_amdgcn_readlane(cur.p_a.z, k);
+                pp.w = __builtin_amdgcn_readlane(cur.p_a.w, k);
+                flat_patch(jb, rel_a, lim, __builtin_amdgcn_readlane(cur.hx_a, k), __builtin_amdgcn_readlane(cur.hw_a, k), pp, L, v_table,
+                           S, P.ncell, P.div_magic, lane);
+            }
+            if (rel_b < lim && !dn_b) {
+                pp.x = __builtin_amdgcn_readlane(cur.p_b.x, k);
+                pp.y = __builtin_amdgcn_readlane(cur.p_b.y, k);
+                pp.z = __builtin_amdgcn_readlane(cur.p_b.z, k);
+                pp.w = __builtin_amdgcn_readlane(cur.p_b.w, k);
+                flat_patch(jb, rel_b, lim, __builtin_amdgcn_readlane(cur.hx_b, k), __builtin_amdgcn_readlane(cur.hw_b, k), pp, L, v_table,
+                           S, P.ncell, P.div_magic, lane);
+            }
+        }
+    }
+    CW_WAVE_BUSY(P, t_start, bid & 1);
+    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
+}
+
 // the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
 __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
 {
@@ -1465,6 +1632,18 @@ __global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int ren
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     if ((int)blockIdx.x < render_blocks) render_groups<3>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
+}
+// ... and with the flat sweep (render_flat)
+__global__ __launch_bounds__(256) void cw_render_flat_step_kernel(CwParams P, int render_blocks, int pace)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    if ((int)blockIdx.x < render_blocks) render_flat<3>(P, 1, nullptr, pace, (int)blockIdx.x, render_blocks);
+    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
+}
+__global__ __launch_bounds__(256) void cw_render_flat_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace)
+{
+    if (mode == 3) render_flat<3>(P, skip_done, ext_out, pace, (int)blockIdx.x, (int)gridDim.x);
+    else render_flat<2>(P, skip_done, ext_out, pace, (int)blockIdx.x, (int)gridDim.x);
 }
 // the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
 __global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
@@ -1629,6 +1808,12 @@ static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
     const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
     return tn.render_linear >= 2 || jobs <= 2560 * waves;
 }
+// flat sweep (render_flat): Ray raster, frames of at least one job (S >= 8), 16-byte aligned destination
+static inline int cw_render_flat(const CwParams &P, const CwTuning &tn, const uint8_t *dst)
+{
+    if (!tn.render_flat || P.raster != 0 || P.frame_bytes < CW_FLAT_JB || ((uintptr_t)dst & 15u)) return 0;
+    return ((unsigned long long)P.n_envs * P.frame_bytes + CW_FLAT_JB - 1) / CW_FLAT_JB < (1ull << 31);
+}
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
                                     int fast_parity, hipStream_t st);
@@ -1650,7 +1835,8 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
+    if (cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) hipLaunchKernelGGL(cw_render_flat_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, tn.render_pace);
+    else if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
     else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
@@ -1713,7 +1899,9 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/r02_fused_render.txt H)
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-        if (cw_render_linear(*P, tn))
+        if (cw_render_flat(*P, tn, P->obs))
+            hipLaunchKernelGGL(cw_render_flat_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        else if (cw_render_linear(*P, tn))
             hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
         else
             hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
@@ -1829,6 +2017,7 @@ hipError_t cwk_launch_idle(hipStream_t st)
 }
 
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
+int cwk_render_is_flat(const CwParams *P, const CwTuning *T) { return cw_render_flat(*P, *T, P->obs); }
 int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
