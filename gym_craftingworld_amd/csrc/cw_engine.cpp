@@ -568,6 +568,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
         tn.render_flat = geti("CW_TUNE_RENDER_FLAT", tn.render_flat);
         tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
+        tn.flat_chunks = geti("CW_TUNE_FLAT_CHUNKS", tn.flat_chunks);
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
         if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
@@ -955,6 +956,7 @@ const char *cw_render_kernel_name(const cw_engine *e)
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+    if (cwk_render_is_flat(&e->P, &e->tune) == 2) return one_launch ? "cw_render_fill_step_kernel" : "cw_render_fill_kernel";
     if (cwk_render_is_flat(&e->P, &e->tune)) return one_launch ? "cw_render_flat_step_kernel" : "cw_render_flat_kernel";
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";

@@ -1452,17 +1452,14 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
 
 // ---- FLAT sweep: the frame array as ONE BYTE STREAM, zero-filled with line-aligned 16-byte stores, then patched ----------
 // A Ray frame is almost all zeros: COLORS_N[0] is black and at most 8 objects + the agent are on the grid, so <= 9 of the S*S cells
-// (<= 36 twelve-byte cell rows) are not.  Job = CW_FLAT_JB bytes of the frame array starting at a multiple of CW_FLAT_JB, whatever
+// (<= 36 twelve-byte cell rows) are not.  Job = `chunks` KiB of the frame array starting at a multiple of that, whatever
 // frames those bytes belong to (48*S*S is a multiple of 16 but not of 128: a frame starts anywhere in a cache line, and a job holds
 // the end of one frame and the start of the next 1 time in 7 at 21x21): the wave writes zeros, 64 lanes x 16 B = 1 KiB of whole
 // 128-B lines per store instruction -- the shape of a plain fill, no store shares a line with another wave's -- and then lanes 0..35
 // store the coloured cell rows of the job's frame(s) that lie inside the job: lane = (slot or agent, pixel row of the cell), 12 B each,
 // clipped to the job dword by dword where a cell row crosses its edge (rare: a scalar branch).  One wave's stores to one address are
 // performed in program order, so the patch lands on the fill; the line is still in L2 then, so HBM sees it once.  No load, no LDS in the
-// loop, records a batch ahead as in render_groups.  (Needs 48*S*S >= CW_FLAT_JB, i.e. S >= 8: at most two frames per job.)
-#ifndef CW_FLAT_JB
-#define CW_FLAT_JB 3072u
-#endif
+// loop, records a batch ahead as in render_groups.  (A job is at most a frame long: at most two frames per job.)
 struct CwFlatLane {                  // per-lane constants of the patch
     uint32_t sh16, sh4;              // 16 * (slot & 1), 4 * slot
     uint32_t dy;
@@ -1498,14 +1495,14 @@ __device__ __forceinline__ void flat_patch(uint8_t *__restrict__ jb, int rel_e, 
 }
 
 template <int MODE>
-__device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int bid, int n_blocks)
+__device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int chunks, int bid, int n_blocks)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = bid * wpb + wave_in_block;
     const int n_waves = n_blocks * wpb;
-    const uint32_t FB = P.frame_bytes, JB = CW_FLAT_JB;
+    const uint32_t FB = P.frame_bytes, JB = 1024u * (uint32_t)chunks;            // (the launcher made sure that JB <= FB: at most two frames per job)
     const unsigned long long total = (unsigned long long)P.n_envs * FB;
     const int n_jobs = (int)((total + JB - 1) / JB);                           // (the launcher checked that this fits)
     if (wave >= n_jobs) return;
@@ -1531,9 +1528,11 @@ __device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, ui
     // The records of a batch are fetched a batch ahead with loads the compiler does not see (inline asm): it would otherwise be free to
     // wait for them before the job loop -- and does, depending on register allocation (SIInsertWaitcnts flushes vmcnt in a loop's
     // preheader if the loop "uses" a register with a load pending, even one it redefines first) -- which puts a load round trip
-    // under the write storm on every batch boundary.  flat_wait() is the one place they are waited for; it names every loaded
-    // register as an in/out operand, so no use can be scheduled above it.  Every lane loads (clamped indices): no exec-masked region.
-    struct Rec { int rel, lim; uint32_t hx_a, hw_a, hx_b, hw_b, dn_a, dn_b; u32x4s p_a, p_b; };
+    // under the write storm on every batch boundary.  The loaded registers (Raw) are read in exactly one place: flat_take(), one asm
+    // block that waits for the loads and then copies them into the registers the job loop reads (tests/test_isa.py checks the built
+    // code object for both properties).  Every lane loads (clamped indices): no exec-masked region around the asm.
+    struct Raw { uint32_t w[14]; };      // hx_a, hw_a, p_a[4], hx_b, hw_b, p_b[4], dn_a, dn_b
+    struct Rec { int rel, lim; Raw raw; };
     auto fetch = [&](int base) {
         Rec r;
         const int i = base + lane;
@@ -1546,73 +1545,138 @@ __device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, ui
         const uint32_t env_b = min(env + 1u, (uint32_t)P.n_envs - 1u);
         const uint4 *ha = P.hdr + env, *hb = P.hdr + env_b, *pa = P.pos + env, *pb = P.pos + env_b;
         const uint8_t *da = P.done + env, *db = P.done + env_b;
-        r.dn_a = r.dn_b = 0;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.hx_a) : "v"(ha) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(r.hw_a) : "v"(ha) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.p_a) : "v"(pa) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.hx_b) : "v"(hb) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(r.hw_b) : "v"(hb) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.p_b) : "v"(pb) : "memory");
-        if (want_done) {                                                       // (wave-uniform)
-            asm volatile("global_load_ubyte %0, %1, off" : "=v"(r.dn_a) : "v"(da) : "memory");
-            asm volatile("global_load_ubyte %0, %1, off" : "=v"(r.dn_b) : "v"(db) : "memory");
-        }
+        uint32_t *w = r.raw.w;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(w[0]) : "v"(ha) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[1]) : "v"(ha) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(w[2]) : "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(w[3]) : "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w[4]) : "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[5]) : "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(w[6]) : "v"(hb) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[7]) : "v"(hb) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(w[8]) : "v"(pb) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(w[9]) : "v"(pb) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w[10]) : "v"(pb) : "memory");
+        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[11]) : "v"(pb) : "memory");
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(w[12]) : "v"(da) : "memory");
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(w[13]) : "v"(db) : "memory");
         return r;
     };
-    auto flat_wait = [&](Rec &r) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.hx_a), "+v"(r.hw_a), "+v"(r.p_a), "+v"(r.hx_b), "+v"(r.hw_b), "+v"(r.p_b), "+v"(r.dn_a), "+v"(r.dn_b) : : "memory");
+    auto flat_take = [&](const Raw &n) {
+        Raw c;
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %14\n\tv_mov_b32 %1, %15\n\tv_mov_b32 %2, %16\n\tv_mov_b32 %3, %17\n\tv_mov_b32 %4, %18\n\t"
+                     "v_mov_b32 %5, %19\n\tv_mov_b32 %6, %20\n\tv_mov_b32 %7, %21\n\tv_mov_b32 %8, %22\n\tv_mov_b32 %9, %23\n\tv_mov_b32 %10, %24\n\t"
+                     "v_mov_b32 %11, %25\n\tv_mov_b32 %12, %26\n\tv_mov_b32 %13, %27"
+                     : "=&v"(c.w[0]), "=&v"(c.w[1]), "=&v"(c.w[2]), "=&v"(c.w[3]), "=&v"(c.w[4]), "=&v"(c.w[5]), "=&v"(c.w[6]), "=&v"(c.w[7]),
+                       "=&v"(c.w[8]), "=&v"(c.w[9]), "=&v"(c.w[10]), "=&v"(c.w[11]), "=&v"(c.w[12]), "=&v"(c.w[13])
+                     : "v"(n.w[0]), "v"(n.w[1]), "v"(n.w[2]), "v"(n.w[3]), "v"(n.w[4]), "v"(n.w[5]), "v"(n.w[6]), "v"(n.w[7]), "v"(n.w[8]),
+                       "v"(n.w[9]), "v"(n.w[10]), "v"(n.w[11]), "v"(n.w[12]), "v"(n.w[13])
+                     : "memory");
+        return c;
     };
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
-        flat_wait(nxt);
-        const Rec cur = nxt;
-        if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
+        const Raw cur = flat_take(nxt.raw);
+        const int cur_rel = nxt.rel, cur_lim = nxt.lim;
+        nxt = fetch(base + CW_WAVE);                                          // (past the wave's last batch: clamped indices, never read)
         const int in_batch = min(q_mine - base, CW_WAVE);
         for (int k = 0; k < in_batch; k++) {
             if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
             for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 7");
-            const int rel_a = __builtin_amdgcn_readlane(cur.rel, k);
-            const int lim = __builtin_amdgcn_readlane(cur.lim, k);
-            const bool dn_a = want_done && __builtin_amdgcn_readlane(cur.dn_a, k) != 0;
-            const bool dn_b = want_done && __builtin_amdgcn_readlane(cur.dn_b, k) != 0;
+            const int rel_a = __builtin_amdgcn_readlane(cur_rel, k);
+            const int lim = __builtin_amdgcn_readlane(cur_lim, k);
+            const bool dn_a = want_done && __builtin_amdgcn_readlane(cur.w[12], k) != 0;
+            const bool dn_b = want_done && __builtin_amdgcn_readlane(cur.w[13], k) != 0;
             const int rel_b = rel_a + (int)FB;
             uint8_t *const jb = dst_base + (size_t)((base + k) * n_waves + wave) * JB;
             const uint4 z4 = make_uint4(0, 0, 0, 0);
             if (!dn_a && !dn_b && lim == (int)JB) {                           // nearly always: the whole job, no finished env in it
-#pragma unroll
-                for (uint32_t c = 0; c < JB / 1024u; c++) {
-                    *(uint4 *)(jb + c * 1024u + 16u * lane) = z4;
-                    if (c == 1 && pace_mid) __builtin_amdgcn_s_sleep(1);
+                uint8_t *q = jb + 16u * lane;
+                for (int c = 0; c < chunks; c++, q += 1024) {
+                    *(uint4 *)q = z4;
+                    if (pace_mid && (c & 1) && c + 1 < chunks) __builtin_amdgcn_s_sleep(1);
                 }
             } else {                                                           // bytes of a finished env's frame belong to its resetting wave
-#pragma unroll
-                for (uint32_t c = 0; c < JB / 1024u; c++) {
-                    const int rel = (int)(c * 1024u + 16u * lane);
+                for (int c = 0; c < chunks; c++) {
+                    const int rel = c * 1024 + 16 * lane;
                     const bool skip = (rel < rel_b) ? dn_a : dn_b;
                     if (rel < lim && !skip) *(uint4 *)(jb + rel) = z4;
                 }
             }
             u32x4s pp;
             if (!dn_a) {
-                pp.x = __builtin_amdgcn_readlane(cur.p_a.x, k);
-                pp.y = __builtin_amdgcn_readlane(cur.p_a.y, k);
-                pp.z = __builtin_amdgcn_readlane(cur.p_a.z, k);
-                pp.w = __builtin_amdgcn_readlane(cur.p_a.w, k);
-                flat_patch(jb, rel_a, lim, __builtin_amdgcn_readlane(cur.hx_a, k), __builtin_amdgcn_readlane(cur.hw_a, k), pp, L, v_table,
+                pp.x = __builtin_amdgcn_readlane(cur.w[2], k);
+                pp.y = __builtin_amdgcn_readlane(cur.w[3], k);
+                pp.z = __builtin_amdgcn_readlane(cur.w[4], k);
+                pp.w = __builtin_amdgcn_readlane(cur.w[5], k);
+                flat_patch(jb, rel_a, lim, __builtin_amdgcn_readlane(cur.w[0], k), __builtin_amdgcn_readlane(cur.w[1], k), pp, L, v_table,
                            S, P.ncell, P.div_magic, lane);
             }
             if (rel_b < lim && !dn_b) {
-                pp.x = __builtin_amdgcn_readlane(cur.p_b.x, k);
-                pp.y = __builtin_amdgcn_readlane(cur.p_b.y, k);
-                pp.z = __builtin_amdgcn_readlane(cur.p_b.z, k);
-                pp.w = __builtin_amdgcn_readlane(cur.p_b.w, k);
-                flat_patch(jb, rel_b, lim, __builtin_amdgcn_readlane(cur.hx_b, k), __builtin_amdgcn_readlane(cur.hw_b, k), pp, L, v_table,
+                pp.x = __builtin_amdgcn_readlane(cur.w[8], k);
+                pp.y = __builtin_amdgcn_readlane(cur.w[9], k);
+                pp.z = __builtin_amdgcn_readlane(cur.w[10], k);
+                pp.w = __builtin_amdgcn_readlane(cur.w[11], k);
+                flat_patch(jb, rel_b, lim, __builtin_amdgcn_readlane(cur.w[6], k), __builtin_amdgcn_readlane(cur.w[7], k), pp, L, v_table,
                            S, P.ncell, P.div_magic, lane);
             }
         }
     }
     CW_WAVE_BUSY(P, t_start, bid & 1);
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
+}
+
+// ---- the same fill + patch, ONE WAVE PER FRAME, not persistent (the shape of a plain device fill): the grid has a wave per env,
+// workgroups are dispatched in address order, a wave fetches its env's record with scalar loads (wave-uniform), writes the frame's
+// 48*S*S bytes as zeros -- 16 B per lane, 1 KiB per store instruction, 16-byte aligned (a frame shares only its first and last line
+// with its neighbours, painted by the neighbouring waves of the same workgroup) -- patches the <= 36 coloured cell rows and exits.
+// Latencies are hidden by occupancy (no LDS, few registers), not by prefetching.
+template <int MODE>
+__device__ __forceinline__ void render_fill_frame(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int env)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const bool want_done = (MODE == 3) && skip_done;
+    const u32x4s h = cload((const u32x4s *)(P.hdr + env));
+    const u32x4s pp = cload((const u32x4s *)(P.pos + env));
+    if (want_done) {
+        const uint32_t dw = cload((const uint32_t *)(P.done + (env & ~3)));
+        if ((dw >> (8 * (env & 3))) & 0xFFu) return;                           // finished: its resetting wave paints it
+    }
+    const uint32_t FB = P.frame_bytes;
+    uint8_t *const dst = ((MODE == 2) ? ext_out : P.obs) + (size_t)env * FB;
+    CwFlatLane L;
+    L.sh16 = 16u * (((uint32_t)lane >> 2) & 1u);
+    L.sh4 = 4u * ((uint32_t)lane >> 2);
+    L.dy = (uint32_t)lane & 3u;
+    L.obj = lane < 32;
+    L.agent = lane >= 32 && lane < 36;
+    L.mid = L.dy == 1u || L.dy == 2u;
+    L.row2 = L.dy == 2u;
+    const uint32_t v_table = rgb_of_code((uint32_t)lane);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const uint32_t n_full = FB >> 10, rem = FB & 1023u;
+    uint8_t *q = dst + 16u * lane;
+    for (uint32_t c = 0; c < n_full; c++, q += 1024) {
+        *(uint4 *)q = z4;
+        if (c & 1) for (int z = 0; z < (pace & 0xFF); z++) __builtin_amdgcn_s_sleep(1);
+    }
+    if (16u * lane < rem) *(uint4 *)q = z4;
+    flat_patch(dst, 0, (int)FB, h.x, h.w, pp, L, v_table, P.size, P.ncell, P.div_magic, lane);
+}
+// grid: [reset_blocks resetting workgroups first (they are dispatched first and run beside the early frames)] + ceil(N / 4) frame workgroups
+__global__ __launch_bounds__(256) void cw_render_fill_step_kernel(CwParams P, int reset_blocks, int pace)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    if ((int)blockIdx.x < reset_blocks) { reset_list_block(P, s_mt, (int)blockIdx.x, reset_blocks, 1, 0, 1); return; }
+    const int env = ((int)blockIdx.x - reset_blocks) * (int)(blockDim.x / CW_WAVE) + (int)__builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    if (env < P.n_envs) render_fill_frame<3>(P, 1, nullptr, pace, env);
+}
+__global__ __launch_bounds__(256) void cw_render_fill_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace)
+{
+    const int env = (int)blockIdx.x * (int)(blockDim.x / CW_WAVE) + (int)__builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    if (env >= P.n_envs) return;
+    if (mode == 3) render_fill_frame<3>(P, skip_done, ext_out, pace, env);
+    else render_fill_frame<2>(P, skip_done, ext_out, pace, env);
 }
 
 // the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
@@ -1634,16 +1698,16 @@ __global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int ren
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
 // ... and with the flat sweep (render_flat)
-__global__ __launch_bounds__(256) void cw_render_flat_step_kernel(CwParams P, int render_blocks, int pace)
+__global__ __launch_bounds__(256) void cw_render_flat_step_kernel(CwParams P, int render_blocks, int pace, int chunks)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_flat<3>(P, 1, nullptr, pace, (int)blockIdx.x, render_blocks);
+    if ((int)blockIdx.x < render_blocks) render_flat<3>(P, 1, nullptr, pace, chunks, (int)blockIdx.x, render_blocks);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
-__global__ __launch_bounds__(256) void cw_render_flat_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace)
+__global__ __launch_bounds__(256) void cw_render_flat_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace, int chunks)
 {
-    if (mode == 3) render_flat<3>(P, skip_done, ext_out, pace, (int)blockIdx.x, (int)gridDim.x);
-    else render_flat<2>(P, skip_done, ext_out, pace, (int)blockIdx.x, (int)gridDim.x);
+    if (mode == 3) render_flat<3>(P, skip_done, ext_out, pace, chunks, (int)blockIdx.x, (int)gridDim.x);
+    else render_flat<2>(P, skip_done, ext_out, pace, chunks, (int)blockIdx.x, (int)gridDim.x);
 }
 // the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
 __global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
@@ -1808,11 +1872,14 @@ static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
     const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
     return tn.render_linear >= 2 || jobs <= 2560 * waves;
 }
-// flat sweep (render_flat): Ray raster, frames of at least one job (S >= 8), 16-byte aligned destination
+// flat sweep (render_flat)?  -> 1-KiB chunks per job (0: no): Ray raster, 16-byte aligned destination, a job no longer than a frame
 static inline int cw_render_flat(const CwParams &P, const CwTuning &tn, const uint8_t *dst)
 {
-    if (!tn.render_flat || P.raster != 0 || P.frame_bytes < CW_FLAT_JB || ((uintptr_t)dst & 15u)) return 0;
-    return ((unsigned long long)P.n_envs * P.frame_bytes + CW_FLAT_JB - 1) / CW_FLAT_JB < (1ull << 31);
+    if (!tn.render_flat || P.raster != 0 || P.frame_bytes < 1024u || ((uintptr_t)dst & 15u)) return 0;
+    int chunks = tn.flat_chunks < 1 ? 1 : tn.flat_chunks;
+    if ((uint32_t)chunks > P.frame_bytes / 1024u) chunks = (int)(P.frame_bytes / 1024u);
+    const unsigned long long jb = 1024ull * chunks;
+    return ((unsigned long long)P.n_envs * P.frame_bytes + jb - 1) / jb < (1ull << 30) ? chunks : 0;
 }
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
@@ -1835,7 +1902,11 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) hipLaunchKernelGGL(cw_render_flat_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, tn.render_pace);
+    if (tn.render_flat == 2 && cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) {
+        hipLaunchKernelGGL(cw_render_fill_kernel, dim3((P.n_envs + 3) / 4), dim3(256), 0, st, P, mode, skip_done, ext_out, tn.render_pace);
+        return;
+    }
+    if (const int chunks = cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) hipLaunchKernelGGL(cw_render_flat_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, tn.render_pace, chunks);
     else if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
     else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
@@ -1899,8 +1970,10 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/r02_fused_render.txt H)
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-        if (cw_render_flat(*P, tn, P->obs))
-            hipLaunchKernelGGL(cw_render_flat_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        if (tn.render_flat == 2 && cw_render_flat(*P, tn, P->obs))
+            hipLaunchKernelGGL(cw_render_fill_step_kernel, dim3(reset_blocks + (n + 3) / 4), dim3(256), 0, st, *P, reset_blocks, tn.render_pace);
+        else if (const int chunks = cw_render_flat(*P, tn, P->obs))
+            hipLaunchKernelGGL(cw_render_flat_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace, chunks);
         else if (cw_render_linear(*P, tn))
             hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
         else
@@ -2017,7 +2090,7 @@ hipError_t cwk_launch_idle(hipStream_t st)
 }
 
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
-int cwk_render_is_flat(const CwParams *P, const CwTuning *T) { return cw_render_flat(*P, *T, P->obs); }
+int cwk_render_is_flat(const CwParams *P, const CwTuning *T) { return cw_render_flat(*P, *T, P->obs) ? T->render_flat : 0; }
 int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)

@@ -54,6 +54,7 @@ struct CwTuning {
     int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
     int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
     int render_flat = 0;            // full-frame render as a FLAT sweep: line-aligned zero fill of the frame array + <= 36 patched cell rows per frame (render_flat)
+    int flat_chunks = 3;            // ... its job size in KiB (capped at the frame size)
     int render_pace_fine = 0;       // ... bits 16-23 of render_pace: x `s_nop 7` (+ loop overhead, ~16 clocks) before every job
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset kernels
     int fused_reset_blocks_per_cu = 1;   // ... and the resetting tail of the one-launch full-frame step (cwk_launch_step)

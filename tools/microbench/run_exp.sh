@@ -22,7 +22,8 @@ for rep in $(seq 1 "$REPS"); do
     label=$(echo "$label" | sed 's/^ *//;s/ *$//'); [ -z "$label" ] && continue; case "$label" in \#*) continue;; esac
     if [ "${label#pytest}" != "$label" ]; then
       [ "$rep" = 1 ] || continue
-      line=$(env $envs timeout -k 10 900 python -m pytest tests -m gpu -x -q $args 2>&1 | tail -1)
+      env $envs timeout -k 10 900 python -m pytest tests -m gpu -q $args > gpurun_out/last_pytest.txt 2>&1
+      tail -40 gpurun_out/last_pytest.txt >> "${OUT%.txt}_pytest.txt"; line=$(tail -1 gpurun_out/last_pytest.txt)
       printf '%-46s %s\n' "$label" "$line" | tee -a "$OUT"
       continue
     fi
