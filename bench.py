@@ -176,8 +176,10 @@ def main():
     ap.add_argument('--mixed-menus', action='store_true',
                     help='BASELINE configs[3] shape: env i uses ordered task list i mod 8 of a fixed menu of eight (heterogeneous selected_tasks / '
                          'number_of_tasks / stacking / reward_style per env)')
-    ap.add_argument('--prewarm-steps', type=int, default=200,
-                    help='untimed steps before the W warm-up steps, to bring a card that idled through set-up to its steady state (0: none)')
+    ap.add_argument('--prewarm-steps', type=int, default=288,
+                    help='untimed steps before the W warm-up steps (0: none): a card that idled through set-up runs its first ~100 launches 3-5 %% '
+                         'slower, and the engine surveys the eight placements of its sweep loop over its first 256 steps (cw_engine.cpp: adapt_tick); '
+                         'reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
     ap.add_argument('--quick', action='store_true',

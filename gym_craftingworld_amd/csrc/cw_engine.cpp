@@ -18,7 +18,6 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev, int la_parity);
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
-int cwk_render_is_flat(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity, int all_envs, hipStream_t st);
 hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
@@ -103,9 +102,22 @@ struct cw_engine {
         signed char pace_of_window[64] = {0};  // what each recent window ran at; negative: a settling window, not counted
         float stat[16] = {0};                  // per pace: running mean step time of its counted windows (ms; 0: unknown)
         unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
+        // ... and of the PLACEMENT of the sweep's batch loop (cw_render_step_kernel<k>, cw_kernels.hip: render_groups)
+        bool pace_on = false;                  // (1) is tuned (off: CW_TUNE_RENDER_PACE_BESIDE forces the number)
+        bool place_on = false;                 // (2) is tuned (off: CW_TUNE_RENDER_PLACE forces one)
+        int place = 3;                         // the placement held outside a survey
+        bool surveying = false;
+        unsigned survey_w0 = 0;                // first window of the running survey
+        signed char place_of_window[64] = {0}; // placement each recent window ran at
+        signed char round_of_window[64] = {0}; // 0: not a survey window; r + 1: round r of a survey (round 0 is not counted)
+        float survey_ms[8][3] = {{0}};         // ms per step of placement k in survey rounds 1..3
+        unsigned survey_seen = 0;              // survey windows read so far
+        float place_ms = 0;                    // what `place` measured when it was chosen
+        int place_bad = 0;                     // consecutive counted windows more than 4 % above that
+        unsigned surveys = 0;
     } adapt;
 };
-enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8 };
+enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24 };
 
 // Look-ahead engines keep mt[] two episodes ahead of the reference's timeline.  Every entry point that reads or replaces the
 // RNG streams, or resets outside cw_step, first returns to the canonical form (mt[e] = snapshot of e's next slot); the next
@@ -338,38 +350,96 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     return CW_OK;
 }
 
-// Online tuner of the sweep's extra sleeps beside resets.  How much the sweep has to slow down while envs are being reset beside it
-// depends on the box and on how many are reset per step (profiles/r02_pace.txt, r02_fused_render.txt), and launches timed at
-// cw_create do not predict it.  So cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every
-// CW_ADAPT_W steps (a "window"), and the time between two consecutive ones, read whenever both have completed -- however far the host
-// runs ahead of the GPU -- is what CW_ADAPT_W whole steps took.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1,
-// two at cur - 1 (the first window after a change settles and is not counted; a window holding a step on which every env was reset
-// is an outlier and is not counted either); each counted window updates the running figure of its value, and `cur` moves to a
-// neighbour whose figure is 0.7 % better (figures older than three cycles do not count).  With fewer than CW_BESIDE_MIN resets per
-// step the value is never used by the kernel and its drift is harmless.  Only performance depends on any of it.
+// Online tuner of the one-launch full-frame step: (1) the sweep's extra sleeps beside resets, (2) the placement of its batch loop.
+// Neither can be predicted from launches timed at cw_create (profiles/r02_pace.txt, r02_fused_render.txt, r03_placement.txt), so cw_step
+// keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and the time between
+// two consecutive ones, read whenever both have completed -- however far the host runs ahead of the GPU -- is what CW_ADAPT_W whole steps
+// took.  Only performance depends on any of it: every placement and every pace paints the same frames.
+// (1) Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the first window after a change settles and is
+// not counted; a window holding a step on which every env was reset is an outlier and is not counted either); each counted window updates
+// the running figure of its value, and `cur` moves to a neighbour whose figure is 0.7 % better (figures older than three cycles do not
+// count).  With fewer than CW_BESIDE_MIN resets per step the value is never used by the kernel and its drift is harmless.
+// (2) The same instructions run up to 17 % apart depending on where the batch loop lies modulo 32 bytes, and which placement is the good one
+// changes with the loop body, the compiler and the box.  So all eight are built (cw_render_step_kernel<k>) and a SURVEY picks one: four
+// rounds of one window per placement (the first round -- a variant's first launches load its code -- is not counted), the placement with
+// the lowest median of its three counted windows is then held.  A survey runs when the engine starts stepping and again when the held
+// placement has read more than 4 % above its own survey figure for CW_PLACE_BAD_WINDOWS counted windows in a row (the regime has moved:
+// e.g. episode phases that have spread out).  The pace of (1) is frozen during a survey.  CW_TUNE_RENDER_PLACE=k forces a placement.
 static void adapt_tick(cw_engine *e, hipStream_t st)
 {
     cw_engine::Adapt &a = e->adapt;
     const unsigned w = a.seq / CW_ADAPT_W;           // the window about to start
     if (hipEventRecord(a.ev[w % 64], st) != hipSuccess) return;
+    const bool verbose = getenv("CW_TUNE_VERBOSE") != nullptr;
     bool moved = false;
     while (a.next_window + 1 <= w) {                 // window next_window lies between ev[next_window] and ev[next_window + 1]
         const unsigned cw = a.next_window;
-        if (w - cw >= 63) { a.next_window++; continue; }                         // (its events have been reused)
+        if (w - cw >= 63) {                                                      // (its events have been reused)
+            if (a.round_of_window[cw % 64]) a.survey_seen++;                     //  a survey window lost: its sample stays 0 = unknown
+            a.next_window++;
+            continue;
+        }
         if (cw + 1 == w) break;                                                  // its closing event was recorded just now
         if (hipEventQuery(a.ev[(cw + 1) % 64]) != hipSuccess) break;
         float ms = 0.f;
         const int p = a.pace_of_window[cw % 64];
+        const int round = a.round_of_window[cw % 64], place = a.place_of_window[cw % 64];
         a.next_window++;
-        if (p < 0 || hipEventElapsedTime(&ms, a.ev[cw % 64], a.ev[(cw + 1) % 64]) != hipSuccess || ms <= 0.f) continue;
+        const bool timed = hipEventElapsedTime(&ms, a.ev[cw % 64], a.ev[(cw + 1) % 64]) == hipSuccess && ms > 0.f;
         ms /= (float)CW_ADAPT_W;
+        if (round) {                                                             // a survey window
+            if (timed && round >= 2) a.survey_ms[place & 7][round - 2] = ms;
+            a.survey_seen++;
+            continue;
+        }
+        if (p < 0 || !timed) continue;
         const bool known = a.stat[p] > 0 && cw - a.stat_window[p] < 80;
         if (known && ms > 1.06f * a.stat[p]) continue;                           // a reset storm inside the window
         a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
         a.stat_window[p] = cw;
         moved = true;
+        if (a.place_on && !a.surveying && a.place_ms > 0 && p == a.cur)          // is the held placement still what it was?
+            a.place_bad = ms > 1.04f * a.place_ms ? a.place_bad + 1 : 0;
     }
-    if (moved) {                                     // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
+    if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
+        int best = a.place;                                                      // every survey window has been read: hold the best placement
+        float best_ms = 0.f;
+        char log[256] = "";
+        size_t len = 0;
+        for (int k = 0; k < CW_PLACES; k++) {
+            float *m = a.survey_ms[k];
+            if (m[0] <= 0 || m[1] <= 0 || m[2] <= 0) continue;                   // (a lost sample: the placement does not compete)
+            const float med = std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2]));
+            if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", k, med);
+            if (best_ms == 0.f || med < best_ms) { best_ms = med; best = k; }
+        }
+        if (verbose) fprintf(stderr, "[craftingworld] placement survey %u (window %u), median ms/step by placement:%s -> %d\n", a.surveys, w, log, best);
+        a.place = best;
+        a.place_ms = best_ms;
+        a.place_bad = 0;
+        a.surveying = false;
+        for (int p = 0; p < 16; p++) a.stat[p] = 0;                              // the pace figures belonged to the old placement
+    }
+    if (a.place_on && !a.surveying && (a.surveys == 0 || a.place_bad >= CW_PLACE_BAD_WINDOWS)) {
+        if (verbose && a.surveys) fprintf(stderr, "[craftingworld] placement %d has read > 4 %% above its %.4f ms/step for %d windows: new survey\n",
+                                          a.place, a.place_ms, a.place_bad);
+        a.surveying = true;
+        a.survey_w0 = w;
+        a.survey_seen = 0;
+        a.place_bad = 0;
+        a.surveys++;
+        for (int k = 0; k < CW_PLACES; k++) a.survey_ms[k][0] = a.survey_ms[k][1] = a.survey_ms[k][2] = 0.f;
+    }
+    if (a.surveying && w < a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {         // a survey window: placement by turns, pace frozen
+        const unsigned j = w - a.survey_w0;
+        a.place_of_window[w % 64] = (signed char)(j % CW_PLACES);
+        a.round_of_window[w % 64] = (signed char)(j / CW_PLACES + 1);
+        a.pace_of_window[w % 64] = (signed char)a.cur;
+        return;
+    }
+    a.place_of_window[w % 64] = (signed char)a.place;                            // (survey windows still being read: the old placement meanwhile)
+    a.round_of_window[w % 64] = 0;
+    if (moved && !a.surveying && a.pace_on) {        // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
         const int c = a.cur;
         auto fresh = [&](int p) { return p >= 0 && p <= CW_ADAPT_MAX && a.stat[p] > 0 && a.next_window - a.stat_window[p] < 80; };
         if (fresh(c)) {
@@ -377,7 +447,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             if (fresh(c + 1) && a.stat[c + 1] < a.stat[best] * 0.993f) best = c + 1;
             if (fresh(c - 1) && a.stat[c - 1] < a.stat[best] * (best == c ? 0.993f : 1.0f)) best = c - 1;
             if (best != c) {
-                if (getenv("CW_TUNE_VERBOSE"))
+                if (verbose)
                     fprintf(stderr, "[craftingworld] sleeps beside resets (online, window %u): +%d %.4f ms/step | +%d %.4f | +%d %.4f -> +%d\n", w, c,
                             a.stat[c], c + 1, fresh(c + 1) ? a.stat[c + 1] : 0.0, c - 1, fresh(c - 1) ? a.stat[c - 1] : 0.0, best);
                 a.cur = best;
@@ -387,9 +457,11 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
     // the cycle: 0-19 cur | 20 (settle), 21 cur + 1 | 22 (settle), 23 cur - 1; window 0 of the cycle settles too
     const unsigned pos = w % 24;
     int p = a.cur;
-    const bool settle = (pos == 0 || pos == 20 || pos == 22);
-    if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
-    else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
+    const bool settle = (pos == 0 || pos == 20 || pos == 22) || a.surveying;
+    if (!a.surveying && a.pace_on) {
+        if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
+        else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
+    }
     a.pace_of_window[w % 64] = (signed char)(settle ? -1 - p : p);
 }
 
@@ -566,9 +638,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
-        tn.render_flat = geti("CW_TUNE_RENDER_FLAT", tn.render_flat);
         tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
-        tn.flat_chunks = geti("CW_TUNE_FLAT_CHUNKS", tn.flat_chunks);
+        tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
         if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
@@ -671,16 +742,19 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
     if (rc == CW_OK) e->tune.render_pace |= (e->tune.render_pace_fine & 0xFF) << 16;
-    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
-        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_flat(&e->P, &e->tune)) &&
-        !getenv("CW_TUNE_RENDER_PACE_BESIDE") && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) &&
-        (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
+    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
+        !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
-        for (hipEvent_t &ev : a.ev)
-            if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: pace tuner set-up failed");
         a.cur = (e->tune.render_pace >> 12) & 15;
         if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
-        a.on = rc == CW_OK;
+        a.pace_on = !getenv("CW_TUNE_RENDER_PACE_BESIDE");
+        a.place = e->tune.render_place;
+        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+        if (a.pace_on || a.place_on) {
+            for (hipEvent_t &ev : a.ev)
+                if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
+            a.on = rc == CW_OK;
+        }
     }
     if (rc != CW_OK) {
         cw_destroy(e);
@@ -829,9 +903,11 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
             const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
             e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | ((pw < 0 ? -1 - pw : pw) << 12);
+            if (e->adapt.place_on) e->tune.render_place = e->adapt.place_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
             e->adapt.seq++;
         } else {
-            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | (e->adapt.cur << 12);     // a captured graph keeps the value it was captured with
+            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | (e->adapt.cur << 12);     // a captured graph keeps the values it was captured with
+            if (e->adapt.place_on) e->tune.render_place = e->adapt.place;
         }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
@@ -956,8 +1032,6 @@ const char *cw_render_kernel_name(const cw_engine *e)
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
-    if (cwk_render_is_flat(&e->P, &e->tune) == 2) return one_launch ? "cw_render_fill_step_kernel" : "cw_render_fill_kernel";
-    if (cwk_render_is_flat(&e->P, &e->tune)) return one_launch ? "cw_render_flat_step_kernel" : "cw_render_flat_kernel";
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
 }

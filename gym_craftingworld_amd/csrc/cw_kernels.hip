@@ -585,6 +585,8 @@ __device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint3
 // 65 536 envs succeed on almost every step, and 1-5 resetting waves do not disturb the sweep -- reacting to them cost 15 us on most
 // launches of the synchronized benchmark (the "two launch modes" of profiles/r02_pace.txt H)
 #define CW_BESIDE_MIN 32
+#define CW_PLACE_DEFAULT 3   // placement of render_groups' batch loop where no tuner picks it (cw_render, the two-kernel step)
+#define CW_N_PLACES 8
 
 // One env's reset() (ray.py:156-218) by one wavefront; every value in the result is wave-uniform.
 struct CwResetOut {
@@ -1337,7 +1339,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
 // (0.2407 vs 0.2471 ms) -- the smoother the stream of stores, the better.  So a wave sleeps 64 clocks in the middle of
 // a job's stores (`pace` bit 8) and `pace & 0xFF` x 64 clocks per pair of jobs; cw_create finds both on the box it runs on,
 // as it does the XCD shares.
-template <int MODE>
+template <int MODE, int PLACE = CW_PLACE_DEFAULT>
 __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
                                               int bid, int n_blocks)
 {
@@ -1376,7 +1378,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // beside it, which is what it then is.)
     const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
-    const int pace_fine = (pace >> 16) & 0xFF;                               // x ~16 clocks before every job (s_nop loop)
+    const int pace_fine = (pace >> 16) & 0xFF;                               // iterations of a one-s_nop loop before every job
     CW_WAVE_CLOCK(t_start);
     if (MODE == 3) CW_WAVE_STAMP(wave, 0);
     struct Rec { int env, g; uint32_t hx, hw, done; uint4 p; };
@@ -1397,12 +1399,16 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         }
         return r;
     };
-    // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions read
-    // 0.2325 ms at this placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few clocks
-    // per job at the loop's branch targets, a pace finer than s_sleep's 64 clocks (profiles/r02_pace.txt N-P).  So the placement
-    // is pinned: a 32-byte boundary plus three s_nop (executed once per wave).  After editing the loop below, or to try a neighbour:
-    // tools/microbench/exp_align.sh.
-    asm volatile(".p2align 5");asm volatile("s_nop 0"); asm volatile("s_nop 0"); asm volatile("s_nop 0");
+    // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions have
+    // read 0.2325 ms at one placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few
+    // clocks per job at the loop's branch targets (profiles/r02_pace.txt N-P) -- and which placement is the good one moves with every edit
+    // of the loop body, with the box, and would move with the compiler (profiles/r03_placement.txt).  So the placement is a TUNED parameter,
+    // not a pinned one: the one-launch step is built at all eight placements modulo 32 bytes (PLACE x s_nop after a 32-byte boundary,
+    // executed once per wave; cw_render_step_kernel<0..7>) and cw_step measures which one this process should run (cw_engine.cpp: adapt_tick).
+    asm volatile(".p2align 5");
+#pragma unroll
+    for (int z = 0; z < PLACE; z++) asm volatile("s_nop 0");
+    asm volatile("cw_sweep_head_%=:" ::);             // (a local symbol: tools/isa_report.py reads the loop's address off the code object)
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
         const Rec cur = nxt;
@@ -1410,7 +1416,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         const int in_batch = min(q_mine - base, CW_WAVE);
         for (int k = 0; k < in_batch; k++) {
             if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
-            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 7");
+            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 0");
             const int env = __builtin_amdgcn_readlane(cur.env, k);
             if (env < 0) continue;
             if (want_done && __builtin_amdgcn_readlane(cur.done, k)) continue;
@@ -1450,235 +1456,6 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
-// ---- FLAT sweep: the frame array as ONE BYTE STREAM, zero-filled with line-aligned 16-byte stores, then patched ----------
-// A Ray frame is almost all zeros: COLORS_N[0] is black and at most 8 objects + the agent are on the grid, so <= 9 of the S*S cells
-// (<= 36 twelve-byte cell rows) are not.  Job = `chunks` KiB of the frame array starting at a multiple of that, whatever
-// frames those bytes belong to (48*S*S is a multiple of 16 but not of 128: a frame starts anywhere in a cache line, and a job holds
-// the end of one frame and the start of the next 1 time in 7 at 21x21): the wave writes zeros, 64 lanes x 16 B = 1 KiB of whole
-// 128-B lines per store instruction -- the shape of a plain fill, no store shares a line with another wave's -- and then lanes 0..35
-// store the coloured cell rows of the job's frame(s) that lie inside the job: lane = (slot or agent, pixel row of the cell), 12 B each,
-// clipped to the job dword by dword where a cell row crosses its edge (rare: a scalar branch).  One wave's stores to one address are
-// performed in program order, so the patch lands on the fill; the line is still in L2 then, so HBM sees it once.  No load, no LDS in the
-// loop, records a batch ahead as in render_groups.  (A job is at most a frame long: at most two frames per job.)
-struct CwFlatLane {                  // per-lane constants of the patch
-    uint32_t sh16, sh4;              // 16 * (slot & 1), 4 * slot
-    uint32_t dy;
-    bool obj, agent, mid, row2;      // lane < 32 | lanes 32..35 | dy is 1 or 2 | dy == 2
-};
-__device__ __forceinline__ void flat_patch(uint8_t *__restrict__ jb, int rel_e, int lim, uint32_t hx, uint32_t codes, const u32x4s &pp,
-                                           const CwFlatLane &L, uint32_t v_table, int S, int ncell, uint32_t div_magic, int lane)
-{
-    const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
-    const uint32_t hold = (hx >> 16) & 0xFFu;
-    const uint32_t o2 = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;    // ray.py:484-486
-    // the lane's slot: its u16 of the position record, its nibble of the codes
-    const uint32_t w = L.sh4 < 8u ? pp.x : L.sh4 < 16u ? pp.y : L.sh4 < 24u ? pp.z : pp.w;
-    uint32_t cell = (w >> L.sh16) & 0xFFFFu;
-    uint32_t code = (codes >> (L.sh4 & 31u)) & 15u;
-    const bool under = L.obj && L.dy == 0 && code != 0 && cell == agent_cell;                 // an object in the agent's cell: its lanes paint the overlay
-    const bool obj_under_agent = CW_BALLOT(under) != 0;
-    if (L.agent) { cell = agent_cell; code = 0; }
-    const bool valid = L.obj ? (code != 0 && cell < (uint32_t)ncell) : (L.agent && !obj_under_agent);
-    const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);
-    u32x3 d = cell_row_dwords(col);
-    if (cell == agent_cell && L.mid) d = overlay_dwords(d, L.row2 ? o2 : 0x00FFFFFFu);     // ray.py:483-486
-    const uint32_t r = __umulhi(cell, div_magic), c = cell - r * S;
-    const int rel = rel_e + (int)((4u * r + L.dy) * (12u * S) + 12u * c);         // first byte of the cell row, relative to the job
-    const bool inside = valid && rel >= 0 && rel + 12 <= lim;
-    if (inside) *(u32x3_a4 *)(jb + rel) = d;
-    const bool partial = valid && !inside && rel + 12 > 0 && rel < lim;           // crosses the job's edge: the dwords on this side
-    if (CW_BALLOT(partial)) {
-        if (partial && rel >= 0 && rel + 4 <= lim) *(uint32_t *)(jb + rel) = d.x;
-        if (partial && rel + 4 >= 0 && rel + 8 <= lim) *(uint32_t *)(jb + rel + 4) = d.y;
-        if (partial && rel + 8 >= 0 && rel + 12 <= lim) *(uint32_t *)(jb + rel + 8) = d.z;
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void render_flat(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int chunks, int bid, int n_blocks)
-{
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wpb = blockDim.x / CW_WAVE;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = bid * wpb + wave_in_block;
-    const int n_waves = n_blocks * wpb;
-    const uint32_t FB = P.frame_bytes, JB = 1024u * (uint32_t)chunks;            // (the launcher made sure that JB <= FB: at most two frames per job)
-    const unsigned long long total = (unsigned long long)P.n_envs * FB;
-    const int n_jobs = (int)((total + JB - 1) / JB);                           // (the launcher checked that this fits)
-    if (wave >= n_jobs) return;
-    const int q_mine = (n_jobs - wave + n_waves - 1) / n_waves;               // jobs wave, wave + n_waves, ...
-    const bool want_done = (MODE == 3) && skip_done;
-    const int S = P.size;
-    CwFlatLane L;
-    L.sh16 = 16u * (((uint32_t)lane >> 2) & 1u);
-    L.sh4 = 4u * ((uint32_t)lane >> 2);
-    L.dy = (uint32_t)lane & 3u;
-    L.obj = lane < 32;
-    L.agent = lane >= 32 && lane < 36;
-    L.mid = L.dy == 1u || L.dy == 2u;
-    L.row2 = L.dy == 2u;
-    const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
-    uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
-    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
-    const bool pace_mid = (pace & 0x100) != 0;
-    const int pace_fine = (pace >> 16) & 0xFF;                               // x ~16 clocks per job (s_nop loop)
-    CW_WAVE_CLOCK(t_start);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
-    // The records of a batch are fetched a batch ahead with loads the compiler does not see (inline asm): it would otherwise be free to
-    // wait for them before the job loop -- and does, depending on register allocation (SIInsertWaitcnts flushes vmcnt in a loop's
-    // preheader if the loop "uses" a register with a load pending, even one it redefines first) -- which puts a load round trip
-    // under the write storm on every batch boundary.  The loaded registers (Raw) are read in exactly one place: flat_take(), one asm
-    // block that waits for the loads and then copies them into the registers the job loop reads (tests/test_isa.py checks the built
-    // code object for both properties).  Every lane loads (clamped indices): no exec-masked region around the asm.
-    struct Raw { uint32_t w[14]; };      // hx_a, hw_a, p_a[4], hx_b, hw_b, p_b[4], dn_a, dn_b
-    struct Rec { int rel, lim; Raw raw; };
-    auto fetch = [&](int base) {
-        Rec r;
-        const int i = base + lane;
-        const int id = min(i * n_waves + wave, n_jobs - 1);
-        const unsigned long long lo = (unsigned long long)id * JB;
-        const uint32_t env = (uint32_t)(lo / FB);
-        r.rel = (int)((long long)((unsigned long long)env * FB) - (long long)lo);          // -FB < rel <= 0: where frame `env` starts
-        r.lim = (int)(total - lo < JB ? total - lo : JB);
-        // the next frame may start inside the job (1 job in 7 at 21x21); its record is fetched regardless (the neighbour's: same lines)
-        const uint32_t env_b = min(env + 1u, (uint32_t)P.n_envs - 1u);
-        const uint4 *ha = P.hdr + env, *hb = P.hdr + env_b, *pa = P.pos + env, *pb = P.pos + env_b;
-        const uint8_t *da = P.done + env, *db = P.done + env_b;
-        uint32_t *w = r.raw.w;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(w[0]) : "v"(ha) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[1]) : "v"(ha) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(w[2]) : "v"(pa) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(w[3]) : "v"(pa) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w[4]) : "v"(pa) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[5]) : "v"(pa) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(w[6]) : "v"(hb) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[7]) : "v"(hb) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(w[8]) : "v"(pb) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(w[9]) : "v"(pb) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(w[10]) : "v"(pb) : "memory");
-        asm volatile("global_load_dword %0, %1, off offset:12" : "=v"(w[11]) : "v"(pb) : "memory");
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(w[12]) : "v"(da) : "memory");
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(w[13]) : "v"(db) : "memory");
-        return r;
-    };
-    auto flat_take = [&](const Raw &n) {
-        Raw c;
-        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %14\n\tv_mov_b32 %1, %15\n\tv_mov_b32 %2, %16\n\tv_mov_b32 %3, %17\n\tv_mov_b32 %4, %18\n\t"
-                     "v_mov_b32 %5, %19\n\tv_mov_b32 %6, %20\n\tv_mov_b32 %7, %21\n\tv_mov_b32 %8, %22\n\tv_mov_b32 %9, %23\n\tv_mov_b32 %10, %24\n\t"
-                     "v_mov_b32 %11, %25\n\tv_mov_b32 %12, %26\n\tv_mov_b32 %13, %27"
-                     : "=&v"(c.w[0]), "=&v"(c.w[1]), "=&v"(c.w[2]), "=&v"(c.w[3]), "=&v"(c.w[4]), "=&v"(c.w[5]), "=&v"(c.w[6]), "=&v"(c.w[7]),
-                       "=&v"(c.w[8]), "=&v"(c.w[9]), "=&v"(c.w[10]), "=&v"(c.w[11]), "=&v"(c.w[12]), "=&v"(c.w[13])
-                     : "v"(n.w[0]), "v"(n.w[1]), "v"(n.w[2]), "v"(n.w[3]), "v"(n.w[4]), "v"(n.w[5]), "v"(n.w[6]), "v"(n.w[7]), "v"(n.w[8]),
-                       "v"(n.w[9]), "v"(n.w[10]), "v"(n.w[11]), "v"(n.w[12]), "v"(n.w[13])
-                     : "memory");
-        return c;
-    };
-    Rec nxt = fetch(0);
-    for (int base = 0; base < q_mine; base += CW_WAVE) {
-        const Raw cur = flat_take(nxt.raw);
-        const int cur_rel = nxt.rel, cur_lim = nxt.lim;
-        nxt = fetch(base + CW_WAVE);                                          // (past the wave's last batch: clamped indices, never read)
-        const int in_batch = min(q_mine - base, CW_WAVE);
-        for (int k = 0; k < in_batch; k++) {
-            if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
-            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 7");
-            const int rel_a = __builtin_amdgcn_readlane(cur_rel, k);
-            const int lim = __builtin_amdgcn_readlane(cur_lim, k);
-            const bool dn_a = want_done && __builtin_amdgcn_readlane(cur.w[12], k) != 0;
-            const bool dn_b = want_done && __builtin_amdgcn_readlane(cur.w[13], k) != 0;
-            const int rel_b = rel_a + (int)FB;
-            uint8_t *const jb = dst_base + (size_t)((base + k) * n_waves + wave) * JB;
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            if (!dn_a && !dn_b && lim == (int)JB) {                           // nearly always: the whole job, no finished env in it
-                uint8_t *q = jb + 16u * lane;
-                for (int c = 0; c < chunks; c++, q += 1024) {
-                    *(uint4 *)q = z4;
-                    if (pace_mid && (c & 1) && c + 1 < chunks) __builtin_amdgcn_s_sleep(1);
-                }
-            } else {                                                           // bytes of a finished env's frame belong to its resetting wave
-                for (int c = 0; c < chunks; c++) {
-                    const int rel = c * 1024 + 16 * lane;
-                    const bool skip = (rel < rel_b) ? dn_a : dn_b;
-                    if (rel < lim && !skip) *(uint4 *)(jb + rel) = z4;
-                }
-            }
-            u32x4s pp;
-            if (!dn_a) {
-                pp.x = __builtin_amdgcn_readlane(cur.w[2], k);
-                pp.y = __builtin_amdgcn_readlane(cur.w[3], k);
-                pp.z = __builtin_amdgcn_readlane(cur.w[4], k);
-                pp.w = __builtin_amdgcn_readlane(cur.w[5], k);
-                flat_patch(jb, rel_a, lim, __builtin_amdgcn_readlane(cur.w[0], k), __builtin_amdgcn_readlane(cur.w[1], k), pp, L, v_table,
-                           S, P.ncell, P.div_magic, lane);
-            }
-            if (rel_b < lim && !dn_b) {
-                pp.x = __builtin_amdgcn_readlane(cur.w[8], k);
-                pp.y = __builtin_amdgcn_readlane(cur.w[9], k);
-                pp.z = __builtin_amdgcn_readlane(cur.w[10], k);
-                pp.w = __builtin_amdgcn_readlane(cur.w[11], k);
-                flat_patch(jb, rel_b, lim, __builtin_amdgcn_readlane(cur.w[6], k), __builtin_amdgcn_readlane(cur.w[7], k), pp, L, v_table,
-                           S, P.ncell, P.div_magic, lane);
-            }
-        }
-    }
-    CW_WAVE_BUSY(P, t_start, bid & 1);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
-}
-
-// ---- the same fill + patch, ONE WAVE PER FRAME, not persistent (the shape of a plain device fill): the grid has a wave per env,
-// workgroups are dispatched in address order, a wave fetches its env's record with scalar loads (wave-uniform), writes the frame's
-// 48*S*S bytes as zeros -- 16 B per lane, 1 KiB per store instruction, 16-byte aligned (a frame shares only its first and last line
-// with its neighbours, painted by the neighbouring waves of the same workgroup) -- patches the <= 36 coloured cell rows and exits.
-// Latencies are hidden by occupancy (no LDS, few registers), not by prefetching.
-template <int MODE>
-__device__ __forceinline__ void render_fill_frame(const CwParams &P, int skip_done, uint8_t *ext_out, int pace, int env)
-{
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const bool want_done = (MODE == 3) && skip_done;
-    const u32x4s h = cload((const u32x4s *)(P.hdr + env));
-    const u32x4s pp = cload((const u32x4s *)(P.pos + env));
-    if (want_done) {
-        const uint32_t dw = cload((const uint32_t *)(P.done + (env & ~3)));
-        if ((dw >> (8 * (env & 3))) & 0xFFu) return;                           // finished: its resetting wave paints it
-    }
-    const uint32_t FB = P.frame_bytes;
-    uint8_t *const dst = ((MODE == 2) ? ext_out : P.obs) + (size_t)env * FB;
-    CwFlatLane L;
-    L.sh16 = 16u * (((uint32_t)lane >> 2) & 1u);
-    L.sh4 = 4u * ((uint32_t)lane >> 2);
-    L.dy = (uint32_t)lane & 3u;
-    L.obj = lane < 32;
-    L.agent = lane >= 32 && lane < 36;
-    L.mid = L.dy == 1u || L.dy == 2u;
-    L.row2 = L.dy == 2u;
-    const uint32_t v_table = rgb_of_code((uint32_t)lane);
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
-    const uint32_t n_full = FB >> 10, rem = FB & 1023u;
-    uint8_t *q = dst + 16u * lane;
-    for (uint32_t c = 0; c < n_full; c++, q += 1024) {
-        *(uint4 *)q = z4;
-        if (c & 1) for (int z = 0; z < (pace & 0xFF); z++) __builtin_amdgcn_s_sleep(1);
-    }
-    if (16u * lane < rem) *(uint4 *)q = z4;
-    flat_patch(dst, 0, (int)FB, h.x, h.w, pp, L, v_table, P.size, P.ncell, P.div_magic, lane);
-}
-// grid: [reset_blocks resetting workgroups first (they are dispatched first and run beside the early frames)] + ceil(N / 4) frame workgroups
-__global__ __launch_bounds__(256) void cw_render_fill_step_kernel(CwParams P, int reset_blocks, int pace)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < reset_blocks) { reset_list_block(P, s_mt, (int)blockIdx.x, reset_blocks, 1, 0, 1); return; }
-    const int env = ((int)blockIdx.x - reset_blocks) * (int)(blockDim.x / CW_WAVE) + (int)__builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    if (env < P.n_envs) render_fill_frame<3>(P, 1, nullptr, pace, env);
-}
-__global__ __launch_bounds__(256) void cw_render_fill_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace)
-{
-    const int env = (int)blockIdx.x * (int)(blockDim.x / CW_WAVE) + (int)__builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    if (env >= P.n_envs) return;
-    if (mode == 3) render_fill_frame<3>(P, skip_done, ext_out, pace, env);
-    else render_fill_frame<2>(P, skip_done, ext_out, pace, env);
-}
-
 // the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
 __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
 {
@@ -1691,23 +1468,12 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
 // three frames painted by that wave) -- the pair that cwk_launch_step otherwise runs as two kernels on two streams with an event
 // fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
 // barrier packets: the render's part runs 3-6 % shorter without them (profiles/r02_fused_render.txt).
+template <int PLACE>
 __global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_groups<3>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
+    if ((int)blockIdx.x < render_blocks) render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
-}
-// ... and with the flat sweep (render_flat)
-__global__ __launch_bounds__(256) void cw_render_flat_step_kernel(CwParams P, int render_blocks, int pace, int chunks)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_flat<3>(P, 1, nullptr, pace, chunks, (int)blockIdx.x, render_blocks);
-    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
-}
-__global__ __launch_bounds__(256) void cw_render_flat_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace, int chunks)
-{
-    if (mode == 3) render_flat<3>(P, skip_done, ext_out, pace, chunks, (int)blockIdx.x, (int)gridDim.x);
-    else render_flat<2>(P, skip_done, ext_out, pace, chunks, (int)blockIdx.x, (int)gridDim.x);
 }
 // the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
 __global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
@@ -1872,15 +1638,6 @@ static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
     const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
     return tn.render_linear >= 2 || jobs <= 2560 * waves;
 }
-// flat sweep (render_flat)?  -> 1-KiB chunks per job (0: no): Ray raster, 16-byte aligned destination, a job no longer than a frame
-static inline int cw_render_flat(const CwParams &P, const CwTuning &tn, const uint8_t *dst)
-{
-    if (!tn.render_flat || P.raster != 0 || P.frame_bytes < 1024u || ((uintptr_t)dst & 15u)) return 0;
-    int chunks = tn.flat_chunks < 1 ? 1 : tn.flat_chunks;
-    if ((uint32_t)chunks > P.frame_bytes / 1024u) chunks = (int)(P.frame_bytes / 1024u);
-    const unsigned long long jb = 1024ull * chunks;
-    return ((unsigned long long)P.n_envs * P.frame_bytes + jb - 1) / jb < (1ull << 30) ? chunks : 0;
-}
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
                                     int fast_parity, hipStream_t st);
@@ -1902,12 +1659,7 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (tn.render_flat == 2 && cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) {
-        hipLaunchKernelGGL(cw_render_fill_kernel, dim3((P.n_envs + 3) / 4), dim3(256), 0, st, P, mode, skip_done, ext_out, tn.render_pace);
-        return;
-    }
-    if (const int chunks = cw_render_flat(P, tn, mode == 2 ? ext_out : P.obs)) hipLaunchKernelGGL(cw_render_flat_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, tn.render_pace, chunks);
-    else if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
+    if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
     else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
@@ -1970,12 +1722,14 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/r02_fused_render.txt H)
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-        if (tn.render_flat == 2 && cw_render_flat(*P, tn, P->obs))
-            hipLaunchKernelGGL(cw_render_fill_step_kernel, dim3(reset_blocks + (n + 3) / 4), dim3(256), 0, st, *P, reset_blocks, tn.render_pace);
-        else if (const int chunks = cw_render_flat(*P, tn, P->obs))
-            hipLaunchKernelGGL(cw_render_flat_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace, chunks);
-        else if (cw_render_linear(*P, tn))
-            hipLaunchKernelGGL(cw_render_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.render_pace);
+        if (cw_render_linear(*P, tn)) {
+            typedef void (*StepRenderFn)(CwParams, int, int);
+            static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
+                                                               cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
+                                                               cw_render_step_kernel<6>, cw_render_step_kernel<7>};
+            hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
+                               tn.render_pace);
+        }
         else
             hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
                                tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
@@ -2090,7 +1844,6 @@ hipError_t cwk_launch_idle(hipStream_t st)
 }
 
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
-int cwk_render_is_flat(const CwParams *P, const CwTuning *T) { return cw_render_flat(*P, *T, P->obs) ? T->render_flat : 0; }
 int cwk_render_jobs(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs; }
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)

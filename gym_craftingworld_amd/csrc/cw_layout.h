@@ -53,9 +53,9 @@ struct CwTuning {
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
     int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
-    int render_flat = 0;            // full-frame render as a FLAT sweep: line-aligned zero fill of the frame array + <= 36 patched cell rows per frame (render_flat)
-    int flat_chunks = 3;            // ... its job size in KiB (capped at the frame size)
-    int render_pace_fine = 0;       // ... bits 16-23 of render_pace: x `s_nop 7` (+ loop overhead, ~16 clocks) before every job
+    int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;
+                                    // tuned online by cw_step, CW_TUNE_RENDER_PLACE=k forces one)
+    int render_pace_fine = 0;       // ... bits 16-23 of render_pace: iterations of a one-s_nop loop before every job (a pace finer than s_sleep's 64 clocks)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset kernels
     int fused_reset_blocks_per_cu = 1;   // ... and the resetting tail of the one-launch full-frame step (cwk_launch_step)
     int fused_render = 1;           // FULL pixel step: render + auto-resets in ONE launch (cw_render_step_kernel) instead of two kernels on two streams

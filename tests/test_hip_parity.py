@@ -1714,6 +1714,62 @@ def test_bench_json_line_carries_the_contract():
     assert d['metric_window']['steps'] == 40 and d['metric_window']['value'] > 0 and len(d['metric_window']['slowest_step_ms']) == 2
 
 
+@pytest.mark.gpu
+def test_headline_perf_floor_of_the_sweep_kernel():
+    """The performance regime of the dominant kernel is a tested property: a fresh `bench.py --quick --steps 300` (BASELINE configs[2]:
+    65 536 envs, 21x21, full frames) must paint at >= 0.72 of the 8 TB/s HBM peak at its median launch (rounds 2-3 measured 0.756-0.785;
+    a build on the placement cliff of profiles/r02_pace.txt O reads 0.65).  The engine's survey of the eight loop placements runs inside
+    bench.py's untimed warm-up."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT') and not k.startswith('CW_TUNE_')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--quick', '--steps', '300'], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])                # the JSON line is the LAST line of rank 0's stdout
+    r = d['roofline']
+    assert r['kernel'] == 'cw_render_step_kernel' and d['config']['envs_per_gpu'] == 65536
+    assert r['frac_at_median_launch'] >= 0.72, r
+    assert d['value'] >= 2.45e8, d['value']                         # ... and the whole step (round 1: 2.30e8, rounds 2-3: 2.72-2.80e8)
+
+
+@pytest.mark.gpu
+def test_every_placement_of_the_sweep_loop_paints_the_same_frames():
+    """cw_render_step_kernel<0..7> differ by where their batch loop lies in the code object and by nothing else: forced one by one
+    (CW_TUNE_RENDER_PLACE) they leave the same frames, results and random streams as the dirty-cell engine, resets included."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, T = 4099, 30
+    kw = dict(size=(21, 21), max_steps=9, seed=5)
+    acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(3))
+    ref = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    ref.reset()
+    for t in range(T):
+        ref.step(acts[t])
+    want = (ref._obs.clone(), ref._desired_img.clone(), ref._init_img.clone(), ref.reward.clone(), ref.hdr.clone(), ref.get_rng_states())
+    ref.close()
+    old = os.environ.get('CW_TUNE_RENDER_PLACE')
+    try:
+        for k in range(8):
+            os.environ['CW_TUNE_RENDER_PLACE'] = str(k)
+            env = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+            assert env.render_kernel_name() == 'cw_render_step_kernel'
+            env.reset()
+            for t in range(T):
+                env.step(acts[t])
+            assert torch.equal(env._obs, want[0]) and torch.equal(env._desired_img, want[1]) and torch.equal(env._init_img, want[2]), k
+            assert torch.equal(env.reward, want[3]) and torch.equal(env.hdr, want[4]), k
+            keys, pos = env.get_rng_states()
+            assert np.array_equal(keys[:, 1:], want[5][0][:, 1:]) and np.array_equal(pos, want[5][1]), k
+            env.close()
+    finally:
+        if old is None:
+            os.environ.pop('CW_TUNE_RENDER_PLACE', None)
+        else:
+            os.environ['CW_TUNE_RENDER_PLACE'] = old
+
+
 def _reference_render_of_any_state(state):
     """ray.py:442-486 restated in numpy for a caller-supplied one-hot state (test-side oracle): sum of object colours per cell,
     x4 upscale, agent = first cell with channel 8 set -> centre 2x2 white, bottom row of it in the colour of the largest hold
