@@ -290,7 +290,6 @@ def main():
         with torch.cuda.graph(graph):                    # G steps, each reading its own action row
             for t in range(G):
                 env.step_async(actions[t])
-            env.lookahead_join()                         # (look-ahead engines: every forked refill joins the graph's end)
 
     if args.rollout and args.obs_mode != 'state':
         raise SystemExit('--rollout needs --obs-mode state')

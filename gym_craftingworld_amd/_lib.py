@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CW_LIB_PATH') or os.path.join(_HERE, 'libcraftingworld.so')   # CW_LIB_PATH: experiment builds
 
-CW_ABI_VERSION = 1
+CW_ABI_VERSION = 2
 CW_MT_N = 624
 CW_MAX_TASKS = 16
 CW_MAX_MENUS = 256
@@ -82,7 +82,6 @@ ABI = {
     'cw_render_kernel_name': (C.c_char_p, [_VP]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
     'cw_synchronize': (C.c_int, [_VP, _VP]),
-    'cw_lookahead_join': (C.c_int, [_VP, _VP]),
     'cw_num_envs': (C.c_int, [_VP]),
     'cw_abi_version': (C.c_int, []),
     'cw_last_error': (C.c_char_p, []),

@@ -16,10 +16,8 @@
 
 extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
-                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev, int la_parity);
+                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
-hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity, int all_envs, hipStream_t st);
-hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
@@ -85,13 +83,6 @@ struct cw_engine {
     hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int prof_cap = 0, prof_n = 0;
-    // look-ahead resets (CW_TUNE_LOOKAHEAD=1; cw_kernels.hip: cw_la_refill_kernel)
-    bool la_filled = false;            // both slots of every env hold its next two episodes (mt[] is two episodes ahead)
-    unsigned la_step = 0;              // steps taken since the slots were filled: parity of the refill queue
-    hipEvent_t ev_la_step = nullptr, ev_la_refill[2] = {nullptr, nullptr};
-    bool la_refill_pending[2] = {false, false};
-    bool la_capturing = false;         // the cw_step calls currently being made are recorded into a HIP graph
-    unsigned la_capture_step0 = 0;
     // online tuner of the render pace (full-frame mode, linear sweep): see adapt_tick
     struct Adapt {
         bool on = false;
@@ -118,20 +109,6 @@ struct cw_engine {
     } adapt;
 };
 enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24 };
-
-// Look-ahead engines keep mt[] two episodes ahead of the reference's timeline.  Every entry point that reads or replaces the
-// RNG streams, or resets outside cw_step, first returns to the canonical form (mt[e] = snapshot of e's next slot); the next
-// cw_step fills the slots again from there -- the same episodes, the streams being what they were.
-static int la_rollback(cw_engine *e)
-{
-    if (!e->la_filled) return CW_OK;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(cwk_launch_la_rollback(&e->P, &e->tune, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    e->la_filled = false;
-    e->la_refill_pending[0] = e->la_refill_pending[1] = false;
-    return CW_OK;
-}
 
 // ------------------------------------------------------------------------------ MT19937 (host)
 // numpy RandomState (key, pos)  <->  the engine's consume-and-replace form (cw_mt.h).
@@ -666,20 +643,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC(mt_idx, N);
     ALLOC(pool, N * (size_t)e->K * 9);
     if (rc == CW_OK) rc = dev_alloc(e, &e->seed_scratch, N);
-    e->tune.lookahead = (getenv("CW_TUNE_LOOKAHEAD") && atoi(getenv("CW_TUNE_LOOKAHEAD")) != 0 && cfg->obs_mode != CW_OBS_PIXELS_FULL &&
-                         cfg->auto_reset && !cfg->host_outputs) ? 1 : 0;
-    if (e->tune.lookahead) {
-        ALLOC(la_init_pos, 2 * N);
-        ALLOC(la_goal_pos, 2 * N);
-        ALLOC(la_goal_codes, 2 * N);
-        ALLOC(la_agents, 2 * N);
-        ALLOC(la_desired, 2 * N);
-        ALLOC(la_mt, 2 * N * CW_MT_N);
-        ALLOC(la_mt_idx, 2 * N);
-        ALLOC(la_next, N);
-        ALLOC(la_queue, 2 * N);
-        ALLOC(la_qcount, 4);
-    }
     // step outputs and frames: device memory, or mapped host memory for the single-env loop
 #define ALLOC_OUT(field, count)                                 \
     if (rc == CW_OK) rc = cfg->host_outputs ? host_alloc(e, &P.field, (count)) : dev_alloc(e, &P.field, (count))
@@ -717,10 +680,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     }
     if (rc == CW_OK && (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
                         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_la_step, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_la_refill[0], hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_la_refill[1], hipEventDisableTiming) != hipSuccess))
+                        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess))
         rc = fail(CW_ERR_HIP, "cw_create: side stream / event creation failed");
     if (rc != CW_OK) {
         for (void *p : e->allocs) (void)hipFree(p);
@@ -728,8 +688,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (e->side) (void)hipStreamDestroy(e->side);
         if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
         if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-        if (e->ev_la_step) (void)hipEventDestroy(e->ev_la_step);
-        for (hipEvent_t ev : e->ev_la_refill) if (ev) (void)hipEventDestroy(ev);
         delete e;
         return rc;
     }
@@ -773,8 +731,6 @@ int cw_destroy(cw_engine *e)
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->ev_la_step) (void)hipEventDestroy(e->ev_la_step);
-    for (hipEvent_t ev : e->ev_la_refill) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->adapt.ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
@@ -789,7 +745,6 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_seed_mt: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     const size_t N = (size_t)e->n;
     for (size_t i = 0; i < N; i++)
         if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
@@ -806,7 +761,6 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     if (!e || !seeds) return fail(CW_ERR_INVALID, "cw_seed_int: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, nullptr));
@@ -819,7 +773,6 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_get_mt: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
     HIP_TRY(hipDeviceSynchronize());
@@ -835,7 +788,6 @@ int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
     if (e->K == 0) return CW_OK;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     HIP_TRY(cwk_launch_pool(&e->P, &e->tune, (hipStream_t)stream));
     // one-time, off the hot path: the pool and the advanced RNG streams are complete before any other stream can reset from them
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -847,7 +799,6 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
     if (!e) return fail(CW_ERR_INVALID, "cw_reset: null engine");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     e->has_reset = true;
     return CW_OK;
@@ -861,42 +812,6 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    if (e->tune.lookahead && e->tune.fused_step) {
-        // step s: promote finished envs to their pre-generated episodes; the consumed slots are regenerated by the refill
-        // kernel on the side stream, which step s+2 (the next one with this parity) waits for.  An env consumes at most one slot
-        // per step and has two, so the slot it needs is always valid.
-        hipStream_t st = (hipStream_t)stream;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-        if (capturing != e->la_capturing) {
-            // Entering a capture: the refills recorded so far are outside it, so nothing may be pending (cw_synchronize first) and
-            // the slots must be filled; the graph must hold an EVEN number of steps (queue parity at its start = at its end) and
-            // end with cw_lookahead_join (every forked refill joined).  Leaving a capture: its refills were never launched.
-            if (capturing && (!e->la_filled || e->la_refill_pending[0] || e->la_refill_pending[1]))
-                return fail(CW_ERR_STATE, "cw_step (look-ahead): before capturing, take one eager cw_step and call cw_synchronize");
-            e->la_capturing = capturing;
-            e->la_refill_pending[0] = e->la_refill_pending[1] = false;
-            if (capturing) e->la_capture_step0 = e->la_step;
-            else e->la_step = e->la_capture_step0;                              // (an even number of steps was captured: same parity)
-        }
-        if (!e->la_filled) {
-            HIP_TRY(cwk_launch_la_refill(&e->P, &e->tune, 0, 1, st));           // both slots of every env, in stream order
-            e->la_filled = true;
-            e->la_step = 0;
-            e->la_refill_pending[0] = e->la_refill_pending[1] = false;
-        }
-        const int parity = (int)(e->la_step & 1u);
-        if (e->la_refill_pending[parity]) HIP_TRY(hipStreamWaitEvent(st, e->ev_la_refill[parity], 0));
-        HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, st, e->side, e->ev_fork, e->ev_join, ev, parity));
-        HIP_TRY(hipEventRecord(e->ev_la_step, st));
-        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_la_step, 0));
-        HIP_TRY(cwk_launch_la_refill(&e->P, &e->tune, parity, 0, e->side));
-        HIP_TRY(hipEventRecord(e->ev_la_refill[parity], e->side));
-        e->la_refill_pending[parity] = true;
-        e->la_step++;
-        if (ev) e->prof_n++;
-        return CW_OK;
-    }
     if (e->adapt.on) {                               // full-frame mode: the sweep's extra sleeps beside resets follow what the steps measure (adapt_tick)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
@@ -911,7 +826,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         }
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
-                            e->ev_fork, e->ev_join, ev, -1));
+                            e->ev_fork, e->ev_join, ev));
     if (ev) e->prof_n++;
     return CW_OK;
 }
@@ -925,7 +840,6 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_rollout called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
@@ -1063,24 +977,6 @@ int cw_synchronize(cw_engine *e, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (e->tune.lookahead) {
-        HIP_TRY(hipStreamSynchronize(e->side));
-        e->la_refill_pending[0] = e->la_refill_pending[1] = false;
-    }
-    return CW_OK;
-}
-
-int cw_lookahead_join(cw_engine *e, cw_stream_t stream)
-{
-    if (!e) return fail(CW_ERR_INVALID, "cw_lookahead_join: null engine");
-    if (!e->tune.lookahead) return CW_OK;
-    DeviceGuard guard(e->device);
-    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    for (int p = 0; p < 2; p++)
-        if (e->la_refill_pending[p]) {
-            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, e->ev_la_refill[p], 0));
-            e->la_refill_pending[p] = false;
-        }
     return CW_OK;
 }
 
@@ -1306,7 +1202,6 @@ int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity)
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_checkpoint_save called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     const CwCkptHeader h = ckpt_header(e);
     if (capacity < h.total_bytes) return fail(CW_ERR_INVALID, "cw_checkpoint_save: buffer of %zu bytes, %llu needed", capacity, (unsigned long long)h.total_bytes);
     HIP_TRY(hipDeviceSynchronize());
@@ -1325,7 +1220,6 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (!e || !buf) return fail(CW_ERR_INVALID, "cw_checkpoint_load: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-    { const int rb = la_rollback(e); if (rb != CW_OK) return rb; }
     CwCkptHeader h;
     if (length < sizeof(h)) return fail(CW_ERR_INVALID, "cw_checkpoint_load: %zu bytes is not a checkpoint", length);
     memcpy(&h, buf, sizeof(h));

@@ -600,19 +600,10 @@ struct CwResetOut {
 // menu_fn() yields the env's task-menu id; it is called after the MT state's loads are in flight, so a caller that
 // still has to fetch the id (cw_reset_kernel: from the header) overlaps that fetch with them.
 template <typename MenuFn>
-__device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env, MenuFn menu_fn, uint32_t *lds_mt, int lane,
-                                                     uint32_t *snap = nullptr, int32_t *snap_idx = nullptr)
+__device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env, MenuFn menu_fn, uint32_t *lds_mt, int lane)
 {
     CW_STAMP(env, 0);
     const CwMtWave::Pending pend = CwMtWave::load_issue(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);
-    if (snap) {                                      // look-ahead refill: the stream as it stands BEFORE this episode is drawn
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            const int j = lane + 64 * k;
-            if (j < CW_MT_WORDS) snap[j] = pend.w[k];
-        }
-        if (lane == 0) *snap_idx = pend.gidx;
-    }
     const uint32_t menu_id = menu_fn();
     const CwMenuDev M = P.menus[menu_id];
     CwMtWave mt;
@@ -895,7 +886,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
 // launch waiting on the first: a step is bounded by one launch plus one reset's latency.  The full-frame pixel
 // mode keeps the separate kernels (its reset hides under the render kernel on a side stream).
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
-                                                                                int paint, int epw, int la_parity)
+                                                                                int paint, int epw)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -950,75 +941,6 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
     }
     if (m && P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
-    if (la_parity >= 0) {
-        // Look-ahead (prototype): the env's next episode was generated ahead (cw_la_refill_kernel) -- a finished env is
-        // PROMOTED to it lane-parallel, no RNG work here; the consumed slot goes on the refill queue of this step's parity.
-        if (m) {
-            const size_t N = (size_t)P.n_envs;
-            uint32_t slot = 0, n_codes = 0, n_agents = 0, n_desired = 0;
-            uint4 n_ip = make_uint4(0, 0, 0, 0), n_gp = n_ip;
-            if (done) {
-                slot = P.la_next[env];
-                const size_t k = slot * N + (size_t)env;
-                n_ip = P.la_init_pos[k];
-                n_gp = P.la_goal_pos[k];
-                n_codes = P.la_goal_codes[k];
-                n_agents = P.la_agents[k];
-                n_desired = P.la_desired[k];
-            }
-            int qbase = 0;
-            if (lane == 0) qbase = atomicAdd(&P.la_qcount[la_parity], __popcll(m));
-            qbase = __shfl(qbase, 0);
-            if (paint) {                             // dirty-cell mode: terminal frame (old state), then the new episode's three frames
-                unsigned long long mm = m;
-                while (mm) {
-                    const int l = __builtin_ctzll(mm);
-                    mm &= mm - 1;
-                    const int env_l = env0 + l;
-                    if (P.terminal_img) {
-                        const uint32_t hx = __builtin_amdgcn_readlane(h.x, l);
-                        uint32_t tp[8], rgb[8];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) tp[k] = __builtin_amdgcn_readlane(sp[k], l);
-                        const uint32_t codes = __builtin_amdgcn_readlane(h.w, l);
-                        const uint32_t acell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
-                        const uint32_t hold = (hx >> 16) & 0xFFu;
-                        uint8_t *dst = P.terminal_img + (size_t)env_l * P.frame_bytes;
-                        if (P.raster == 1) {
-                            render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, tp, codes, acell, hold, lane, P.alt_pace);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
-                            render_frame(dst, nullptr, P.size, P.ncell, P.div_magic, tp, rgb, acell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
-                        }
-                    }
-                    CwResetOut r;
-                    r.init_pos = make_uint4(__builtin_amdgcn_readlane(n_ip.x, l), __builtin_amdgcn_readlane(n_ip.y, l),
-                                            __builtin_amdgcn_readlane(n_ip.z, l), __builtin_amdgcn_readlane(n_ip.w, l));
-                    r.goal_pos = make_uint4(__builtin_amdgcn_readlane(n_gp.x, l), __builtin_amdgcn_readlane(n_gp.y, l),
-                                            __builtin_amdgcn_readlane(n_gp.z, l), __builtin_amdgcn_readlane(n_gp.w, l));
-                    r.goal_codes = __builtin_amdgcn_readlane(n_codes, l);
-                    const uint32_t ag = __builtin_amdgcn_readlane(n_agents, l);
-                    r.init_agent = ag & 0xFFFFu;
-                    r.goal_agent = ag >> 16;
-                    r.desired = 0; r.subset = 0;
-                    paint_reset_frames(P, env_l, r, lane);
-                }
-            }
-            if (done) {
-                P.la_queue[(size_t)la_parity * N + (size_t)(qbase + __popcll(m & ((1ull << lane) - 1ull)))] = env | (int)(slot << 30);
-                P.la_next[env] = (uint8_t)(slot ^ 1u);
-                CwResetOut r;
-                r.init_pos = n_ip; r.goal_pos = n_gp; r.goal_codes = n_codes;
-                r.init_agent = n_agents & 0xFFFFu; r.goal_agent = n_agents >> 16;
-                r.desired = n_desired & 0xFFFFu; r.subset = n_desired >> 16;
-                store_episode_records(P, env, r, true);                    // step_num >= 1 here
-                h = reset_header(P, r, h.x >> 24);
-                unpack_pos(n_ip, sp);
-            }
-        }
-        m = 0;
-    }
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
@@ -1052,67 +974,6 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
     if (live) {
         P.hdr[env] = h;
         P.pos[env] = pack_pos(sp);
-    }
-}
-
-// Look-ahead refill (prototype): one WAVEFRONT per job generates an env's next-but-one episode into the slot the env just
-// consumed -- snapshot of the env's MT19937 state first (what get_rng_states reports while that episode is still ahead),
-// then reset_env_wave exactly as an inline reset would run it, on the same stream, so the episode sequence of every env is
-// the one it would have had.  all_envs: both slots of every env in order (after cw_reset / seeding); else the queue of one
-// step parity, released by the last workgroup.
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_la_refill_kernel(CwParams P, int parity, int all_envs)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
-    const int n_waves = gridDim.x * CW_RESET_WAVES;
-    const size_t N = (size_t)P.n_envs;
-    // the wave's first queue entry is fetched together with the count (entries past the count are stale but in bounds)
-    const int first = (!all_envs && wave < P.n_envs) ? P.la_queue[(size_t)parity * N + wave] : 0;
-    const int count = all_envs ? P.n_envs : P.la_qcount[parity];
-    if (P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
-    for (int job = wave; job < count; job += n_waves) {
-        for (int rep = 0; rep < (all_envs ? 2 : 1); rep++) {
-            const int entry = all_envs ? 0 : (job == wave ? first : P.la_queue[(size_t)parity * N + job]);
-            const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : (entry & 0x3FFFFFFF));
-            const uint32_t slot = __builtin_amdgcn_readfirstlane(all_envs ? (uint32_t)rep : ((uint32_t)entry >> 30));
-            const size_t k = slot * N + (size_t)env;
-            const uint32_t v_hx = P.hdr[env].x;       // in flight beside the MT state (the menu byte never changes)
-            const CwResetOut r = reset_env_wave(P, env, [&]() { return __builtin_amdgcn_readfirstlane(v_hx) >> 24; }, s_mt[wave_in_block], lane,
-                                                P.la_mt + k * CW_MT_WORDS, P.la_mt_idx + k);
-            if (lane == 0) {
-                P.la_init_pos[k] = r.init_pos;
-                P.la_goal_pos[k] = r.goal_pos;
-                P.la_goal_codes[k] = r.goal_codes;
-                P.la_agents[k] = r.init_agent | (r.goal_agent << 16);
-                P.la_desired[k] = r.desired | (r.subset << 16);
-                if (all_envs && rep == 0) P.la_next[env] = 0;
-            }
-        }
-    }
-    if (!all_envs) {                                 // release the queue for the step after next
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int t = atomicAdd(&P.la_qcount[2 + parity], 1);
-            if (t == (int)gridDim.x - 1) { P.la_qcount[parity] = 0; P.la_qcount[2 + parity] = 0; }
-        }
-    }
-}
-// Back to the canonical form (mt[e] = the env's RNG state as the reference would hold it: before the next episode is
-// generated): every env's mt := the snapshot of the slot it would consume next.  The slots are then stale.
-__global__ __launch_bounds__(256) void cw_la_rollback_kernel(CwParams P)
-{
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE;
-    const int n_waves = gridDim.x * blockDim.x / CW_WAVE;
-    const size_t N = (size_t)P.n_envs;
-    for (int env = wave; env < P.n_envs; env += n_waves) {
-        const size_t k = (size_t)P.la_next[env] * N + (size_t)env;
-        const uint32_t *src = P.la_mt + k * CW_MT_WORDS;
-        uint32_t *dst = P.mt + (size_t)env * CW_MT_WORDS;
-        for (int j = lane; j < CW_MT_WORDS; j += CW_WAVE) dst[j] = src[j];
-        if (lane == 0) P.mt_idx[env] = P.la_mt_idx[k];
     }
 }
 
@@ -1694,7 +1555,7 @@ int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset)
 // the caller's stream, so the caller sees ordinary stream order.
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode,
                            int auto_reset, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                           hipEvent_t *ev /* 6 or null */, int la_parity /* -1: no look-ahead */)
+                           hipEvent_t *ev /* 6 or null */)
 {
     const CwTuning &tn = *T;
     const int n = P->n_envs;
@@ -1707,7 +1568,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         const int epw = cw_envs_per_wave(n);
         const int waves = (n + epw - 1) / epw;
         hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
-                           *P, actions, act_dtype, pixels ? 1 : 0, epw, la_parity);
+                           *P, actions, act_dtype, pixels ? 1 : 0, epw);
         if (ev) for (int k = 1; k < 6; k++) (void)hipEventRecord(ev[k], st);
         return hipGetLastError();
     }
@@ -1784,18 +1645,6 @@ hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mo
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st)
 {
     hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(*T, P->n_envs)), dim3(256), 0, st, *P, 5);
-    return hipGetLastError();
-}
-
-hipError_t cwk_launch_la_refill(const CwParams *P, const CwTuning *T, int parity, int all_envs, hipStream_t st)
-{
-    hipLaunchKernelGGL(cw_la_refill_kernel, dim3(cw_reset_grid(*T, P->n_envs)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, parity, all_envs);
-    return hipGetLastError();
-}
-
-hipError_t cwk_launch_la_rollback(const CwParams *P, const CwTuning *T, hipStream_t st)
-{
-    hipLaunchKernelGGL(cw_la_rollback_kernel, dim3(T->n_cu * 4), dim3(256), 0, st, *P);
     return hipGetLastError();
 }
 

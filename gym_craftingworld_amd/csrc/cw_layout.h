@@ -51,7 +51,6 @@ struct CwTuning {
     int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
-    int lookahead = 0;              // state / dirty-cell modes: episodes generated two ahead on a side stream, promoted at done (prototype)
     int render_linear = 1;          // full-frame render as ONE linear sweep (job = a run of whole grid rows) up to 2560 rounds per wave; 2: always
     int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;
                                     // tuned online by cw_step, CW_TUNE_RENDER_PLACE=k forces one)
@@ -60,7 +59,7 @@ struct CwTuning {
     int fused_reset_blocks_per_cu = 1;   // ... and the resetting tail of the one-launch full-frame step (cwk_launch_step)
     int fused_render = 1;           // FULL pixel step: render + auto-resets in ONE launch (cw_render_step_kernel) instead of two kernels on two streams
     int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job,
-                                    // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x3100)
+                                    // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x2100; cw_step tunes bits 12-15)
 };
 
 // Everything the kernels need, passed by value.
@@ -106,18 +105,6 @@ struct CwParams {
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
     int32_t tune_reset_prio; // s_setprio 3 for: 2 the render waves and the resets inlined in the fused / rollout kernels (default), 1 every resetting wave, 0 nobody
-    // look-ahead resets (CW_TUNE_LOOKAHEAD=1, state / dirty-cell modes; null otherwise): two pre-generated episodes per env
-    // ("slots"; slot s of env e at index s*N + e) and the env's MT19937 state as it was BEFORE each was generated
-    uint4 *la_init_pos;      // [2][N]
-    uint4 *la_goal_pos;      // [2][N]
-    uint32_t *la_goal_codes; // [2][N]
-    uint32_t *la_agents;     // [2][N] init agent cell | goal agent cell << 16
-    uint32_t *la_desired;    // [2][N] desired mask | subset rule << 16
-    uint32_t *la_mt;         // [2][N][624] snapshot of mt[e] before slot s was generated (= the env's RNG state while that
-    int32_t *la_mt_idx;      // [2][N]        episode is the NEXT one: what get_rng_states must report)
-    uint8_t *la_next;        // [N] slot the env consumes at its next reset
-    int32_t *la_queue;       // [2][N] consumed (env | slot << 30) entries of the steps of each parity, for the refill kernel
-    int32_t *la_qcount;      // [4] entries of parity 0 / 1, release tickets of parity 0 / 1
     int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
     int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
     int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)

@@ -292,11 +292,6 @@ class CraftingWorldVecEnv:
         """Block until everything this env enqueued on the current stream (and on its own side stream) has finished."""
         self._sync()
 
-    def lookahead_join(self):
-        """Look-ahead engines (CW_TUNE_LOOKAHEAD=1): make the current stream wait for the episode refills still in flight --
-        call it before ending a HIP-graph capture of an even number of step() calls.  A no-op otherwise."""
-        L.check(self._lib.cw_lookahead_join(self._h, self._stream()), 'cw_lookahead_join')
-
     def reset_async(self):
         L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')     # enqueues; nothing waits
         self._has_reset = True

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 1
+#define CW_ABI_VERSION 2   /* 2: cw_profile grew ms_render_kernel_median; cw_lookahead_join removed with the look-ahead prototype */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -228,7 +228,7 @@ int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
 /* Name of the kernel that ms_render_kernel brackets for this engine (what a rocprofv3 kernel trace of the same run lists it as):
  * "cw_render_step_kernel" / "cw_render_frames_step_kernel" (full-frame render + the auto-resets beside it, one launch; linear
- * sweep / frame per wave), "cw_render_kernel" / "cw_render_frames_kernel" (the render alone), the step kernel's name in
+ * sweep -- a trace lists its eight placements as cw_render_step_kernel<0> .. <7>, cw_step measures which one to launch -- / frame per wave), "cw_render_kernel" / "cw_render_frames_kernel" (the render alone), the step kernel's name in
  * CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
@@ -236,11 +236,6 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out);
 /* Blocks the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize): the one host
  * synchronisation of the single-env loop, where step() returns Python scalars (ray.py:376-378). */
 int cw_synchronize(cw_engine *e, cw_stream_t stream);
-/* Look-ahead engines only (experiment knob CW_TUNE_LOOKAHEAD=1: state / dirty-cell modes generate every env's next two
- * episodes ahead on an engine-owned stream and promote finished envs instead of resetting them; results are identical).
- * Makes `stream` wait for the refills still in flight -- enqueue only.  Needed before ending a HIP-graph capture of cw_step
- * calls (an even number of them); a no-op on other engines. */
-int cw_lookahead_join(cw_engine *e, cw_stream_t stream);
 int cw_num_envs(const cw_engine *e);
 int cw_abi_version(void);
 const char *cw_last_error(void);   /* thread-local text of the last failing call */

@@ -1582,82 +1582,6 @@ def test_flat_and_onehot_facades_replay_their_own_reference_fixtures(name):
     env.close()
 
 
-@pytest.mark.parametrize('obs_mode,pool,terminal', [('state', 0, False), ('pixels_dirty', 0, True), ('state', 3, False), ('pixels_dirty', 2, False)])
-def test_lookahead_resets_equal_inline_resets(obs_mode, pool, terminal, monkeypatch, tmp_path):
-    """CW_TUNE_LOOKAHEAD=1 (prototype: every env's next two episodes generated ahead on a side stream, finished envs
-    promoted instead of reset) against the inline path: identical rewards, dones, masks, state tensors and frames at every
-    step with short episodes (many envs finish on consecutive steps), identical RNG streams whenever they are read
-    (get_rng_states rolls the look-ahead back), across an explicit reset(), a re-seed, a persistent rollout and a
-    checkpoint written by the look-ahead engine and resumed by a plain one."""
-    from gym_craftingworld_amd import CraftingWorldVecEnv
-    N = 700
-    kw = dict(size=(6, 6), max_steps=4, obs_mode=obs_mode, fixed_init_state=pool, keep_terminal_obs=terminal,
-              selected_tasks=['GoToHouse', 'EatBread', 'MoveAxe', 'ChopTree'], number_of_tasks=2)
-    plain = CraftingWorldVecEnv(N, seed=41, **kw)
-    monkeypatch.setenv('CW_TUNE_LOOKAHEAD', '1')
-    ahead = CraftingWorldVecEnv(N, seed=41, **kw)
-    monkeypatch.delenv('CW_TUNE_LOOKAHEAD')
-    gen = torch.Generator(device='cuda').manual_seed(3)
-    acts = torch.randint(0, 6, (200, N), device='cuda', dtype=torch.uint8, generator=gen)
-
-    def same(tag):
-        assert torch.equal(plain.hdr, ahead.hdr) and torch.equal(plain.slot_pos, ahead.slot_pos), tag
-        assert torch.equal(plain.counters, ahead.counters), tag
-        if obs_mode != 'state':
-            op, oa = plain._observation(), ahead._observation()
-            for k in op:
-                assert torch.equal(op[k], oa[k]), (tag, k)
-
-    def steps(t0, t1):
-        for t in range(t0, t1):
-            _, rp, dp, ip = plain.step(acts[t])
-            _, ra, da, ia = ahead.step(acts[t])
-            torch.cuda.synchronize()
-            assert torch.equal(rp, ra) and torch.equal(dp, da), t
-            assert torch.equal(ip['achieved_goal'], ia['achieved_goal']) and torch.equal(ip['desired_goal'], ia['desired_goal']), t
-            if terminal:
-                d = dp.nonzero().flatten()
-                assert torch.equal(ip['terminal_observation'][d], ia['terminal_observation'][d]), t
-            same(t)
-
-    def rng_same(tag):
-        kp, pp = plain.get_rng_states()
-        ka, pa = ahead.get_rng_states()
-        assert np.array_equal(pp, pa) and np.array_equal(kp[:, 1:], ka[:, 1:]), tag
-
-    plain.reset(); ahead.reset()
-    same('reset')
-    steps(0, 30)
-    assert int(plain.counters[1]) > 5 * N                    # every env finished many episodes, often on consecutive steps
-    rng_same('after 30 steps')
-    steps(30, 45)
-    plain.reset(); ahead.reset()                              # explicit reset in the middle of episodes
-    same('explicit reset')
-    steps(45, 60)
-    assert plain.seed(1234) == ahead.seed(1234)               # new streams mid-run
-    steps(60, 80)
-    rng_same('after re-seed')
-    if obs_mode == 'state':
-        rp, dp = plain.rollout(acts[80:110])
-        ra, da = ahead.rollout(acts[80:110])
-        assert torch.equal(rp, ra) and torch.equal(dp, da)
-        same('rollout')
-    steps(110, 130)
-    path = str(tmp_path / 'ck')
-    ahead.save_checkpoint(path)                                # written by the look-ahead engine (canonical streams) ...
-    third = CraftingWorldVecEnv(N, seed=7, **kw)
-    third.load_checkpoint(path)                                # ... resumed by a plain one
-    for t in range(130, 160):
-        _, rp, dp, _ = plain.step(acts[t])
-        _, ra, da, _ = ahead.step(acts[t])
-        _, rt, dt, _ = third.step(acts[t])
-        assert torch.equal(rp, ra) and torch.equal(rp, rt) and torch.equal(dp, da) and torch.equal(dp, dt), t
-    same('end')
-    assert torch.equal(plain.hdr, third.hdr) and torch.equal(plain.slot_pos, third.slot_pos)
-    rng_same('end')
-    plain.close(); ahead.close(); third.close()
-
-
 def test_bench_self_launched_two_ranks_share_the_gpu():
     """`python bench.py --gpus 2` started plainly (no torchrun): the parent starts two fresh ranks before touching HIP, both ranks
     run their env shard on this one GPU (--rehearse-on-one-gpu; gloo carries the timing barrier), rank 0's single JSON line comes
