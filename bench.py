@@ -24,7 +24,11 @@ Prints ONE JSON line on rank 0 (contract in the task prompt), with
   metric_window -- SURVEY 8d's window whatever --steps says: 2*max_steps consecutive steps (both synchronized
                   time-out steps inside), timed in the same process, with the two slowest steps;
   repeats      -- the K-step region timed three times (value is the first, as the contract says);
-  single_env   -- BASELINE configs[0]: make('craftingworld-v3'), 200 random steps through the N=1 facade.
+  metric_window_desync -- the same window with the episode phases spread out (about N/max_steps envs finish on EVERY step: the steady
+                  state of a run whose policy finishes episodes), same process, with its own roofline fraction;
+  single_env   -- BASELINE configs[0]: make('craftingworld-v3'), 200 random steps through the N=1 facade;
+  per_rank_ms_per_step -- every rank's own time for the timed region (gathered once, after it): stragglers show in a scaling run.
+The JSON line is the LAST line of rank 0's stdout; everything else any library prints to fd 1 is sent to stderr.
 """
 import argparse
 import json
@@ -182,6 +186,11 @@ def main():
                          'reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
+    ap.add_argument('--shard-check', type=int, default=0, metavar='T',
+                    help='no timing: reset, take T steps with actions that depend only on (step, GLOBAL env index), write per-env CRC32s of '
+                         'the final frames and the reward / done of every step of this rank\'s shard to --shard-out/rank<r>.npz and exit '
+                         '(tests: shards of self-launched ranks == the single-batch run)')
+    ap.add_argument('--shard-out', default='gpurun_out/shard_check')
     ap.add_argument('--quick', action='store_true',
                     help='profiling runs (rocprofv3 / PMC passes serialise kernels): only the contract regions -- no repeats, no metric '
                          'window, no other modes, no single env, no CPU baseline')
@@ -199,6 +208,12 @@ def main():
     if launch.needs_self_launch(args.gpus):
         sys.exit(launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout=args.launch_timeout))
 
+    # The JSON line must be the LAST line of rank 0's stdout, and libraries write to fd 1 as they please ("[Gloo] Rank 0 is connected to
+    # ..."): keep the real stdout aside for that one line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -215,35 +230,36 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     backend_used = None
+    timing_group = None          # the group the timing barrier and the max-over-ranks run on (None = the default group)
     if world > 1:
         import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # The default group is gloo (CPU, rendezvous over MASTER_ADDR:MASTER_PORT): it carries the control plane -- above all the agreement
+        # on whether RCCL works.  RCCL (backend "nccl") is a second group for the two timing collectives; no data-path collective exists.
+        # Every rank tries one all-reduce on it, then all ranks MIN-reduce an "ok" flag over gloo: either everybody uses RCCL or nobody
+        # does, whatever subset of ranks saw the failure (a rank whose peers never join waits out the 60-s group timeout first).
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         backend_used = args.dist_backend
         if args.dist_backend == 'nccl':
-            # RCCL carries only the timing barrier and the max-over-ranks (no data-path collective exists).  If it cannot come up
-            # on this node, every rank sees the failure and the same two collectives go over gloo instead -- a scaling run is not
-            # lost to the barrier's transport; the JSON line says which one was used.
+            ok, why = 1, ''
             try:
-                dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))
-                dist.barrier()
+                timing_group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=60))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=timing_group)
                 torch.cuda.synchronize(dev)
+                ok = int(probe.item() == world)
             except Exception as exc:  # noqa: BLE001
-                sys.stderr.write('[bench] rank %d: RCCL process group failed (%s: %s); using gloo for the timing barrier\n'
-                                 % (rank, type(exc).__name__, str(exc).splitlines()[0] if str(exc) else ''))
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
-                dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
+                ok, why = 0, '%s: %s' % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '')
+                sys.stderr.write('[bench] rank %d: RCCL group failed (%s)\n' % (rank, why))
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                timing_group = None
                 args.dist_backend = 'gloo'
-                backend_used = 'gloo (RCCL process group failed: %s)' % type(exc).__name__
-        else:
-            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
+                backend_used = 'gloo (RCCL group failed on at least one rank%s)' % ((': ' + why) if why else '')
 
     from gym_craftingworld_amd import CraftingWorldVecEnv
-    from gym_craftingworld_amd.sharding import max_over_ranks, shard_range
+    from gym_craftingworld_amd.sharding import gather_over_ranks, max_over_ranks, shard_range
 
     K, W = args.steps, args.warmup
     # weak scaling: the global batch is envs_per_gpu * world envs; rank g owns the contiguous range
@@ -262,6 +278,36 @@ def main():
                               device=dev, seed=lo, raster=args.raster, **menu_kw)
     render_kernel = env.render_kernel_name()     # what a rocprofv3 kernel trace of this run lists the bracketed kernel as
     env.reset()
+    if args.shard_check > 0:
+        # Engine-level shard equivalence across PROCESSES: actions depend on (step, global env index) only, so the ranks of any sharding
+        # must reproduce, env by env, what one process stepping the whole batch produces.  No timing.
+        import zlib
+        Tn = args.shard_check
+        rews, dones = [], []
+        for t in range(Tn):
+            g = np.arange(lo, hi, dtype=np.uint64)
+            a = (((g * np.uint64(2654435761) + np.uint64(t) * np.uint64(40503)) >> np.uint64(7)) % np.uint64(6)).astype(np.uint8)
+            _, r, d, _ = env.step(torch.from_numpy(a).to(dev))
+            rews.append(r.cpu().numpy().copy())
+            dones.append(d.cpu().numpy().copy())
+        env.synchronize()
+        out = dict(lo=lo, hi=hi, reward=np.stack(rews), done=np.stack(dones), hdr=env.hdr.cpu().numpy(), counters=env.counters.cpu().numpy())
+        if args.obs_mode != 'state':
+            for key, t_ in (('obs_crc', env._obs), ('goal_crc', env._desired_img), ('init_crc', env._init_img)):
+                h = t_.cpu().numpy()
+                out[key] = np.array([zlib.crc32(h[i].tobytes()) for i in range(N)], dtype=np.uint32)
+        keys, pos = env.get_rng_states()
+        out['rng_crc'] = np.array([zlib.crc32(keys[i, 1:].tobytes()) ^ int(pos[i]) for i in range(N)], dtype=np.uint32)
+        os.makedirs(args.shard_out, exist_ok=True)
+        np.savez(os.path.join(args.shard_out, 'rank%d.npz' % rank), **out)
+        env.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            json_out.write(json.dumps({'shard_check': Tn, 'n_gpus': world, 'envs': [lo, hi], 'out': args.shard_out}) + '\n')
+            json_out.flush()
+        return
     if args.desync:
         env.set_state(step_num=((np.arange(lo, hi) * 7) % args.max_steps).astype(np.int32))
     # synthetic actions: uniform in [0,6), pre-generated on device, one row per step (not part of the env)
@@ -271,7 +317,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=timing_group)
         torch.cuda.synchronize(dev)
 
     G = args.graph_steps
@@ -321,9 +367,11 @@ def main():
         t0 = time.perf_counter()
         run(k, t_off)
         barrier()
-        return max_over_ranks(time.perf_counter() - t0, device=red_dev)
+        timed_region.mine = time.perf_counter() - t0
+        return max_over_ranks(timed_region.mine, device=red_dev, group=timing_group)
 
     elapsed = timed_region(K, W)                     # THE timed region of the contract: exactly K steps after W warm-up steps
+    per_rank_s = gather_over_ranks(timed_region.mine, device=red_dev, group=timing_group)      # (once, after the region: who was the slowest?)
     # ... and twice more (the driver's K may be tiny: 20 steps are 5 ms); `value` stays the first region
     repeats_s = [elapsed] + ([] if args.quick else [timed_region(K, W + (r + 1) * K) for r in range(2)])
     t_next = W + 3 * K
@@ -375,6 +423,42 @@ def main():
                   'note': 'same process, after the K-step regions; value from a pass without events (max over ranks), per-step '
                           'figures from a second pass with one event per step (rank 0)'}
 
+    # ... and the same window with the episode phases spread out (ray.py:367: episodes end at different steps once a policy succeeds;
+    # about N/max_steps envs are reset beside every sweep): the steady state of a long run, in the same process.  The engine's tuners
+    # (extra sleeps beside resets, loop placement) get an untimed stretch to settle on the new regime first.
+    window_desync = None
+    if not args.quick and args.obs_mode == 'pixels' and not args.desync:
+        KW_ = 2 * args.max_steps
+        env.set_state(step_num=((np.arange(lo, hi) * 7) % args.max_steps).astype(np.int32))
+        for chunk in range(3):                           # 3 x 2*max_steps untimed steps, a host sync between them (the tuners read completed windows)
+            run(KW_, t_next)
+            t_next += KW_
+            torch.cuda.synchronize(dev)
+        ep0 = int(env.counters[1].item())
+        wd_elapsed = timed_region(KW_, t_next)
+        wd_episodes = int(env.counters[1].item()) - ep0
+        t_next += KW_
+        env.profile_begin(KW_)
+        barrier()
+        run(KW_, t_next)
+        barrier()
+        wd_prof = env.profile_end()
+        t_next += KW_
+        wd_resets = int(env.counters[1].item()) - ep0 - wd_episodes
+        S_ = args.size
+        frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
+        wd_bytes = float(N) * (S_ * S_ + frame_) + 2.0 * frame_ * wd_resets / KW_
+        wd_ms = wd_prof['ms_render_kernel']
+        window_desync = {'steps': KW_, 'value': float(N) * world * KW_ / wd_elapsed, 'unit': 'env-steps/s', 'ms_per_step': wd_elapsed / KW_ * 1e3,
+                         'episodes_finished': wd_episodes, 'resets_per_step': wd_episodes / KW_,
+                         'roofline': {'kernel': render_kernel, 'avg_launch_ms': wd_ms, 'median_launch_ms': wd_prof['ms_render_kernel_median'] or None,
+                                      'achieved': wd_bytes / (wd_ms * 1e-3) / 1e9 if wd_ms > 0 else None,
+                                      'frac': wd_bytes / (wd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if wd_ms > 0 else None,
+                                      'algorithmic_bytes_per_launch': wd_bytes},
+                         'note': 'same process, after metric_window: step_num := 7 e mod max_steps, %d untimed steps for the online tuners, '
+                                 'then the window without events (value, max over ranks) and once more with the library\'s events '
+                                 '(roofline, rank 0)' % (3 * KW_)}
+
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
     # step (the reference's own render_edit strategy), state-only has no frames at all.
@@ -388,12 +472,16 @@ def main():
             for t in range(20):
                 e2.step_async(actions[t % rows])
             torch.cuda.synchronize(dev)
-            tt = time.perf_counter()
-            for t in range(k2):
-                e2.step_async(actions[(20 + t) % rows])
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - tt
-            other[mode] = {'value': N * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1}
+            dts = []
+            for rep in range(3):                         # three times back to back: box / run variance of the launch-bound modes in one record
+                tt = time.perf_counter()
+                for t in range(k2):
+                    e2.step_async(actions[(20 + rep * k2 + t) % rows])
+                torch.cuda.synchronize(dev)
+                dts.append(time.perf_counter() - tt)
+            dt = dts[0]
+            other[mode] = {'value': N * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1,
+                           'repeats': {'n': 3, 'value': [N * k2 / x for x in dts], 'us_per_step': [x / k2 * 1e6 for x in dts]}}
             e2.close()
 
     if rank == 0:
@@ -419,12 +507,14 @@ def main():
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
         # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)
-        traffic = None
+        traffic = traffic_source = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
         if pmcs and args.obs_mode == 'pixels' and N == 65536 and S == 21:
             try:
                 traffic = json.load(open(pmcs[-1])).get('hbm_bytes_per_launch')
+                traffic_source = ('not measured in this run: quoted from %s (separate rocprofv3 --pmc passes of the same command, '
+                                  'tools/profile_pmc.sh)' % os.path.relpath(pmcs[-1], ROOT))
             except Exception:  # noqa: BLE001
                 traffic = None
         # the practical ceiling beside the spec peak: a plain device fill of the same number of bytes,
@@ -454,7 +544,7 @@ def main():
                        'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)',
                        'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
             'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
                          'launch_ms_min_max': [prof['ms_render_kernel_min'], prof['ms_render_kernel_max']],
@@ -469,11 +559,14 @@ def main():
             'kernels_ms': {'step': prof['ms_step_kernel'] or None, 'reset': prof['ms_reset_kernel'] or None,
                            'render': prof['ms_render_kernel'] or None, 'ms_per_step_with_events': elapsed_prof / K * 1e3},
             'episodes_finished': episodes, 'prewarm_steps': prewarm_steps,
+            'warmup_total': prewarm_steps + W,           # untimed steps before the timed region: `warmup` is the contract's W
+            'per_rank_ms_per_step': [x / K * 1e3 for x in per_rank_s],
             'repeats': {'n': len(repeats_s), 'ms_per_step': [x / K * 1e3 for x in repeats_s],
                         'value': [total_steps / x for x in repeats_s], 'value_min': total_steps / max(repeats_s),
                         'value_median': total_steps / sorted(repeats_s)[len(repeats_s) // 2],
                         'note': 'the K-step region three times back to back; `value` is the first'},
             'metric_window': window,
+            'metric_window_desync': window_desync,
             'dist_backend': backend_used,
             'other_obs_modes_1gpu': other,
         }
@@ -482,12 +575,14 @@ def main():
         if not args.no_single_env and world == 1:
             env.close()                                  # (idempotent)
             out['single_env'] = single_env_latency(dev)
-        print(json.dumps(out))
-        sys.stdout.flush()
     env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        json_out.write(json.dumps(out) + '\n')         # the last line of rank 0's stdout
+        json_out.flush()
 
 
 if __name__ == '__main__':

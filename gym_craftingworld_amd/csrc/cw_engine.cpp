@@ -456,7 +456,8 @@ static int calibrate_render_shares(cw_engine *e)
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (off && atoi(off) == 0)) return CW_OK;   // (host-mapped frames: PCIe-bound anyway)
     // the paced linear sweep does not profit (m+1: 0.2349 / 0.2349 / 0.2356 ms with shares, 0.2355 / 0.2353 / 0.2349 with equal ones,
     // alternating on one box, profiles/r02_pace.txt): the shares are for the frame-per-wave kernel; CW_TUNE_RENDER_SHARES=1 forces them
-    if (cwk_render_is_linear(&e->P, &tn) && !(off && atoi(off) != 0)) return CW_OK;
+    // (the one-launch step runs the sweep on equal shares whatever is calibrated here: nothing to measure for it)
+    if (cwk_render_is_linear(&e->P, &tn) && (!(off && atoi(off) != 0) || cwk_step_renders_fused(&e->P, &tn, e->auto_reset))) return CW_OK;
     if (const char *q = getenv("CW_TUNE_RENDER_QALL")) {          // forced (experiments): "q_all,parity"
         int qa = 0, par = -1;
         if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
@@ -616,6 +617,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
         tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
+        tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
         tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);

@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
 // as it does the XCD shares.
 template <int MODE, int PLACE = CW_PLACE_DEFAULT>
 __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                              int bid, int n_blocks)
+                                              int bid, int n_blocks, int env_lo, int env_n)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     const int wave = bid * wpb + wave_in_block;
     const int n_waves = n_blocks * wpb;
     const int S = P.size, gr = P.grp_rows, G = P.grp_per_frame;
-    const int n_jobs = P.n_envs * G;                                         // (the launcher checked that this fits)
+    const int n_jobs = env_n * G;                                            // this launch sweeps envs [env_lo, env_lo + env_n): a CHUNK of the batch (cw_sweep_chunks)
     if (wave >= n_jobs) return;
     const bool want_done = (MODE == 3) && skip_done;
     const bool classes = fast_parity >= 0;
@@ -1250,8 +1250,9 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         r.env = -1; r.g = 0; r.hx = 0; r.hw = 0; r.done = 0;
         r.p = make_uint4(0, 0, 0, 0);
         if (i < q_mine && id < n_jobs) {
-            r.env = id / G;
-            r.g = id - r.env * G;
+            const int e_local = id / G;
+            r.env = env_lo + e_local;
+            r.g = id - e_local * G;
             const uint32_t *h = (const uint32_t *)(P.hdr + r.env);
             r.hx = h[0];
             r.hw = h[3];
@@ -1318,10 +1319,11 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
 }
 
 // the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
+__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
+                                                        int env_lo, int env_n)
 {
-    if (mode == 3) render_groups<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
-    else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
+    if (mode == 3) render_groups<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
+    else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
 }
 
 // The FULL pixel step's render AND its auto-resets in one launch: the first render_blocks workgroups are the linear sweep over
@@ -1330,10 +1332,10 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
 // fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
 // barrier packets: the render's part runs 3-6 % shorter without them (profiles/r02_fused_render.txt).
 template <int PLACE>
-__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace)
+__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks);
+    if ((int)blockIdx.x < render_blocks) render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks, env_lo, env_n);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
 // the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
@@ -1453,6 +1455,46 @@ __global__ __launch_bounds__(256) void cw_render_onehot_kernel(const uint8_t *__
     }
 }
 
+// ... and CraftingWorldEnvAltObs.render(state) (craftingworld_altobs.py:489-560) on ANY one-hot state: pixel k of a cell's 3x3 tile =
+// CPV_COLORS[k] x (state[cell][k] + state[cell][9 + k] for k < 3): objects 0..7 and the agent channel, the hold channels added onto
+// items 0..2 (:530-533); then 3 more pixel rows, zero except pixels 3..5 = 255 if any cell has a hold channel set (:557-559).
+// Frames [3S+3][3S][3] uint16 (the reference's int image: up to 2 x colour).
+__global__ __launch_bounds__(256) void cw_render_onehot_alt_kernel(const uint8_t *__restrict__ oh, int n_states, int S, uint32_t div_magic,
+                                                                   uint16_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE;
+    const int n_waves = gridDim.x * blockDim.x / CW_WAVE;
+    const int ncell = S * S;
+    const uint32_t row_px = 3u * S;
+    for (int f = wave; f < n_states; f += n_waves) {
+        const uint8_t *st = oh + (size_t)f * ncell * 12;
+        bool held = false;
+        for (int cell = lane; cell < ncell; cell += CW_WAVE) {
+            const uint8_t *c = st + 12 * cell;
+            held = held || c[9] || c[10] || c[11];
+        }
+        const bool any_held = CW_BALLOT(held) != 0;
+        uint16_t *img = out + (size_t)f * (size_t)(3 * S + 3) * row_px * 3;
+        for (int cell = lane; cell < ncell; cell += CW_WAVE) {
+            const uint8_t *c = st + 12 * cell;
+            const uint32_t cr = __umulhi((uint32_t)cell, div_magic), cc = (uint32_t)cell - cr * S;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const uint32_t cnt = (uint32_t)c[k] + (k < 3 ? (uint32_t)c[9 + k] : 0u), col = cpv_color(k);
+                uint16_t *px = img + ((size_t)(3u * cr + k / 3) * row_px + 3u * cc + k % 3) * 3;
+                px[0] = (uint16_t)(cnt * (col & 0xFFu)); px[1] = (uint16_t)(cnt * ((col >> 8) & 0xFFu)); px[2] = (uint16_t)(cnt * (col >> 16));
+            }
+        }
+        for (uint32_t j = (uint32_t)lane; j < 3u * row_px; j += CW_WAVE) {
+            const uint32_t x = j % row_px;
+            const uint16_t v = (any_held && x >= 3u && x < 6u) ? 255 : 0;
+            uint16_t *px = img + ((size_t)(3u * S) * row_px + j) * 3;
+            px[0] = v; px[1] = v; px[2] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ seeding
 // seed() (ray.py:145-147) at batch scale, one lane per env: numpy RandomState(seed) is init_genrand -- 623 dependent
 // multiplies, embarrassingly parallel over envs -- and leaves pos = 624; an injected RandomState state (key, pos) is
@@ -1487,17 +1529,26 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// linear sweep where the geometry allows it (Ray raster, S <= 64) and where it is the faster one: its waves are in step only at
-// the start of a launch, and over thousands of rounds they drift apart (the write window smears, the slower XCDs' waves trail) --
-// measured at 21x21: 0.69 vs 0.665 of the HBM peak for frame-per-wave at 262 144 envs (1 792 rounds per wave), 0.676 vs 0.725 at
-// 524 288, 0.62 vs 0.71 at 2^20 (profiles/r02_other_configs.txt).  CW_TUNE_RENDER_LINEAR=2 forces it whatever the batch.
+// linear sweep where the geometry allows it: Ray raster, S <= 64.  Its waves are in step only at the start of a launch; over thousands
+// of rounds they drift apart (the write window smears, the slower XCDs' waves trail): 0.76-0.77 of the HBM peak up to ~1 800 rounds per
+// wave (262 144 envs at 21x21), 0.62-0.68 at 2^20 envs in one launch (profiles/r02_other_configs.txt, r02_pace.txt R-S).  So a large
+// batch is swept in CHUNKS of at most tn.render_chunk_rounds rounds per wave, back-to-back launches over consecutive env ranges on
+// one stream (a launch gap of ~2 us against ~1 ms per chunk; every launch starts with its waves in step again).
 static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
 {
     if (!tn.render_linear || P.raster != 0 || P.grp_rows <= 0) return 0;
+    return (long long)P.n_envs * P.grp_per_frame < (1ll << 30);
+}
+// -> number of chunks; *per = envs per chunk (the last one may be shorter)
+static inline int cw_sweep_chunks(const CwParams &P, const CwTuning &tn, int *per)
+{
     const long long jobs = (long long)P.n_envs * P.grp_per_frame;
-    if (jobs >= (1ll << 30)) return 0;
     const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
-    return tn.render_linear >= 2 || jobs <= 2560 * waves;
+    const long long cap = (long long)(tn.render_chunk_rounds > 0 ? tn.render_chunk_rounds : 1 << 30) * waves;
+    int n = (int)((jobs + cap - 1) / cap);
+    if (n < 1) n = 1;
+    *per = (P.n_envs + n - 1) / n;
+    return (P.n_envs + *per - 1) / *per;
 }
 static inline int cw_render_grid(const CwTuning &tn, int jobs);
 static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
@@ -1520,8 +1571,13 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_render_linear(P, tn)) hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace);
-    else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
+    if (cw_render_linear(P, tn)) {
+        int per = 0;
+        const int n_chunks = cw_sweep_chunks(P, tn, &per);
+        for (int c = 0; c < n_chunks; c++)
+            hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace, c * per,
+                               min(per, P.n_envs - c * per));
+    } else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
@@ -1584,12 +1640,15 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
         if (cw_render_linear(*P, tn)) {
-            typedef void (*StepRenderFn)(CwParams, int, int);
+            typedef void (*StepRenderFn)(CwParams, int, int, int, int);
             static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
                                                                cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
                                                                cw_render_step_kernel<6>, cw_render_step_kernel<7>};
-            hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
-                               tn.render_pace);
+            int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
+            const int n_chunks = cw_sweep_chunks(*P, tn, &per);
+            for (int c = 0; c < n_chunks; c++)
+                hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
+                                   render_blocks, tn.render_pace, c * per, min(per, n - c * per));
         }
         else
             hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
@@ -1653,7 +1712,8 @@ hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, in
     int blocks = (n_states + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(cw_render_onehot_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
+    if (P->raster == 1) hipLaunchKernelGGL(cw_render_onehot_alt_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
+    else hipLaunchKernelGGL(cw_render_onehot_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
     return hipGetLastError();
 }
 

@@ -189,6 +189,9 @@ class CraftingWorldEnv:
     def _after_step_enqueue(self):
         """hook: more work for the same stream sync (the one-hot façade exports its state here)"""
 
+    def _exact_values(self):
+        """hook (reference_dtypes=True only): values the engine's uint8 frame cannot hold, restored in the int64 copy"""
+
     def step(self, action):
         a = int(action)
         if not 0 <= a < len(self.ACTIONS):
@@ -204,6 +207,7 @@ class CraftingWorldEnv:
         self.step_num += 1
         if not self._live:
             self.obs_image[...] = self._h_obs
+            self._exact_values()
         self._pull_goals()
         if self.store_gif is True and self.ep_no % self.render_save_rate == 0:    # ray.py:370-374
             self._gif_frames.append(self._gif_frame())
@@ -219,7 +223,8 @@ class CraftingWorldEnv:
         if mode == 'human':
             raise NotImplementedError('mode="human" (matplotlib popup) is out of scope')
         if state is None:
-            return self._vec.render()[0].cpu().numpy().astype(self._dtype)
+            img = self._vec.render()[0].cpu().numpy().astype(self._dtype)
+            return self._exact_image(img) if not self._live else img
         st = np.asarray(state)
         S = self.STATE_W
         if st.shape != (S, S, 12):
@@ -230,6 +235,9 @@ class CraftingWorldEnv:
             raise ValueError('state must be a one-hot (0/1) array')
         img = self._vec.render_states(st.astype(np.uint8)[None])[0].cpu().numpy()
         return img.astype(self._dtype)
+
+    def _exact_image(self, img):
+        return img
 
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         return self._vec.compute_reward(achieved_goal, desired_goal, info)
@@ -316,9 +324,21 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 class CraftingWorldEnvAltObs(CraftingWorldEnv):
     """craftingworld_altobs.py:85-886 (exported by the reference, not registered): same dynamics, 3x3-px CPV
     rasteriser with a "holding" strip, images ((W+1)*3, H*3, 3); stacked_obs=True returns the four images
-    stacked (4, ., ., 3) instead of the Dict (altobs.py:116-119, 258-261, 408-412).  Pixel values are the
-    reference's int image modulo 256 (it reaches 2 x colour when sticks are held over sticks)."""
+    stacked (4, ., ., 3) instead of the Dict (altobs.py:116-119, 258-261, 408-412).  The reference's int image reaches
+    2 x colour in ONE place -- sticks held over a sticks cell: pixel 0 of the agent's tile is (90, 164, 320), altobs.py:527-543.
+    The engine's frames are uint8 and hold (90, 164, 64) there (a value no other state produces); with reference_dtypes=True the
+    int64 copies handed out are exact: the one pixel is restored on the host.  (Default dtype uint8: modulo 256.)"""
     _raster = 'alt'
+
+    def _exact_image(self, img):
+        first = img[0:3 * self.STATE_W:3, 0::3]                # pixel 0 of every tile (a view): sticks items, count x (45, 82, 160)
+        twice = (first[..., 0] == 90) & (first[..., 1] == 164) & (first[..., 2] == 64)
+        if twice.any():
+            first[..., 2][twice] = 320
+        return img
+
+    def _exact_values(self):
+        self._exact_image(self.obs_image)
 
     def __init__(self, *a, stacked_obs=False, **kw):
         super().__init__(*a, **kw)

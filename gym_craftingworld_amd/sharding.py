@@ -19,13 +19,23 @@ def env_seeds(seed_base, lo, hi):
     return [int(seed_base) + e for e in range(lo, hi)]
 
 
-def max_over_ranks(value, device='cpu'):
-    """MAX-reduce a python float over the default process group (identity without one)."""
+def max_over_ranks(value, device='cpu', group=None):
+    """MAX-reduce a python float over a process group (default: the default one; identity without one)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def gather_over_ranks(value, device='cpu', group=None):
+    """Every rank's python float, in rank order, on every rank (one all_gather; [value] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]
 
 
 def sum_over_ranks(values, device='cpu'):

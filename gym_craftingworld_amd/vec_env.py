@@ -388,12 +388,13 @@ class CraftingWorldVecEnv:
     def render_states(self, one_hot):
         """render(state) of ray.py:442-486 for caller-supplied one-hot states [M,S,S,12] of any content (several objects in a
         cell, any number of objects): -> int16 tensor [M,4S,4S,3] holding the reference's int image (sums of colours; the
-        agent is the first cell with channel 8 set and must exist).  Does not touch the envs."""
+        agent is the first cell with channel 8 set and must exist).  raster='alt': CraftingWorldEnvAltObs.render(state)
+        (craftingworld_altobs.py:489-560), [M,3S+3,3S,3].  Does not touch the envs."""
         oh = torch.as_tensor(np.asarray(one_hot) if not torch.is_tensor(one_hot) else one_hot)
         oh = oh.to(device=self.device, dtype=torch.uint8).contiguous()
         if oh.dim() != 4 or tuple(oh.shape[1:]) != (self.size, self.size, 12):
             raise ValueError('states must have shape [M, %d, %d, 12]' % (self.size, self.size))
-        out = torch.empty((oh.shape[0], 4 * self.size, 4 * self.size, 3), dtype=torch.int16, device=self.device)
+        out = torch.empty((oh.shape[0],) + self.frame_shape, dtype=torch.int16, device=self.device)
         L.check(self._lib.cw_render_onehot(self._h, C.c_void_p(oh.data_ptr()), oh.shape[0], C.c_void_p(out.data_ptr()), self._stream()),
                 'cw_render_onehot')
         self._states_keepalive = oh

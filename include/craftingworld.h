@@ -181,7 +181,10 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);
 /* render(state) (ray.py:442-486) for caller-supplied one-hot states of ANY content: onehot is a DEVICE array [n_states][S][S][12]
  * uint8 (S = the engine's size), out_frames a DEVICE array [n_states][4S][4S][3] uint16 -- the reference's image is the SUM of the
  * colours of the objects in a cell (int; up to 8 x 255), the agent is the first cell (row-major) with channel 8 set and must exist,
- * the held item's colour comes from the largest hold channel set anywhere.  Does not touch the engine's own state. */
+ * the held item's colour comes from the largest hold channel set anywhere.  Does not touch the engine's own state.
+ * Engines with CW_RASTER_ALT render CraftingWorldEnvAltObs.render(state) instead (craftingworld_altobs.py:489-560): out_frames is
+ * [n_states][3S+3][3S][3] uint16, pixel k of a cell's tile = CPV_COLORS[k] x (channel k + hold channel 9+k for k < 3), the strip's
+ * pixels 3..5 are 255 if any cell has a hold channel set. */
 int cw_render_onehot(cw_engine *e, const uint8_t *onehot, int32_t n_states, uint16_t *out_frames, cw_stream_t stream);
 
 /* Dense state views written to caller-supplied DEVICE buffers (observation_vector_space,

@@ -963,19 +963,23 @@ def test_host_mapped_outputs_equal_device_outputs(obs_mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,variant', [('ray5_scripted', 'dict'), ('ray8_selected', 'int64'), ('ray5_subset', 'flat'),
-                                          ('ray8_scripted', 'onehot'), ('alt5_random', 'alt'), ('alt8_scripted', 'alt_stacked')])
+                                          ('ray8_scripted', 'onehot'), ('alt5_random', 'alt'), ('alt8_scripted', 'alt_stacked'),
+                                          ('alt4_double', 'alt_exact'), ('alt8_scripted', 'alt_exact'), ('alt4_double', 'alt_exact_stacked')])
 def test_single_env_facades_replay_fixtures(name, variant):
     """The gym.Env-shaped N=1 classes (host-mapped outputs, no auto-reset, numpy in/out) on whole reference
     trajectories: every reward, done, achieved mask, frame and reset of the fixture, through each façade's own
-    return convention (Dict / int64 copies / Flat's bare frame / OneHot states / AltObs Dict and stacked)."""
+    return convention (Dict / int64 copies / Flat's bare frame / OneHot states / AltObs Dict and stacked).  alt_exact: the AltObs class
+    with reference_dtypes=True against the fixtures' int16 CRCs -- the reference's int image EXACTLY, values above 255 included
+    (alt4_double holds sticks over sticks on 9 steps: (90, 164, 320), craftingworld_altobs.py:527-543)."""
     import gym_craftingworld_amd as cw
     meta, kw, g = load(name)
     cls = {'dict': cw.CraftingWorldEnv, 'int64': cw.CraftingWorldEnv, 'flat': cw.CraftingWorldEnvFlat,
-           'onehot': cw.CraftingWorldEnvOneHot, 'alt': cw.CraftingWorldEnvAltObs, 'alt_stacked': cw.CraftingWorldEnvAltObs}[variant]
+           'onehot': cw.CraftingWorldEnvOneHot}.get(variant, cw.CraftingWorldEnvAltObs)
+    exact = variant.startswith('alt_exact')
     extra = {}
-    if variant == 'int64':
+    if variant == 'int64' or exact:
         extra['reference_dtypes'] = True
-    if variant == 'alt_stacked':
+    if variant in ('alt_stacked', 'alt_exact_stacked'):
         extra['stacked_obs'] = True
     if variant == 'flat':
         kw = {k: v for k, v in kw.items() if k != 'fixed_init_state'}
@@ -985,7 +989,7 @@ def test_single_env_facades_replay_fixtures(name, variant):
     def frames(o):      # -> (observation, desired_goal or None, init_observation or None) as uint8
         if variant == 'flat':
             return o, None, None
-        if variant == 'alt_stacked':
+        if variant in ('alt_stacked', 'alt_exact_stacked'):
             assert o.shape[0] == 4 and np.array_equal(o[0], o[2])
             return o[0], o[1], o[3]
         return o['observation'], o['desired_goal'], o['init_observation']
@@ -1006,17 +1010,27 @@ def test_single_env_facades_replay_fixtures(name, variant):
             assert crc(ob.astype(np.uint8)) == g['r_obs_crc'][ri], (name, 'reset obs', ri)
             if des is not None:
                 assert crc(des.astype(np.uint8)) == g['r_desired_img_crc'][ri] and crc(ini.astype(np.uint8)) == g['r_init_img_crc'][ri]
-            if variant == 'int64':
+            if variant == 'int64' or exact:
                 assert ob.dtype == np.int64
+            if exact:
+                assert crc(ob.astype(np.int16)) == g['r_obs_crc16'][ri] and crc(des.astype(np.int16)) == g['r_desired_img_crc16'][ri]
+                assert crc(ini.astype(np.int16)) == g['r_init_img_crc16'][ri]
         bits = sum(int(b) << i for i, b in enumerate(env.desired_goal_vector[0]))
         assert bits == g['r_desired'][ri] and env.ep_no == g['r_ep_no'][ri]
         ri += 1
 
     check_reset(env.reset(), 0)
-    T = min(len(g['action']), 1500)
+    T = len(g['action']) if exact else min(len(g['action']), 1500)
+    over = 0
     for t in range(T):
         o, r, d, info = env.step(int(g['action'][t]))
         assert r == g['reward'][t] and d == bool(g['done'][t]), (name, t)
+        if exact:
+            ob = frames(o)[0]
+            assert crc(ob.astype(np.int16)) == g['obs_crc16'][t] and int(ob.max()) == g['obs_max'][t], (name, 'exact obs', t)
+            over += int(ob.max() > 255)
+            if ob.max() > 255:
+                assert np.array_equal(env.render(), ob)                  # render() of the current state is exact too
         assert sum(int(b) << i for i, b in enumerate(info['achieved_goal'][0])) == g['achieved'][t], (name, 'achieved', t)
         assert env.step_num == g['step_num'][t]
         if d:
@@ -1031,6 +1045,10 @@ def test_single_env_facades_replay_fixtures(name, variant):
         else:
             assert crc(frames(o)[0].astype(np.uint8)) == g['obs_crc'][t], (name, 'obs', t)
     assert ri >= 2
+    if exact:
+        assert over == int((g['obs_max'] > 255).sum()) and (over == 9 if name == 'alt4_double' else True)
+        if 'stacked' not in variant:
+            assert np.array_equal(env.obs_image.astype(np.int16), g['final_obs16'])
     env.close()
 
 
@@ -1069,7 +1087,8 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
-                                           (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt')])
+                                           (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'),
+                                           (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked')])
 def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
     sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
@@ -1077,6 +1096,9 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch)
     (CW_TUNE_OVERLAP=0) -- and all three must leave exactly the frames, results and random streams of the dirty-cell engine,
     with episodes ending on every step (phases spread out) and all at once."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
+    if raster == 'ray-chunked':      # large batches are swept in several launches over consecutive env ranges (cw_sweep_chunks): here 5 / 14 of them,
+        raster = 'ray'               # the last one shorter, the resetting workgroups on the first
+        monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '5' if N < 10000 else '35')
     kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
     engines = {}
     for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
@@ -1276,6 +1298,72 @@ def test_facade_render_of_a_supplied_state():
 
 
 @pytest.mark.gpu
+def _reference_alt_render_of_any_state(state):
+    """craftingworld_altobs.py:489-560 restated in numpy for a caller-supplied one-hot state (test-side oracle): pixel k of a cell's
+    3x3 tile = CPV_COLORS[k] x (channel k, + hold channel 9 + k for k < 3); three more rows, pixels 3..5 white if anything is held."""
+    cpv = np.array([(45, 82, 160), (255, 102, 102), (204, 204, 0), (211, 211, 211), (34, 133, 34), (0, 215, 255), (153, 52, 255),
+                    (10, 215, 100), (0, 0, 255)], dtype=np.int64)                                   # CPV_COLORS, altobs.py:26-27
+    h, w = state.shape[:2]
+    items = state[:, :, :9].astype(np.int64).copy()
+    items[:, :, :3] += state[:, :, 9:12]
+    img = np.zeros((3 * h + 3, 3 * w, 3), dtype=np.int64)
+    for k in range(9):
+        img[k // 3:3 * h:3, k % 3::3] = items[:, :, k][:, :, None] * cpv[k]
+    if state[:, :, 9:12].max() > 0:
+        img[3 * h:, 3:6] = 255
+    return img
+
+
+def test_altobs_facade_render_of_a_supplied_state():
+    """CraftingWorldEnvAltObs.render(state=one_hot) returns the AltObs image ((S+1)*3, S*3, 3) of THAT state (round 2 returned a Ray-style
+    image here): equal to the frame of an env that is in that state along a trajectory with held items, equal to a numpy restatement of
+    craftingworld_altobs.py:489-560 for arbitrary states (objects doubled up, hold flags anywhere), exact with reference_dtypes=True."""
+    import gym_craftingworld_amd as cw
+    env = cw.CraftingWorldEnvAltObs(size=(6, 6), max_steps=80, reference_dtypes=True)
+    other = cw.CraftingWorldEnvAltObs(size=(6, 6), max_steps=80, reference_dtypes=True)
+    env.seed(3); other.seed(8)
+    env.reset(); other.reset()
+    rng = np.random.RandomState(12)
+    held = 0
+    for t in range(80):
+        obs, _, d, _ = env.step(int(rng.choice([0, 1, 2, 3, 4, 4, 5])))
+        oh = env.obs_one_hot
+        held += int(oh[:, :, 9:].sum() > 0)
+        got = other.render(state=oh)
+        assert got.shape == (21, 18, 3) and got.dtype == np.int64
+        assert np.array_equal(got, obs['observation']) and np.array_equal(got, _reference_alt_render_of_any_state(oh)), t
+        assert np.array_equal(env.render(), obs['observation'])
+        if d:
+            break
+    st = env._vec.get_state()
+    held = 0
+    for hold in (1, 2, 3):                                   # held items: counted on their own object pixel at the agent's tile + the strip's flag
+        g2 = st['grid'][0].copy()
+        where = np.argwhere(g2 == hold)
+        if len(where) == 0:
+            continue
+        g2[tuple(where[0])] = 0
+        if hold == 1:                                        # ... and sticks held OVER sticks: 2 x (45, 82, 160) = (90, 164, 320)
+            g2[tuple(st['agent_rc'][0])] = 1
+        env._vec.set_state(grid=g2[None], init_grid=st['init_grid'], agent_rc=st['agent_rc'], hold=np.array([hold]))
+        oh = env.obs_one_hot
+        want = _reference_alt_render_of_any_state(oh)
+        assert oh[:, :, 8 + hold].sum() == 1 and (want.max() == 320) == (hold == 1)
+        assert np.array_equal(other.render(state=oh), want) and np.array_equal(env.render(), want), hold
+        held += 1
+    assert held >= 2
+    for trial in range(20):                                  # arbitrary states: the reference renders whatever the array holds
+        st = (rng.rand(6, 6, 12) < 0.15).astype(int)
+        st[:, :, 8] = 0
+        st[rng.randint(6), rng.randint(6), 8] = 1
+        if trial % 3 == 0:
+            st[:, :, 9:] = 0
+        assert np.array_equal(other.render(state=st), _reference_alt_render_of_any_state(st)), trial
+    with pytest.raises(IndexError):
+        other.render(state=np.zeros((6, 6, 12), int))       # no agent: state_idxs[0][0], altobs.py:501
+    env.close(); other.close()
+
+
 def test_facade_store_gif_files_and_rng_draw(tmp_path, monkeypatch):
     """store_gif=True on the single-env class (ray.py:142-143,160-167,205-216,370-374,769-782): the env id is one
     randint(0, 1000000) taken from the env's own stream at construction (so later placements shift exactly as the
@@ -1603,6 +1691,37 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
 
 
+def test_shards_of_self_launched_ranks_equal_the_single_batch(tmp_path):
+    """Engine-level shard equivalence ACROSS PROCESSES: `bench.py --gpus 2 --shard-check T` self-launches two fresh ranks, each
+    steps its contiguous env range (1 500 envs, full frames, short episodes: many resets) with actions that depend on (step, global env
+    index) only and dumps per-env CRCs of its three frames, every step's reward / done, the packed state and the RNG streams; one process
+    stepping all 3 000 envs does the same; the concatenated shards must equal the single batch, field by field.  Three processes use the
+    GPU at most."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    common = ['--shard-check', '45', '--max-steps', '11', '--mixed-menus']
+    two, one = str(tmp_path / 'two'), str(tmp_path / 'one')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-on-one-gpu', '--dist-backend', 'gloo',
+                        '--envs-per-gpu', '1500', '--shard-out', two] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])['n_gpus'] == 2
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--envs-per-gpu', '3000', '--shard-out', one] + common,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    whole = np.load(os.path.join(one, 'rank0.npz'))
+    parts = [np.load(os.path.join(two, 'rank%d.npz' % r)) for r in range(2)]
+    assert (int(parts[0]['lo']), int(parts[0]['hi']), int(parts[1]['lo']), int(parts[1]['hi'])) == (0, 1500, 1500, 3000)
+    for key in ('obs_crc', 'goal_crc', 'init_crc', 'rng_crc', 'hdr'):
+        assert np.array_equal(np.concatenate([q[key] for q in parts]), whole[key]), key
+    for key in ('reward', 'done'):
+        assert np.array_equal(np.concatenate([q[key] for q in parts], axis=1), whole[key]), key
+    assert np.array_equal(parts[0]['counters'] + parts[1]['counters'], whole['counters'])
+    assert whole['done'].sum() > 3000 * 3                # (episodes of 11 steps: every env was reset several times)
+
+
 @pytest.mark.gpu
 def test_bench_json_line_carries_the_contract():
     """One small `python bench.py` run on this GPU: exactly one JSON line with the contract's keys, the roofline object (dominant kernel
@@ -1618,11 +1737,16 @@ def test_bench_json_line_carries_the_contract():
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout
+    assert len(lines) == 1 and p.stdout.strip().splitlines()[-1] == lines[0], p.stdout      # one JSON line, the LAST line of stdout
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-              'data', 'config', 'roofline', 'cpu_baseline'):
+              'data', 'config', 'roofline', 'cpu_baseline', 'warmup_total', 'per_rank_ms_per_step', 'metric_window_desync'):
         assert k in d, k
+    assert d['warmup_total'] == d['warmup'] + d['prewarm_steps'] and len(d['per_rank_ms_per_step']) == 1
+    assert abs(d['per_rank_ms_per_step'][0] - d['ms_per_step']) < 1e-9
+    wd = d['metric_window_desync']
+    assert wd['steps'] == 40 and wd['value'] > 0 and 0 < wd['roofline']['frac'] < 1 and wd['resets_per_step'] > 8192 / 20 * 0.8
+    assert 'traffic_source' in d['roofline']
     assert d['n_gpus'] == 1 and d['steps'] == 40 and d['warmup'] == 5 and d['higher_is_better'] is True and d['scaling'] == 'weak'
     assert d['vs_baseline'] is None and d['dtype'] == 'u8' and d['unit'] == 'env-steps/s' and 'workload' in d['config']
     assert abs(d['value'] - 8192 * 40 / (d['ms_per_step'] * 40e-3)) < 1e-6 * d['value']

@@ -95,3 +95,32 @@ def test_bench_plain_multi_gpu_start_spawns_ranks_instead_of_refusing():
         assert p.returncode != 0
         assert 'torch.distributed.run' not in p.stderr
         assert 'needs GPU' in p.stderr or 'no MI355X' in p.stderr or 'device' in p.stderr.lower()
+
+
+def test_eight_ranks_start_rendezvous_over_gloo_and_relay_one_line(tmp_path):
+    """The shape of the driver's N=8 scaling run, without GPUs: eight fresh ranks from spawn_ranks() rendezvous over gloo on 127.0.0.1,
+    take the timing barrier, MAX-reduce and gather their times the way bench.py does, and rank 0 alone writes the line the parent relays."""
+    argv = _script(tmp_path, '''
+        import datetime, json, os, sys, time
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from gym_craftingworld_amd.sharding import gather_over_ranks, max_over_ranks, shard_range
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=120))
+        r, w = dist.get_rank(), dist.get_world_size()
+        lo, hi = shard_range(r, w, 8 * 1000 + 3)
+        dist.barrier()
+        mine = 0.001 * (r + 1)
+        worst = max_over_ranks(mine)
+        everyone = gather_over_ranks(mine)
+        dist.barrier()
+        dist.destroy_process_group()
+        if r == 0:
+            print(json.dumps(dict(n_gpus=w, worst=worst, per_rank=everyone, lo=lo, hi=hi)))
+    ''' % ROOT)
+    with open(tmp_path / 'out.txt', 'w') as f:
+        rc = launch.spawn_ranks(argv, 8, stdout=f, timeout=240)
+    assert rc == 0
+    lines = (tmp_path / 'out.txt').read_text().strip().splitlines()
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 8 and abs(d['worst'] - 0.008) < 1e-12 and d['per_rank'] == [0.001 * (i + 1) for i in range(8)]
+    assert (d['lo'], d['hi']) == (0, 1001)

@@ -43,12 +43,14 @@ SCENARIOS = [
     ('ray32_scripted',    dict(size=(32, 32), max_steps=300),                    3232,  1500, 'scripted', 1),
     ('ray4_tiny',         dict(size=(4, 4), max_steps=30),                       404,   3000, 'random',   1),
 ]
-# CraftingWorldEnvAltObs (craftingworld_altobs.py): same dynamics, 3x3-px CPV rasteriser; images are stored
-# as uint8 views (the reference's int image reaches 2 x colour when the agent holds sticks on a sticks cell)
+# CraftingWorldEnvAltObs (craftingworld_altobs.py): same dynamics, 3x3-px CPV rasteriser.  The reference's int image reaches 2 x colour
+# when the agent holds sticks on a sticks cell ((45, 82, 160) -> (90, 164, 320)): CRCs are stored of the uint8 view (what the batch
+# engine's uint8 frames hold) AND of the int16 view (exact; what the N=1 facade returns with reference_dtypes=True)
 ALT_SCENARIOS = [
     ('alt21_scripted',    dict(size=(21, 21)),                                   2121,  1500, 'scripted', 2),
     ('alt5_random',       dict(size=(5, 5), max_steps=40),                       55,    4000, 'random',   2),
     ('alt8_scripted',     dict(size=(8, 8), max_steps=60, reward_style='subset'), 88,   3000, 'scripted', 1),
+    ('alt4_double',       dict(size=(4, 4), max_steps=120),                      109,   5000, 'random',   1),   # sticks held over sticks on 9 steps: values up to 320
 ]
 
 
@@ -88,9 +90,11 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
     size = env.STATE_W
 
     R = dict(desired=[], grid=[], agent=[], rng_pos=[], rng_crc=[], obs_crc=[], desired_img_crc=[],
-             init_img_crc=[], at_step=[], ep_no=[], goal_grid=[], goal_agent=[])
+             init_img_crc=[], at_step=[], ep_no=[], goal_grid=[], goal_agent=[], obs_crc16=[], desired_img_crc16=[], init_img_crc16=[])
     S = dict(action=[], reward=[], done=[], achieved=[], agent=[], hold=[], step_num=[], grid_crc=[],
-             obs_crc=[], grid=[])
+             obs_crc=[], grid=[], obs_crc16=[], obs_max=[])
+    alt = env_name == 'CraftingWorldEnvAltObs'
+
     imgs_desired, imgs_obs = [], []
 
     def record_reset(t):
@@ -112,6 +116,10 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
         R['obs_crc'].append(crc(obs['observation'].astype(np.uint8)))
         R['desired_img_crc'].append(crc(obs['desired_goal'].astype(np.uint8)))
         R['init_img_crc'].append(crc(obs['init_observation'].astype(np.uint8)))
+        if alt:
+            R['obs_crc16'].append(crc(obs['observation'].astype(np.int16)))
+            R['desired_img_crc16'].append(crc(obs['desired_goal'].astype(np.int16)))
+            R['init_img_crc16'].append(crc(obs['init_observation'].astype(np.int16)))
         R['at_step'].append(t)
         R['ep_no'].append(env.ep_no)
         if len(imgs_desired) < keep_images:
@@ -137,6 +145,9 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
         S['step_num'].append(env.step_num)
         S['grid_crc'].append(crc(codes))
         S['obs_crc'].append(crc(obs['observation'].astype(np.uint8)))
+        if alt:
+            S['obs_crc16'].append(crc(obs['observation'].astype(np.int16)))
+            S['obs_max'].append(int(np.max(obs['observation'])))
         if size <= 8:
             S['grid'].append(codes)
         n_success += int(reward == env.MAX_STEPS)
@@ -172,6 +183,13 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
     )
     if size <= 8:
         out['grid'] = np.array(S['grid'], np.uint8)
+    if alt:
+        out['obs_crc16'] = np.array(S['obs_crc16'], np.uint32)
+        out['obs_max'] = np.array(S['obs_max'], np.int16)          # > 255 where sticks are held over sticks
+        out['r_obs_crc16'] = np.array(R['obs_crc16'], np.uint32)
+        out['r_desired_img_crc16'] = np.array(R['desired_img_crc16'], np.uint32)
+        out['r_init_img_crc16'] = np.array(R['init_img_crc16'], np.uint32)
+        out['final_obs16'] = np.asarray(env.obs_image).astype(np.int16)
     if onehot:
         out['r_goal_grid'] = np.array(R['goal_grid'], np.uint8)
         out['r_goal_agent'] = np.array(R['goal_agent'], np.uint8)
