@@ -66,6 +66,7 @@ struct DeviceGuard {
     }
 };
 
+enum { CW_ADAPT_RING = 256 };
 struct cw_engine {
     int device = 0;
     int obs_mode = 0;
@@ -86,11 +87,12 @@ struct cw_engine {
     // online tuner of the render pace (full-frame mode, linear sweep): see adapt_tick
     struct Adapt {
         bool on = false;
-        hipEvent_t ev[64] = {nullptr};         // ev[w % 64] is recorded on the caller's stream when window w begins
+        hipEvent_t ev[CW_ADAPT_RING] = {nullptr};   // ev[w % RING] is recorded on the caller's stream when window w begins (the host may run
+                                               // RING windows = 2 048 steps ahead of the GPU before measurements are lost)
         unsigned seq = 0;                      // steps taken in the tuned mode
         unsigned next_window = 0;              // first window whose duration has not been read yet
         int cur = 2;                           // extra sleeps per pair of jobs while envs are reset beside the sweep, currently held
-        signed char pace_of_window[64] = {0};  // what each recent window ran at; negative: a settling window, not counted
+        signed char pace_of_window[CW_ADAPT_RING] = {0};  // what each recent window ran at; negative: a settling window, not counted
         float stat[16] = {0};                  // per pace: running mean step time of its counted windows (ms; 0: unknown)
         unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
         // ... and of the PLACEMENT of the sweep's batch loop (cw_render_step_kernel<k>, cw_kernels.hip: render_groups)
@@ -99,13 +101,15 @@ struct cw_engine {
         int place = 3;                         // the placement held outside a survey
         bool surveying = false;
         unsigned survey_w0 = 0;                // first window of the running survey
-        signed char place_of_window[64] = {0}; // placement each recent window ran at
-        signed char round_of_window[64] = {0}; // 0: not a survey window; r + 1: round r of a survey (round 0 is not counted)
+        signed char place_of_window[CW_ADAPT_RING] = {0}; // placement each recent window ran at
+        signed char round_of_window[CW_ADAPT_RING] = {0}; // 0: not a survey window; r + 1: round r of a survey (round 0 is not counted)
+        bool tainted[CW_ADAPT_RING] = {false};            // a step of the window was bracketed by cw_profile_* events (each costs a pipeline bubble): not counted
         float survey_ms[8][3] = {{0}};         // ms per step of placement k in survey rounds 1..3
         unsigned survey_seen = 0;              // survey windows read so far
         float place_ms = 0;                    // what `place` measured when it was chosen
         int place_bad = 0;                     // consecutive counted windows more than 4 % above that
         unsigned surveys = 0;
+        unsigned place_struck = 0;             // bit k: placement k was held and fell out of its regime (not held again in this process)
     } adapt;
 };
 enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24 };
@@ -338,31 +342,33 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
 // count).  With fewer than CW_BESIDE_MIN resets per step the value is never used by the kernel and its drift is harmless.
 // (2) The same instructions run up to 17 % apart depending on where the batch loop lies modulo 32 bytes, and which placement is the good one
 // changes with the loop body, the compiler and the box.  So all eight are built (cw_render_step_kernel<k>) and a SURVEY picks one: four
-// rounds of one window per placement (the first round -- a variant's first launches load its code -- is not counted), the placement with
-// the lowest median of its three counted windows is then held.  A survey runs when the engine starts stepping and again when the held
-// placement has read more than 4 % above its own survey figure for CW_PLACE_BAD_WINDOWS counted windows in a row (the regime has moved:
-// e.g. episode phases that have spread out).  The pace of (1) is frozen during a survey.  CW_TUNE_RENDER_PLACE=k forces a placement.
+// rounds of one window per placement (the first round -- a variant's first launches load its code -- is not counted); of the placements
+// whose median window is within 6 % of the fastest, the MEDIAN one is then held (the fastest are bistable, see below).  A survey runs when
+// the engine starts stepping and again when the held placement has read more than 4 % above its own survey figure for
+// CW_PLACE_BAD_WINDOWS counted windows in a row (the regime has moved: e.g. episode phases that have spread out); that placement is
+// then struck off for the rest of the process.  The pace of (1) is frozen during a survey.  CW_TUNE_RENDER_PLACE=k forces a placement.
 static void adapt_tick(cw_engine *e, hipStream_t st)
 {
     cw_engine::Adapt &a = e->adapt;
     const unsigned w = a.seq / CW_ADAPT_W;           // the window about to start
-    if (hipEventRecord(a.ev[w % 64], st) != hipSuccess) return;
+    if (hipEventRecord(a.ev[w % CW_ADAPT_RING], st) != hipSuccess) return;
+    a.tainted[w % CW_ADAPT_RING] = false;
     const bool verbose = getenv("CW_TUNE_VERBOSE") != nullptr;
     bool moved = false;
     while (a.next_window + 1 <= w) {                 // window next_window lies between ev[next_window] and ev[next_window + 1]
         const unsigned cw = a.next_window;
-        if (w - cw >= 63) {                                                      // (its events have been reused)
-            if (a.round_of_window[cw % 64]) a.survey_seen++;                     //  a survey window lost: its sample stays 0 = unknown
+        if (w - cw >= CW_ADAPT_RING - 1) {                                                      // (its events have been reused)
+            if (a.round_of_window[cw % CW_ADAPT_RING]) a.survey_seen++;                     //  a survey window lost: its sample stays 0 = unknown
             a.next_window++;
             continue;
         }
         if (cw + 1 == w) break;                                                  // its closing event was recorded just now
-        if (hipEventQuery(a.ev[(cw + 1) % 64]) != hipSuccess) break;
+        if (hipEventQuery(a.ev[(cw + 1) % CW_ADAPT_RING]) != hipSuccess) break;
         float ms = 0.f;
-        const int p = a.pace_of_window[cw % 64];
-        const int round = a.round_of_window[cw % 64], place = a.place_of_window[cw % 64];
+        const int p = a.pace_of_window[cw % CW_ADAPT_RING];
+        const int round = a.round_of_window[cw % CW_ADAPT_RING], place = a.place_of_window[cw % CW_ADAPT_RING];
         a.next_window++;
-        const bool timed = hipEventElapsedTime(&ms, a.ev[cw % 64], a.ev[(cw + 1) % 64]) == hipSuccess && ms > 0.f;
+        const bool timed = !a.tainted[cw % CW_ADAPT_RING] && hipEventElapsedTime(&ms, a.ev[cw % CW_ADAPT_RING], a.ev[(cw + 1) % CW_ADAPT_RING]) == hipSuccess && ms > 0.f;
         ms /= (float)CW_ADAPT_W;
         if (round) {                                                             // a survey window
             if (timed && round >= 2) a.survey_ms[place & 7][round - 2] = ms;
@@ -379,18 +385,32 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             a.place_bad = ms > 1.04f * a.place_ms ? a.place_bad + 1 : 0;
     }
     if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
-        int best = a.place;                                                      // every survey window has been read: hold the best placement
-        float best_ms = 0.f;
+        // Every survey window has been read.  WHICH placement to hold: not the fastest.  Placements come in three kinds (profiles/
+        // r03_placement.txt): on the cliff (+15-25 %), on the plateau (within ~1 % of each other), and one or two 2-3 % FASTER than the
+        // plateau that are bistable -- the same build runs a whole bench at 0.227 ms per launch or at 0.267, and nothing in a short visit
+        // tells which it will be.  So: drop what is more than 6 % above the fastest (the cliff), and of the rest hold the MEDIAN one --
+        // neither on the cliff nor on the edge.  A placement that later reads > 4 % above its survey figure for CW_PLACE_BAD_WINDOWS
+        // windows is struck off (a.place_struck) and the survey repeated.
+        int best = a.place;
+        float best_ms = 0.f, fastest = 0.f, med[CW_PLACES];
         char log[256] = "";
         size_t len = 0;
         for (int k = 0; k < CW_PLACES; k++) {
             float *m = a.survey_ms[k];
+            med[k] = 0.f;
             if (m[0] <= 0 || m[1] <= 0 || m[2] <= 0) continue;                   // (a lost sample: the placement does not compete)
-            const float med = std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2]));
-            if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", k, med);
-            if (best_ms == 0.f || med < best_ms) { best_ms = med; best = k; }
+            med[k] = std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2]));
+            if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f%s", k, med[k], ((a.place_struck >> k) & 1) ? "x" : "");
+            if ((a.place_struck >> k) & 1) { med[k] = 0.f; continue; }
+            if (fastest == 0.f || med[k] < fastest) fastest = med[k];
         }
-        if (verbose) fprintf(stderr, "[craftingworld] placement survey %u (window %u), median ms/step by placement:%s -> %d\n", a.surveys, w, log, best);
+        int cand[CW_PLACES], n_cand = 0;
+        for (int k = 0; k < CW_PLACES; k++)
+            if (med[k] > 0.f && med[k] <= 1.06f * fastest) cand[n_cand++] = k;
+        std::sort(cand, cand + n_cand, [&](int x, int y) { return med[x] < med[y]; });
+        if (n_cand > 0) { best = cand[(n_cand - 1) / 2]; best_ms = med[best]; }
+        if (verbose) fprintf(stderr, "[craftingworld] placement survey %u (window %u), median ms/step by placement:%s -> %d (median of the %d within 6 %% of the fastest)\n",
+                             a.surveys, w, log, best, n_cand);
         a.place = best;
         a.place_ms = best_ms;
         a.place_bad = 0;
@@ -398,8 +418,12 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         for (int p = 0; p < 16; p++) a.stat[p] = 0;                              // the pace figures belonged to the old placement
     }
     if (a.place_on && !a.surveying && (a.surveys == 0 || a.place_bad >= CW_PLACE_BAD_WINDOWS)) {
-        if (verbose && a.surveys) fprintf(stderr, "[craftingworld] placement %d has read > 4 %% above its %.4f ms/step for %d windows: new survey\n",
-                                          a.place, a.place_ms, a.place_bad);
+        if (a.surveys) {
+            if (verbose) fprintf(stderr, "[craftingworld] placement %d has read > 4 %% above its %.4f ms/step for %d windows: struck off, new survey\n",
+                                 a.place, a.place_ms, a.place_bad);
+            a.place_struck |= 1u << a.place;
+            if ((a.place_struck & 0xFFu) == 0xFFu) a.place_struck = 0;              // (all struck: the regime has moved as a whole; start over)
+        }
         a.surveying = true;
         a.survey_w0 = w;
         a.survey_seen = 0;
@@ -409,13 +433,13 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
     }
     if (a.surveying && w < a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {         // a survey window: placement by turns, pace frozen
         const unsigned j = w - a.survey_w0;
-        a.place_of_window[w % 64] = (signed char)(j % CW_PLACES);
-        a.round_of_window[w % 64] = (signed char)(j / CW_PLACES + 1);
-        a.pace_of_window[w % 64] = (signed char)a.cur;
+        a.place_of_window[w % CW_ADAPT_RING] = (signed char)(j % CW_PLACES);
+        a.round_of_window[w % CW_ADAPT_RING] = (signed char)(j / CW_PLACES + 1);
+        a.pace_of_window[w % CW_ADAPT_RING] = (signed char)a.cur;
         return;
     }
-    a.place_of_window[w % 64] = (signed char)a.place;                            // (survey windows still being read: the old placement meanwhile)
-    a.round_of_window[w % 64] = 0;
+    a.place_of_window[w % CW_ADAPT_RING] = (signed char)a.place;                            // (survey windows still being read: the old placement meanwhile)
+    a.round_of_window[w % CW_ADAPT_RING] = 0;
     if (moved && !a.surveying && a.pace_on) {        // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
         const int c = a.cur;
         auto fresh = [&](int p) { return p >= 0 && p <= CW_ADAPT_MAX && a.stat[p] > 0 && a.next_window - a.stat_window[p] < 80; };
@@ -439,7 +463,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
         else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
     }
-    a.pace_of_window[w % 64] = (signed char)(settle ? -1 - p : p);
+    a.pace_of_window[w % CW_ADAPT_RING] = (signed char)(settle ? -1 - p : p);
 }
 
 // XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
@@ -818,9 +842,10 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
-            const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
+            const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING];
             e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | ((pw < 0 ? -1 - pw : pw) << 12);
-            if (e->adapt.place_on) e->tune.render_place = e->adapt.place_of_window[(e->adapt.seq / CW_ADAPT_W) % 64];
+            if (e->adapt.place_on) e->tune.render_place = e->adapt.place_of_window[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING];
+            if (ev) e->adapt.tainted[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING] = true;
             e->adapt.seq++;
         } else {
             e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | (e->adapt.cur << 12);     // a captured graph keeps the values it was captured with

@@ -1237,14 +1237,18 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // 0.252 ms on one box, 3 best and 1 at 0.267 on another (profiles/r02_pace.txt, r02_fused_render.txt; cw_step tunes the number
     // online).  (done_count is zeroed by the last resetting workgroup: a wave that starts after that paces like a launch with nothing
     // beside it, which is what it then is.)
-    const int pace_pair = (pace & 0xFF) + ((want_done && cload(P.done_count) >= CW_BESIDE_MIN) ? ((pace >> 12) & 15) : 0);
+    const int pace_base = pace & 0xFF, pace_beside = want_done ? ((pace >> 12) & 15) : 0;
     const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
     const int pace_fine = (pace >> 16) & 0xFF;                               // iterations of a one-s_nop loop before every job
     CW_WAVE_CLOCK(t_start);
     if (MODE == 3) CW_WAVE_STAMP(wave, 0);
-    struct Rec { int env, g; uint32_t hx, hw, done; uint4 p; };
+    struct Rec { int env, g, cnt; uint32_t hx, hw, done; uint4 p; };
     auto fetch = [&](int base) {
         Rec r;
+        // the done counter rides with every batch's records (a coherent load: the last resetting workgroup zeroes it when the list is
+        // done): the extra sleeps apply only to batches fetched while envs were still being reset beside the sweep -- the resets are over
+        // after the first 20-40 us of a launch, and slowing the sweep for the rest of it bought nothing
+        r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const int i = base + lane;
         const int id = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
         r.env = -1; r.g = 0; r.hx = 0; r.hw = 0; r.done = 0;
@@ -1276,6 +1280,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         const Rec cur = nxt;
         if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
         const int in_batch = min(q_mine - base, CW_WAVE);
+        const int pace_pair = pace_base + (__builtin_amdgcn_readfirstlane(cur.cnt) >= CW_BESIDE_MIN ? pace_beside : 0);
         for (int k = 0; k < in_batch; k++) {
             if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
             for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 0");
@@ -1531,7 +1536,7 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 // ------------------------------------------------------------------------------------ launchers
 // linear sweep where the geometry allows it: Ray raster, S <= 64.  Its waves are in step only at the start of a launch; over thousands
 // of rounds they drift apart (the write window smears, the slower XCDs' waves trail): 0.76-0.77 of the HBM peak up to ~1 800 rounds per
-// wave (262 144 envs at 21x21), 0.62-0.68 at 2^20 envs in one launch (profiles/r02_other_configs.txt, r02_pace.txt R-S).  So a large
+// wave (262 144 envs at 21x21), 0.62-0.74 at 2^20 envs in one launch (profiles/r02_other_configs.txt, r02_pace.txt R-S, r03_other_configs.txt).  So a large
 // batch is swept in CHUNKS of at most tn.render_chunk_rounds rounds per wave, back-to-back launches over consecutive env ranges on
 // one stream (a launch gap of ~2 us against ~1 ms per chunk; every launch starts with its waves in step again).
 static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
@@ -1548,6 +1553,9 @@ static inline int cw_sweep_chunks(const CwParams &P, const CwTuning &tn, int *pe
     int n = (int)((jobs + cap - 1) / cap);
     if (n < 1) n = 1;
     *per = (P.n_envs + n - 1) / n;
+    // whole multiples of the wave count: every wave of a chunk then paints the same number of jobs, and chunks start at multiples of
+    // 1024 frames (2^20 envs in 7 chunks of 149 797: 0.60 of the HBM peak at EVERY placement; in 8 of 131 072: 0.775, r03_other_configs.txt)
+    if (n > 1) *per = (int)(((long long)*per + waves - 1) / waves * waves);
     return (P.n_envs + *per - 1) / *per;
 }
 static inline int cw_render_grid(const CwTuning &tn, int jobs);

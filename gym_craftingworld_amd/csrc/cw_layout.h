@@ -52,7 +52,7 @@ struct CwTuning {
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int render_linear = 1;          // full-frame render as a linear sweep (job = a run of whole grid rows); 0: frame per wave
-    int render_chunk_rounds = 1792; // ... in launches of at most this many rounds per wave over consecutive env ranges (0: one launch whatever the batch)
+    int render_chunk_rounds = 896;  // ... in launches of at most this many rounds per wave over consecutive env ranges: 131 072 envs at 21x21 (0: one launch whatever the batch)
     int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;
                                     // tuned online by cw_step, CW_TUNE_RENDER_PLACE=k forces one)
     int render_pace_fine = 0;       // ... bits 16-23 of render_pace: iterations of a one-s_nop loop before every job (a pace finer than s_sleep's 64 clocks)
