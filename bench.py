@@ -354,7 +354,7 @@ def main():
 
     # Device warm-up before the contract's W warm-up steps: the card has idled through env construction, and its first few hundred
     # launches after that run 3-6 % slower than the steady state the K timed steps are meant to show (K=20, W=5 without it: 2.60-2.67 x 10^8
-    # in the first region, 2.74-2.77 in the next two; profiles/r02_pace.txt T).  Untimed, like the W steps that follow it.
+    # in the first region, 2.74-2.77 in the next two; profiles/history/r02_pace.txt T).  Untimed, like the W steps that follow it.
     prewarm_steps = 0 if args.rollout else max(args.prewarm_steps, 0)
     if prewarm_steps > 0:
         run((prewarm_steps // G) * G if G > 0 else prewarm_steps, 0)
@@ -390,6 +390,7 @@ def main():
     barrier()
     elapsed_prof = time.perf_counter() - t1
     prof = env.profile_end()
+    tuner = env.tuner_state()                        # (which placement of the sweep loop the profiled launches ran at)
     t_next += K
     episodes = int(env.counters[1].item())
     resets_in_prof = episodes - episodes_before_prof      # envs reset (and repainted: 3 frames each) inside the profiled launches
@@ -502,7 +503,7 @@ def main():
         else:
             alg_bytes = plain_alg_bytes = float(N) * 48.0
             # state-only / dirty-cell: the whole auto-reset step is one launch (step + inline resets), latency-bound
-            fused = os.environ.get('CW_TUNE_FUSED_STEP', '1') != '0'
+            fused = not (os.environ.get('CW_EXPERIMENT_BUILD', '0') not in ('', '0') and os.environ.get('CW_TUNE_FUSED_STEP', '1') == '0')
             dominant, ms = ('cw_step_fused_kernel' if fused else 'cw_step_kernel'), prof['ms_step_kernel']
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
@@ -543,7 +544,11 @@ def main():
                        'sharding': 'contiguous env ranges per rank, no data-path collective',
                        'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)',
                        'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
-            'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': dominant,
+                         # the one-launch step exists at eight placements of its sweep loop, and the engine measures which one to launch: a
+                         # rocprofv3 trace lists them as cw_render_step_kernel<0..7>, this is the one the profiled region ran
+                         'kernel_in_trace': ('%s<%d>' % (dominant, tuner['place'])) if dominant == 'cw_render_step_kernel' else dominant,
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
@@ -555,9 +560,10 @@ def main():
                                                    if args.obs_mode == 'pixels' and prof['ms_render_kernel_median'] > 0 else None),
                          'events': 'hipEventRecord on the launch stream around every kernel, %d launches' % prof['steps']},
             # full-pixel mode brackets only the dominant render kernel (each event record costs a pipeline bubble,
-            # side-stream events perturb the overlap); CW_PROFILE_SIDE_STREAM=1 brackets all three
+            # side-stream events perturb the overlap); an experiment build with CW_PROFILE_SIDE_STREAM=1 brackets all three
             'kernels_ms': {'step': prof['ms_step_kernel'] or None, 'reset': prof['ms_reset_kernel'] or None,
                            'render': prof['ms_render_kernel'] or None, 'ms_per_step_with_events': elapsed_prof / K * 1e3},
+            'tuner': tuner,
             'episodes_finished': episodes, 'prewarm_steps': prewarm_steps,
             'warmup_total': prewarm_steps + W,           # untimed steps before the timed region: `warmup` is the contract's W
             'per_rank_ms_per_step': [x / K * 1e3 for x in per_rank_s],

@@ -8,7 +8,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('CW_LIB_PATH') or os.path.join(_HERE, 'libcraftingworld.so')   # CW_LIB_PATH: experiment builds
+LIB_PATH = os.path.join(_HERE, 'libcraftingworld.so')
+EXP_LIB_PATH = os.path.join(_HERE, 'libcraftingworld_exp.so')     # the same sources with -DCW_EXPERIMENT: launch-shape knobs compiled in
+
+
+def lib_path():
+    """Which build to load: CW_LIB_PATH (any other build, A/B runs) > CW_EXPERIMENT_BUILD=1 (libcraftingworld_exp.so) > the product."""
+    if os.environ.get('CW_LIB_PATH'):
+        return os.environ['CW_LIB_PATH']
+    if os.environ.get('CW_EXPERIMENT_BUILD', '0') not in ('', '0'):
+        return EXP_LIB_PATH
+    return LIB_PATH
 
 CW_ABI_VERSION = 2
 CW_MT_N = 624
@@ -55,6 +65,11 @@ class cw_profile(C.Structure):
                 ('ms_render_kernel_median', C.c_float)]
 
 
+class cw_tuner_state(C.Structure):
+    _fields_ = [('place', C.c_int32), ('surveys', C.c_int32), ('struck_mask', C.c_int32), ('sleeps_beside', C.c_int32),
+                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32)]
+
+
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 ABI = {
@@ -79,6 +94,7 @@ ABI = {
     'cw_checkpoint_load': (C.c_int, [_VP, _VP, C.c_size_t]),
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
+    'cw_tuner': (C.c_int, [_VP, C.POINTER(cw_tuner_state)]),
     'cw_render_kernel_name': (C.c_char_p, [_VP]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),
     'cw_synchronize': (C.c_int, [_VP, _VP]),
@@ -94,7 +110,8 @@ HOST_HELPERS = {
     'cwh_dlpack_make': (_VP, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 
-_lib = None
+_libs = {}      # path -> loaded library (a process may hold the product and the experiment build side by side)
+_lib = None     # the one loaded (or asked for) last: check() takes its error text
 
 
 class CraftingWorldError(RuntimeError):
@@ -102,34 +119,36 @@ class CraftingWorldError(RuntimeError):
 
 
 def load():
-    """Load libcraftingworld.so (after torch, so both share one HIP runtime)."""
+    """Load the engine library chosen by lib_path() (after torch, so both share one HIP runtime); cached per path."""
     global _lib
-    if _lib is not None:
+    path = lib_path()
+    if path in _libs:
+        _lib = _libs[path]
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise CraftingWorldError(
             'HIP extension %s is missing; build it (python -c "import __graft_entry__ as g; g.build()"). '
-            'There is no CPU fallback.' % LIB_PATH)
+            'There is no CPU fallback.' % path)
     try:
         import torch  # noqa: F401  -- loads torch's libamdhip64 first so the SONAME resolves to it
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for table in (ABI, HOST_HELPERS):
         for name, (res, args) in table.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
     if lib.cw_abi_version() != CW_ABI_VERSION:
-        raise CraftingWorldError('libcraftingworld.so ABI %d != binding %d' % (lib.cw_abi_version(), CW_ABI_VERSION))
-    _lib = lib
+        raise CraftingWorldError('%s ABI %d != binding %d' % (os.path.basename(path), lib.cw_abi_version(), CW_ABI_VERSION))
+    _libs[path] = _lib = lib
     return lib
 
 
 def check(rc, what):
     if rc == CW_OK:
         return
-    msg = (load().cw_last_error() or b'').decode(errors='replace')
+    msg = ((_lib or load()).cw_last_error() or b'').decode(errors='replace')
     if rc == CW_ERR_INVALID:
         raise ValueError('%s: %s' % (what, msg))
     raise CraftingWorldError('%s failed (%d): %s' % (what, rc, msg))

@@ -239,7 +239,7 @@ static void prof_free(cw_engine *e)
 // Ray raster: the pace is FIXED at m+0 (one s_sleep inside every job, none between jobs); on top of it come extra sleeps per pair of
 // jobs while at least CW_BESIDE_MIN envs are being reset beside the sweep (cw_kernels.hip: render_groups), and THAT number is what
 // the online tuner (adapt_tick) follows.  Round 2 first measured the pace at cw_create (median launch time per candidate) and let
-// the tuner follow it; then both were compared with forced paces, alternating on one box, several boxes (profiles/r02_pace.txt):
+// the tuner follow it; then both were compared with forced paces, alternating on one box, several boxes (profiles/history/r02_pace.txt):
 // the launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace (0.2298-0.2455 ms for m+0) -- more
 // than the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the processes.  Inside a step sequence
 // the order is the same on every box and shape tried: m+0 0.2333, one sleep per pair without the inner one 0.2332-0.2345, unpaced
@@ -263,7 +263,12 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     if (alt) e->P.alt_pace = 2;                           // (engines that are not calibrated: mid-range)
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions) return CW_OK;      // (the Ray raster is paced in both of its kernels)
     if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
-    if (!alt && !(getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0)) {
+#ifdef CW_EXPERIMENT
+    const bool measure_base_pace = getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0;
+#else
+    const bool measure_base_pace = false;
+#endif
+    if (!alt && !measure_base_pace) {
         const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
         tn.render_pace = 0x100 | (((beside ? atoi(beside) : 2) & 15) << 12);
         return CW_OK;
@@ -332,7 +337,7 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
 }
 
 // Online tuner of the one-launch full-frame step: (1) the sweep's extra sleeps beside resets, (2) the placement of its batch loop.
-// Neither can be predicted from launches timed at cw_create (profiles/r02_pace.txt, r02_fused_render.txt, r03_placement.txt), so cw_step
+// Neither can be predicted from launches timed at cw_create (profiles/history/r02_pace.txt, r02_fused_render.txt, r03_placement.txt), so cw_step
 // keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and the time between
 // two consecutive ones, read whenever both have completed -- however far the host runs ahead of the GPU -- is what CW_ADAPT_W whole steps
 // took.  Only performance depends on any of it: every placement and every pace paints the same frames.
@@ -476,13 +481,22 @@ static int calibrate_render_shares(cw_engine *e)
     CwTuning &tn = e->tune;
     tn.render_q_all = 0;
     tn.render_fast_parity = -1;
+#ifdef CW_EXPERIMENT
     const char *off = getenv("CW_TUNE_RENDER_SHARES");
+#else
+    const char *off = nullptr;
+#endif
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (off && atoi(off) == 0)) return CW_OK;   // (host-mapped frames: PCIe-bound anyway)
     // the paced linear sweep does not profit (m+1: 0.2349 / 0.2349 / 0.2356 ms with shares, 0.2355 / 0.2353 / 0.2349 with equal ones,
-    // alternating on one box, profiles/r02_pace.txt): the shares are for the frame-per-wave kernel; CW_TUNE_RENDER_SHARES=1 forces them
+    // alternating on one box, profiles/history/r02_pace.txt): the shares are for the frame-per-wave kernel; CW_TUNE_RENDER_SHARES=1 forces them
     // (the one-launch step runs the sweep on equal shares whatever is calibrated here: nothing to measure for it)
     if (cwk_render_is_linear(&e->P, &tn) && (!(off && atoi(off) != 0) || cwk_step_renders_fused(&e->P, &tn, e->auto_reset))) return CW_OK;
-    if (const char *q = getenv("CW_TUNE_RENDER_QALL")) {          // forced (experiments): "q_all,parity"
+#ifdef CW_EXPERIMENT
+    const char *forced_shares = getenv("CW_TUNE_RENDER_QALL");              // "q_all,parity"
+#else
+    const char *forced_shares = nullptr;
+#endif
+    if (const char *q = forced_shares) {
         int qa = 0, par = -1;
         if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
         return CW_OK;
@@ -624,13 +638,20 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.frame_bytes = cfg->raster == CW_RASTER_ALT ? 27u * (uint32_t)e->S * (uint32_t)(e->S + 1) : 48u * (uint32_t)e->ncell;
     P.grp_rows = e->S <= 64 ? 64 / e->S : 0;
     P.grp_per_frame = P.grp_rows ? (e->S + P.grp_rows - 1) / P.grp_rows : 0;
-    {   // experiment knobs; the defaults are the measured best
+    {   // Tuning.  The defaults are the measured best; a product build reads six environment variables -- CW_TUNE_VERBOSE,
+        // CW_TUNE_RENDER_ADAPT, CW_TUNE_RENDER_PLACE, CW_TUNE_RENDER_PACE, CW_TUNE_RENDER_PACE_BESIDE, CW_TUNE_RENDER_CHUNK_ROUNDS -- and a
+        // build with -DCW_EXPERIMENT (libcraftingworld_exp.so: A/B runs and the tests that hold the older launch arrangements to the same
+        // results) the launch-shape knobs below as well.
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
-        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);   // 2: the render waves raise their priority, the reset kernel beside them does not
         CwTuning &tn = e->tune;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
         tn.list_blocks = tn.n_cu;
+        P.tune_reset_prio = 2;                               // the render waves raise their priority, the reset kernel beside them does not
+        tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
+        tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
+#ifdef CW_EXPERIMENT
+        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);
         tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
         tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
         const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
@@ -641,13 +662,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
         tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
         tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
-        tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
-        tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
         tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
         tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
+        tn.fused_reset_blocks_per_cu = geti("CW_TUNE_FUSED_RESET_BLOCKS_PER_CU", tn.fused_reset_blocks_per_cu);
+#endif
         if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
         if (tn.reset_blocks_per_cu > 8) tn.reset_blocks_per_cu = 8;
-        tn.fused_reset_blocks_per_cu = geti("CW_TUNE_FUSED_RESET_BLOCKS_PER_CU", tn.fused_reset_blocks_per_cu);
         if (tn.fused_reset_blocks_per_cu < 1) tn.fused_reset_blocks_per_cu = 1;
         if (tn.fused_reset_blocks_per_cu > 8) tn.fused_reset_blocks_per_cu = 8;
         if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
@@ -975,6 +995,19 @@ const char *cw_render_kernel_name(const cw_engine *e)
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
+}
+
+int cw_tuner(const cw_engine *e, cw_tuner_state *out)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_tuner: null argument");
+    const cw_engine::Adapt &a = e->adapt;
+    out->place = a.place_on ? a.place : e->tune.render_place;
+    out->surveys = (int32_t)a.surveys;
+    out->struck_mask = (int32_t)a.place_struck;
+    out->sleeps_beside = a.on && a.pace_on ? a.cur : (e->tune.render_pace >> 12) & 15;
+    out->place_tuned = a.on && a.place_on ? 1 : 0;
+    out->sleeps_tuned = a.on && a.pace_on ? 1 : 0;
+    return CW_OK;
 }
 
 int cw_buffers(cw_engine *e, cw_buffer_table *out)

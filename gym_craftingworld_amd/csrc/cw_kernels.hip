@@ -583,7 +583,7 @@ __device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint3
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
 // the sweep slows down (pace bits 12-15) only beside at least this many resetting waves: with uniform random actions a handful of the
 // 65 536 envs succeed on almost every step, and 1-5 resetting waves do not disturb the sweep -- reacting to them cost 15 us on most
-// launches of the synchronized benchmark (the "two launch modes" of profiles/r02_pace.txt H)
+// launches of the synchronized benchmark (the "two launch modes" of profiles/history/r02_pace.txt H)
 #define CW_BESIDE_MIN 32
 #define CW_PLACE_DEFAULT 3   // placement of render_groups' batch loop where no tuner picks it (cw_render, the two-kernel step)
 #define CW_N_PLACES 8
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
 //
 // PACING.  The kernel is bound by the memory system's write path, and that path is LESS efficient when saturated than
 // when kept just short of it: with every wave pushing stores as fast as it can the launch takes 0.254 ms, with 128 idle
-// clocks per pair of jobs 0.241 ms, with 256 it is slower again (profiles/r02_render_linear.txt; the same holds for every
+// clocks per pair of jobs 0.241 ms, with 256 it is slower again (profiles/history/r02_render_linear.txt; the same holds for every
 // store shape tried, 16-B-per-lane stores staged through LDS included, each with its own optimum).  WHERE the idle clocks
 // sit matters too: 64 clocks between a job's second and third store beat the same clocks between jobs by 2.5 %
 // (0.2407 vs 0.2471 ms) -- the smoother the stream of stores, the better.  So a wave sleeps 64 clocks in the middle of
@@ -1234,7 +1234,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // sleeps of 64 clocks per pair of jobs (pace bits 0-7), and `pace` bits 12-15 more while at least CW_BESIDE_MIN envs are being
     // reset beside this sweep (the launch's resetting workgroups, or the reset kernel on the side stream): their unpaced bursts push a
     // write path that sits just short of saturation over the edge -- phases spread out, 0 / 2 / 3 / 4 extra: 0.263 / 0.245 / 0.248 /
-    // 0.252 ms on one box, 3 best and 1 at 0.267 on another (profiles/r02_pace.txt, r02_fused_render.txt; cw_step tunes the number
+    // 0.252 ms on one box, 3 best and 1 at 0.267 on another (profiles/history/r02_pace.txt, r02_fused_render.txt; cw_step tunes the number
     // online).  (done_count is zeroed by the last resetting workgroup: a wave that starts after that paces like a launch with nothing
     // beside it, which is what it then is.)
     const int pace_base = pace & 0xFF, pace_beside = want_done ? ((pace >> 12) & 15) : 0;
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     };
     // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions have
     // read 0.2325 ms at one placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few
-    // clocks per job at the loop's branch targets (profiles/r02_pace.txt N-P) -- and which placement is the good one moves with every edit
+    // clocks per job at the loop's branch targets (profiles/history/r02_pace.txt N-P) -- and which placement is the good one moves with every edit
     // of the loop body, with the box, and would move with the compiler (profiles/r03_placement.txt).  So the placement is a TUNED parameter,
     // not a pinned one: the one-launch step is built at all eight placements modulo 32 bytes (PLACE x s_nop after a 32-byte boundary,
     // executed once per wave; cw_render_step_kernel<0..7>) and cw_step measures which one this process should run (cw_engine.cpp: adapt_tick).
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
 // the envs that go on (mode 3, skip_done), the rest are resetting workgroups over the done list (one wave per finished env, its
 // three frames painted by that wave) -- the pair that cwk_launch_step otherwise runs as two kernels on two streams with an event
 // fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
-// barrier packets: the render's part runs 3-6 % shorter without them (profiles/r02_fused_render.txt).
+// barrier packets: the render's part runs 3-6 % shorter without them (profiles/history/r02_fused_render.txt).
 template <int PLACE>
 __global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
 {
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 // ------------------------------------------------------------------------------------ launchers
 // linear sweep where the geometry allows it: Ray raster, S <= 64.  Its waves are in step only at the start of a launch; over thousands
 // of rounds they drift apart (the write window smears, the slower XCDs' waves trail): 0.76-0.77 of the HBM peak up to ~1 800 rounds per
-// wave (262 144 envs at 21x21), 0.62-0.74 at 2^20 envs in one launch (profiles/r02_other_configs.txt, r02_pace.txt R-S, r03_other_configs.txt).  So a large
+// wave (262 144 envs at 21x21), 0.62-0.74 at 2^20 envs in one launch (profiles/history/r02_other_configs.txt, r02_pace.txt R-S, r03_other_configs.txt).  So a large
 // batch is swept in CHUNKS of at most tn.render_chunk_rounds rounds per wave, back-to-back launches over consecutive env ranges on
 // one stream (a launch gap of ~2 us against ~1 ms per chunk; every launch starts with its waves in step again).
 static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
@@ -1565,7 +1565,7 @@ static inline int cw_render_grid(const CwTuning &tn, int jobs)
 {
     // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
     // write path saturates with few store streams and gets slower with more of them in flight
-    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/r01_render_sweeps.txt); it also
+    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt); it also
     // leaves the wave slots for the reset kernel running beside it
     const int wpb = tn.render_threads / CW_WAVE;
     int blocks = (jobs + wpb - 1) / wpb;
@@ -1644,7 +1644,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         const int render_blocks = cw_render_grid(tn, n);
         // resetting workgroups: one per CU.  Each costs the launch ~12 ns whether or not anything finished (+1.2 % per 256 of them on
         // every step), and a step on which every env finishes at once is rare: 1 / 2 / 4 per CU = 2.62 / 2.60 / 2.55 x 10^8 env-steps/s
-        // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/r02_fused_render.txt H)
+        // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/history/r02_fused_render.txt H)
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
         if (cw_render_linear(*P, tn)) {

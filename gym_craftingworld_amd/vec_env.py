@@ -485,6 +485,14 @@ class CraftingWorldVecEnv:
         L.check(self._lib.cw_profile_end(self._h, C.byref(p)), 'cw_profile_end')
         return {k: getattr(p, k) for k, _ in p._fields_}
 
+    def tuner_state(self):
+        """What the engine's online tuner holds right now (full-frame mode; performance only): dict with `place` (the placement k of the
+        sweep loop it launches -- a kernel trace lists it as cw_render_step_kernel<k>), `surveys`, `struck_mask`, `sleeps_beside`,
+        `place_tuned`, `sleeps_tuned`."""
+        t = L.cw_tuner_state()
+        L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner')
+        return {k: int(getattr(t, k)) for k, _ in t._fields_}
+
     def compute_reward_batch(self, achieved_mask, desired_mask, subset=None):
         """Vectorised compute_reward_equal / compute_reward_subset (ray.py:757-767) on bit masks, for
         HER-style relabelling on the device: int tensors of any shape -> int32 rewards (MAX_STEPS or -1).

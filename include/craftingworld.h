@@ -235,6 +235,15 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
  * CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
+/* What cw_step's online tuner currently holds (full-frame mode, one-launch step): the placement k of the sweep's batch loop
+ * it launches (the kernel a trace lists as cw_render_step_kernel<k>), how many placement surveys it has run, the placements it struck
+ * off (bit k), the extra sleeps per pair of jobs beside resets, and whether each of the two is tuned (1) or forced / off (0).
+ * Only performance depends on any of it. */
+typedef struct cw_tuner_state {
+    int32_t place, surveys, struck_mask, sleeps_beside, place_tuned, sleeps_tuned;
+} cw_tuner_state;
+int cw_tuner(const cw_engine *e, cw_tuner_state *out);
+
 int cw_buffers(cw_engine *e, cw_buffer_table *out);
 /* Blocks the calling thread until everything enqueued on `stream` has finished (hipStreamSynchronize): the one host
  * synchronisation of the single-env loop, where step() returns Python scalars (ray.py:376-378). */

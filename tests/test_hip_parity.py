@@ -873,7 +873,7 @@ def test_systematic_transition_table():
 @pytest.mark.gpu
 @pytest.mark.parametrize('obs_mode,raster,N', [('state', 'ray', 1003), ('state', 'ray', 70001), ('pixels_dirty', 'ray', 5000),
                                                ('pixels_dirty', 'alt', 777)])
-def test_single_launch_step_equals_separate_kernels(obs_mode, raster, N, monkeypatch):
+def test_single_launch_step_equals_separate_kernels(obs_mode, raster, N, monkeypatch, experiment_build):
     """State-only and dirty-cell modes run a whole auto-reset step as ONE launch (cw_step_fused_kernel: a wave
     steps its envs and resets the finished ones inline); CW_TUNE_FUSED_STEP=0 selects the separate step / reset
     kernels the full-frame mode uses.  Same seeds and actions: every buffer, counter and RNG stream must agree,
@@ -1055,19 +1055,24 @@ def test_single_env_facades_replay_fixtures(name, variant):
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,shares', [(5000, '1,0'), (5000, '3,1'), (5000, '4,0'), (65536, '10,1'), (65536, '63,0'), (65536, 'off'),
                                       (70001, '40,1')])
-def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
+def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, experiment_build):
     """The full-frame render kernel splits the frames unevenly between even and odd workgroups (XCD-aware shares that
     cw_create calibrates).  Whatever the split -- forced here to extreme values, either parity, or switched off --
-    every frame must be painted exactly as the dirty-cell engine paints it: the split may only change the speed."""
+    every frame must be painted exactly as the dirty-cell engine paints it: the split may only change the speed.  (The shares belong to
+    the frame-per-wave painter -- CW_TUNE_RENDER_LINEAR=0 here, as for the AltObs raster and grids wider than 64 cells; the linear sweep
+    of the one-launch step runs on equal shares.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     kw = dict(size=(21, 21), max_steps=9, seed=13)
+    monkeypatch.setenv('CW_TUNE_RENDER_LINEAR', '0')
     if shares == 'off':
         monkeypatch.setenv('CW_TUNE_RENDER_SHARES', '0')
     else:
         monkeypatch.setenv('CW_TUNE_RENDER_QALL', shares)
     full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    assert full.render_kernel_name() == 'cw_render_frames_step_kernel'
     monkeypatch.delenv('CW_TUNE_RENDER_SHARES', raising=False)
     monkeypatch.delenv('CW_TUNE_RENDER_QALL', raising=False)
+    monkeypatch.delenv('CW_TUNE_RENDER_LINEAR')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     of, od = full.reset(), dirty.reset()
     full.obs_fill = of['observation'].fill_(7)            # poison: a frame the kernel skipped would keep this value
@@ -1089,7 +1094,7 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch):
 @pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
                                            (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'),
                                            (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked')])
-def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch):
+def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch, experiment_build):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
     sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
     arrangements stay selectable -- two kernels on two streams (CW_TUNE_FUSED_RENDER=0), one stream with the resets first
@@ -1766,7 +1771,7 @@ def test_bench_json_line_carries_the_contract():
 def test_headline_perf_floor_of_the_sweep_kernel():
     """The performance regime of the dominant kernel is a tested property: a fresh `bench.py --quick --steps 300` (BASELINE configs[2]:
     65 536 envs, 21x21, full frames) must paint at >= 0.72 of the 8 TB/s HBM peak at its median launch (rounds 2-3 measured 0.756-0.785;
-    a build on the placement cliff of profiles/r02_pace.txt O reads 0.65).  The engine's survey of the eight loop placements runs inside
+    a build on the placement cliff of profiles/history/r02_pace.txt O reads 0.65).  The engine's survey of the eight loop placements runs inside
     bench.py's untimed warm-up."""
     import json
     import subprocess

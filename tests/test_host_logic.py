@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib, tmp_path):
     import subprocess
     from gym_craftingworld_amd import _lib
     structs = {'cw_task_menu': _lib.cw_task_menu, 'cw_config': _lib.cw_config, 'cw_buffer_table': _lib.cw_buffer_table,
-               'cw_state_view': _lib.cw_state_view, 'cw_profile': _lib.cw_profile}
+               'cw_state_view': _lib.cw_state_view, 'cw_profile': _lib.cw_profile, 'cw_tuner_state': _lib.cw_tuner_state}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "craftingworld.h"', 'int main(void){']
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))

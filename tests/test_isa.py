@@ -1,5 +1,5 @@
 """CPU tier: what THIS toolchain makes of the HIP kernels -- registers, spills, LDS, and where the full-frame sweep's batch loop
-lies in the gfx950 code object (its placement modulo 32 bytes moves the kernel's launch time by up to 17 %, profiles/r02_pace.txt N-P,
+lies in the gfx950 code object (its placement modulo 32 bytes moves the kernel's launch time by up to 17 %, profiles/history/r02_pace.txt N-P,
 which is why the one-launch step is built at all eight placements and the engine measures which one to run).  The table is committed
 (profiles/r03_isa_resources.txt); a compiler or source change that moves any of it fails here and is visible in review:
 regenerate with `python tools/isa_report.py --write` and re-run the placement table (tools/microbench/specs/r03_placement.spec)."""

@@ -20,7 +20,7 @@ out = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/counters'
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
         if k.startswith('cw_'):
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {k: {c: sorted(v)[len(v) // 2] for c, v in d.items()} for k, d in acc.items()}

@@ -8,13 +8,21 @@ import sys
 from collections import defaultdict
 
 
+def kernel_base(name):
+    """'void cw_render_step_kernel<3>(CwParams, int, ...)' -> 'cw_render_step_kernel' (the eight placements of the sweep loop are one kernel)"""
+    name = name.split('(')[0].strip()
+    if name.startswith('void '):
+        name = name[5:]
+    return name.split('<')[0]
+
+
 def per_kernel(root, counter):
     files = glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)
     acc = defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
             if r.get('Counter_Name') == counter:
-                acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+                acc[kernel_base(r['Kernel_Name'])].append(float(r['Counter_Value']))
     return acc
 
 
