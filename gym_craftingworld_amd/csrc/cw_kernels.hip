@@ -1352,8 +1352,8 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
             // indexed load from a private copy of the argument struct -- scratch memory in the job loop
             auto by_value = [](uint8_t *p) {
                 const unsigned long long v = (unsigned long long)p;
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-                return (uint8_t *)(((unsigned long long)hi << 32) | (unsigned long long)lo);     // (readfirstlane yields an int: widen as unsigned)
+                return (uint8_t *)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                                   (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v));
             };
             uint8_t *const f_obs = by_value(P.obs), *const f_init = by_value(P.init_img), *const f_goal = by_value(P.desired_img);
             for (uint32_t base = 0; base * (uint32_t)n_waves + (uint32_t)wave < n_tail; base += CW_WAVE) {
