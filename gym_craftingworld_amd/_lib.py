@@ -67,7 +67,7 @@ class cw_profile(C.Structure):
 
 class cw_tuner_state(C.Structure):
     _fields_ = [('place', C.c_int32), ('surveys', C.c_int32), ('struck_mask', C.c_int32), ('sleeps_beside', C.c_int32),
-                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32), ('sync_timeouts', C.c_int32)]
+                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)

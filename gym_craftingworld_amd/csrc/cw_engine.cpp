@@ -698,9 +698,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(desired_out, N);
     ALLOC_OUT(episode_length, N);
     ALLOC(done_list, N);
-    ALLOC(done_count, 4);
-    ALLOC(reset_epoch, N);
-    ALLOC(sync_timeouts, 1);
+    ALLOC(done_count, 2);
     ALLOC(counters, 4);
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
@@ -1009,9 +1007,6 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
     out->sleeps_beside = a.on && a.pace_on ? a.cur : (e->tune.render_pace >> 12) & 15;
     out->place_tuned = a.on && a.place_on ? 1 : 0;
     out->sleeps_tuned = a.on && a.pace_on ? 1 : 0;
-    out->sync_timeouts = 0;
-    if (hipMemcpy(&out->sync_timeouts, e->P.sync_timeouts, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)   // (synchronises; off the step path)
-        return fail(CW_ERR_HIP, "cw_tuner: reading the device counter failed");
     return CW_OK;
 }
 
@@ -1308,8 +1303,6 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
         p += sec.bytes;
     }
     e->has_reset = true;
-    // (the restored step counter may run through values this engine has already published resets under: forget them)
-    HIP_TRY(hipMemset(e->P.reset_epoch, 0, (size_t)e->n * sizeof(unsigned long long)));
     if (e->obs_mode != CW_OBS_STATE) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));   // frames follow the records
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;

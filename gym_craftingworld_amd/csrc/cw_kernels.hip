@@ -47,13 +47,6 @@ extern "C" hipError_t cwk_trace_render_read(unsigned long long *dst) { return hi
 #define CW_WAVE_STAMP(wave, k) do { } while (0)
 #endif
 
-// a wave-uniform load through the scalar (constant) cache
-template <typename T>
-__device__ __forceinline__ T cload(const T *p)
-{
-    return *(const __attribute__((address_space(4))) T *)(p);
-}
-
 enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6, HOUSE = 7, WHEAT = 8 };
 // TASK_LIST bit order, ray.py:40-41
 enum { T_MAKEBREAD = 0, T_EATBREAD = 1, T_BUILDHOUSE = 2, T_CHOPTREE = 3, T_CHOPROCK = 4,
@@ -458,7 +451,6 @@ __device__ __forceinline__ void release_done_list(const CwParams &P, int n_block
         if (t == n_blocks - 1) {
             P.done_count[0] = 0;
             P.done_count[1] = 0;
-            P.done_count[2] = 0;
         }
     }
 }
@@ -775,11 +767,8 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
 
 // (bid of n_blocks: the workgroup's index among the resetting workgroups -- the whole grid for cw_reset_kernel, the grid's tail
 // for cw_render_step_kernel)
-// paint: 0 nobody paints here (state-only mode) | 1 the resetting wave paints its env's three frames itself | 2 it PUBLISHES the env instead:
-// records first, then (release) the step's epoch in P.reset_epoch[env] -- the sweep waves of the same launch paint the frames as ordinary
-// paced jobs once they see it (render_groups: tail).  ticket_blocks: how many workgroups draw a ticket on the done list in this launch.
 __device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s_mt)[CW_MT_WORDS], int bid, int n_blocks,
-                                                 int last_reader, int all_envs, int paint, int ticket_blocks = 0)
+                                                 int last_reader, int all_envs, int paint)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
@@ -793,7 +782,6 @@ __device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s
     // nothing finished on this step (most steps): nothing to reset and nothing to release, no ticket either.  Every workgroup reads
     // the same count: the counter only changes when the last of n_blocks tickets has been drawn, i.e. after all of them have read it.
     if (!all_envs && count == 0) return;
-    const unsigned long long epoch = paint == 2 ? cload(P.counters) : 0ull;      // env-steps taken so far: unique to this step (cw_step_kernel adds to it)
     for (int job = wave; job < count; job += n_waves) {
         const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : (job == wave ? first : P.done_list[job]));
         const uint32_t v_hx = P.hdr[env].x, v_hz = P.hdr[env].z;     // in flight beside the MT state
@@ -809,14 +797,10 @@ __device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s
                 P.achieved_out[env] = 0;             // (an auto-reset leaves them at the finished step's values)
                 P.desired_out[env] = (uint16_t)r.desired;
             }
-            if (paint == 2) {                        // every record above is visible before the epoch is
-                __hip_atomic_store(P.reset_epoch + env, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&P.done_count[2], 1);      // (resets completed: the sweep's extra sleeps end when this reaches the count)
-            }
         }
-        if (paint == 1) paint_reset_frames(P, env, r, lane);
+        if (paint) paint_reset_frames(P, env, r, lane);
     }
-    if (!all_envs && last_reader) release_done_list(P, ticket_blocks > 0 ? ticket_blocks : n_blocks);
+    if (!all_envs && last_reader) release_done_list(P, n_blocks);
 }
 
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs, int paint)
@@ -1061,6 +1045,12 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
 // (the scalar loads missed to HBM under the render's own write storm, where a round trip takes ~25 us).
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 
+template <typename T>
+__device__ __forceinline__ T cload(const T *p)
+{
+    return *(const __attribute__((address_space(4))) T *)(p);
+}
+
 struct CwEnvRec {
     u32x4s h, pp;
     uint32_t done_word;
@@ -1212,7 +1202,7 @@ __device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, ui
 // as it does the XCD shares.
 template <int MODE, int PLACE = CW_PLACE_DEFAULT>
 __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                              int bid, int n_blocks, int env_lo, int env_n, int tail_ticket_blocks = 0)
+                                              int bid, int n_blocks, int env_lo, int env_n)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
@@ -1258,11 +1248,7 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         // the done counter rides with every batch's records (a coherent load: the last resetting workgroup zeroes it when the list is
         // done): the extra sleeps apply only to batches fetched while envs were still being reset beside the sweep -- the resets are over
         // after the first 20-40 us of a launch, and slowing the sweep for the rest of it bought nothing
-        r.cnt = 0;
-        if (pace_beside) {                             // envs whose reset is still to come (the one-launch step: count - completed)
-            const int n_done = __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r.cnt = tail_ticket_blocks ? n_done - __hip_atomic_load(P.done_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_done;
-        }
+        r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const int i = base + lane;
         const int id = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
         r.env = -1; r.g = 0; r.hx = 0; r.hw = 0; r.done = 0;
@@ -1279,37 +1265,16 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
         }
         return r;
     };
-    // one job: the group's <= 64 cells, lane = cell; slot positions / codes are wave-uniform
-    auto paint_group = [&](uint8_t *frame, uint32_t g, const u32x4s &pp, uint32_t codes, uint32_t agent_cell, uint32_t hold_rgb) __attribute__((always_inline)) {
-        uint32_t sp[8];
-        unpack_pos_s(pp, sp);
-        const uint32_t row0 = g * gr;
-        const uint32_t cell = row0 * S + (uint32_t)lane;
-        uint32_t code = 0;                                                   // the lane's cell: slot code by 8 compares ...
-#pragma unroll
-        for (int q = 0; q < 8; q++) code = (cell == sp[q]) ? ((codes >> (4 * q)) & 15u) : code;
-        const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);   // ... colour from the table register
-        const u32x3 d = cell_row_dwords(col);
-        const bool ag = (cell == agent_cell);
-        const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;           // ray.py:483
-        const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;              // ray.py:484-486
-        if (lane_in_group && row0 + r_local < (uint32_t)S) {
-            uint8_t *q = frame + (size_t)(4u * row0) * row_bytes + v_off;
-            *(u32x3_a4 *)(q) = d;
-            *(u32x3_a4 *)(q + row_bytes) = d1;
-            if (pace_mid) __builtin_amdgcn_s_sleep(1);                      // (see PACING above)
-            *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
-            *(u32x3_a4 *)(q + 3 * row_bytes) = d;
-        }
-    };
     // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions have
     // read 0.2325 ms at one placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few
     // clocks per job at the loop's branch targets (profiles/history/r02_pace.txt N-P) -- and which placement is the good one moves with every edit
     // of the loop body, with the box, and would move with the compiler (profiles/r03_placement.txt).  So the placement is a TUNED parameter,
     // not a pinned one: the one-launch step is built at all eight placements modulo 32 bytes (PLACE x s_nop after a 32-byte boundary,
     // executed once per wave; cw_render_step_kernel<0..7>) and cw_step measures which one this process should run (cw_engine.cpp: adapt_tick).
-    // (one asm block: nothing can be scheduled between the boundary, the s_nops and the symbol tools/isa_report.py reads the address from)
-    asm volatile(".p2align 5\n\t.rept %0\n\ts_nop 0\n\t.endr\ncw_sweep_head_%=:" ::"i"(PLACE));
+    asm volatile(".p2align 5");
+#pragma unroll
+    for (int z = 0; z < PLACE; z++) asm volatile("s_nop 0");
+    asm volatile("cw_sweep_head_%=:" ::);             // (a local symbol: tools/isa_report.py reads the loop's address off the code object)
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
         const Rec cur = nxt;
@@ -1329,68 +1294,29 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
             pp.y = __builtin_amdgcn_readlane(cur.p.y, k);
             pp.z = __builtin_amdgcn_readlane(cur.p.z, k);
             pp.w = __builtin_amdgcn_readlane(cur.p.w, k);
+            uint32_t sp[8];
+            unpack_pos_s(pp, sp);
+            const uint32_t row0 = g * gr;
+            const uint32_t cell = row0 * S + (uint32_t)lane;
+            uint32_t code = 0;                                               // the lane's cell: slot code by 8 compares ...
+#pragma unroll
+            for (int q = 0; q < 8; q++) code = (cell == sp[q]) ? ((codes >> (4 * q)) & 15u) : code;
+            const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);   // ... colour from the table register
             const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
             const uint32_t hold = (hx >> 16) & 0xFFu;
             const uint32_t hold_rgb = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;
-            paint_group(dst_base + (size_t)env * P.frame_bytes, g, pp, codes, agent_cell, hold_rgb);
-        }
-    }
-    // ---- TAIL (one-launch step): the three frames of every env that is being reset in this launch, as ordinary jobs of the same waves.
-    // The resetting workgroups (first in the grid, so dispatched before any sweep workgroup: a consumer never waits for a producer that
-    // is not running) only compute the new episodes and PUBLISH them (reset_list_block, paint == 2); tail job t = (done-list entry t / 3G,
-    // frame (t / G) % 3 = observation | init_observation | desired_goal, group t % G) goes to wave t % n_waves like every other job.
-    // Round 2 had the resetting wave paint its env's three frames itself: unpaced bursts beside the sweep, and -- what cost more -- a
-    // sweep wave sharing its SIMD with a resetting wave for ~22 us fell ~10 us behind, and a launch lasts as long as its slowest wave
-    // (phases spread out: 0.2435 vs 0.2325 ms per launch).  Spread over all waves the same bytes are ~4 jobs per wave.
-    if (MODE == 3 && tail_ticket_blocks > 0) {
-        const int count = cload(P.done_count);
-        if (count > 0) {
-            __builtin_amdgcn_s_setprio(0);                                   // (a waiting consumer must never starve the producer beside it)
-            const unsigned long long epoch = cload(P.counters);
-            const uint32_t n_tail = (uint32_t)count * 3u * (uint32_t)G;
-            // the three frame arrays as VALUES (through readfirstlane): selecting among the kernel-argument fields themselves becomes an
-            // indexed load from a private copy of the argument struct -- scratch memory in the job loop
-            auto by_value = [](uint8_t *p) {
-                const unsigned long long v = (unsigned long long)p;
-                return (uint8_t *)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
-                                   (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)v));
-            };
-            uint8_t *const f_obs = by_value(P.obs), *const f_init = by_value(P.init_img), *const f_goal = by_value(P.desired_img);
-            for (uint32_t base = 0; base * (uint32_t)n_waves + (uint32_t)wave < n_tail; base += CW_WAVE) {
-                const uint32_t t = (base + (uint32_t)lane) * (uint32_t)n_waves + (uint32_t)wave;
-                const bool mine = t < n_tail;
-                const uint32_t entry = mine ? t / (3u * (uint32_t)G) : 0u, rem = t - entry * 3u * (uint32_t)G;
-                const uint32_t which = rem / (uint32_t)G, g_l = rem - which * (uint32_t)G;
-                const int env_l = P.done_list[entry];
-                // wait until every env of the batch has been published (acquire: the records read below are at least as new)
-                bool ready = !mine;
-                for (int spin = 0; spin < (1 << 22); spin++) {
-                    if (!ready) ready = __hip_atomic_load(P.reset_epoch + env_l, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                    if (CW_BALLOT(!ready) == 0) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (CW_BALLOT(!ready) != 0) {                                // cannot happen (producers run first); never hang, never paint stale records
-                    if (lane == 0) atomicAdd(P.sync_timeouts, 1);
-                    break;
-                }
-                const uint4 v_p = which == 2 ? P.goal_pos[env_l] : P.init_pos[env_l];
-                const uint32_t v_codes = which == 2 ? P.goal_codes[env_l] : (uint32_t)CW_CODES_INITIAL;
-                const uint32_t v_agent = which == 2 ? (uint32_t)P.goal_agent[env_l] : (uint32_t)P.init_agent[env_l];
-                const int in_batch = (int)min((n_tail - wave - base * (uint32_t)n_waves + (uint32_t)n_waves - 1u) / (uint32_t)n_waves, (uint32_t)CW_WAVE);
-                for (int k = 0; k < in_batch; k++) {
-                    if (k & 1) for (int z = 0; z < pace_base; z++) __builtin_amdgcn_s_sleep(1);
-                    u32x4s pp;
-                    pp.x = __builtin_amdgcn_readlane(v_p.x, k);
-                    pp.y = __builtin_amdgcn_readlane(v_p.y, k);
-                    pp.z = __builtin_amdgcn_readlane(v_p.z, k);
-                    pp.w = __builtin_amdgcn_readlane(v_p.w, k);
-                    const uint32_t w_k = __builtin_amdgcn_readlane(which, k);
-                    uint8_t *frames = w_k == 0 ? f_obs : w_k == 1 ? f_init : f_goal;
-                    paint_group(frames + (size_t)__builtin_amdgcn_readlane(env_l, k) * P.frame_bytes, (uint32_t)__builtin_amdgcn_readlane(g_l, k), pp,
-                                (uint32_t)__builtin_amdgcn_readlane(v_codes, k), (uint32_t)__builtin_amdgcn_readlane(v_agent, k), 0x00FFFFFFu);
-                }
+            const u32x3 d = cell_row_dwords(col);
+            const bool ag = (cell == agent_cell);
+            const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
+            const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
+            if (lane_in_group && row0 + r_local < (uint32_t)S) {
+                uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes + v_off;
+                *(u32x3_a4 *)(q) = d;
+                *(u32x3_a4 *)(q + row_bytes) = d1;
+                if (pace_mid) __builtin_amdgcn_s_sleep(1);                // (see PACING above)
+                *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
+                *(u32x3_a4 *)(q + 3 * row_bytes) = d;
             }
-            release_done_list(P, tail_ticket_blocks);                        // (workgroup-wide: every wave of the block comes here, count > 0 for all)
         }
     }
     CW_WAVE_BUSY(P, t_start, bid & 1);
@@ -1411,14 +1337,11 @@ __global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, in
 // fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
 // barrier packets: the render's part runs 3-6 % shorter without them (profiles/history/r02_fused_render.txt).
 template <int PLACE>
-__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int reset_blocks, int pace, int env_lo, int env_n)
+__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    // grid = [reset_blocks resetting workgroups: compute and publish][sweep workgroups: this chunk's frames, then the published envs' frames]
-    // (a launch over a later chunk of a large batch has no resetting workgroups and no tail: they ride on the first chunk's launch)
-    if ((int)blockIdx.x < reset_blocks) reset_list_block(P, s_mt, (int)blockIdx.x, reset_blocks, 1, 0, 2, (int)gridDim.x);
-    else render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x - reset_blocks, (int)gridDim.x - reset_blocks, env_lo, env_n,
-                                 reset_blocks > 0 ? (int)gridDim.x : 0);
+    if ((int)blockIdx.x < render_blocks) render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks, env_lo, env_n);
+    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
 // the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
 __global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
@@ -1733,7 +1656,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
             const int n_chunks = cw_sweep_chunks(*P, tn, &per);
             for (int c = 0; c < n_chunks; c++)
                 hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
-                                   c == 0 ? reset_blocks : 0, tn.render_pace, c * per, min(per, n - c * per));
+                                   render_blocks, tn.render_pace, c * per, min(per, n - c * per));
         }
         else
             hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,

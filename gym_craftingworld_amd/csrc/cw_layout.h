@@ -89,11 +89,9 @@ struct CwParams {
     uint8_t *desired_img;
     uint8_t *init_img;
     uint8_t *terminal_img;   // or null
-    // done-list compaction (cw_kernels.hip)
+    // done-list compaction: done_count[0] = entries, [1] = release ticket (cw_kernels.hip)
     int32_t *done_list;      // [N]
-    int32_t *done_count;     // [4]: entries | release ticket | resets completed (one-launch full-frame step) | -
-    unsigned long long *reset_epoch;    // [N] one-launch full-frame step: counters[0] of the step whose reset of the env has been published (cw_kernels.hip: render_groups, tail)
-    int32_t *sync_timeouts;  // [1] tail batches given up on (must stay 0)
+    int32_t *done_count;     // [2]
     unsigned long long *render_stats;   // [2] calibration only (else null): busy time of even / odd render workgroups' waves
     unsigned long long *counters; // [4]
     const CwMenuDev *menus;

@@ -238,10 +238,9 @@ const char *cw_render_kernel_name(const cw_engine *e);
 /* What cw_step's online tuner currently holds (full-frame mode, one-launch step): the placement k of the sweep's batch loop
  * it launches (the kernel a trace lists as cw_render_step_kernel<k>), how many placement surveys it has run, the placements it struck
  * off (bit k), the extra sleeps per pair of jobs beside resets, and whether each of the two is tuned (1) or forced / off (0).
- * Only performance depends on any of it.  A host call that waits for the device (it reads one device counter). */
+ * Only performance depends on any of it. */
 typedef struct cw_tuner_state {
     int32_t place, surveys, struck_mask, sleeps_beside, place_tuned, sleeps_tuned;
-    int32_t sync_timeouts;   /* batches of reset envs' frames a sweep wave gave up waiting for (one-launch step; must be 0: reading it synchronises) */
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 

@@ -19,8 +19,7 @@ def _report():
 def test_resource_table_and_sweep_loop_placements_match_the_committed_record():
     mod, text = _report()
     rows = {l.split()[0]: l.split() for l in text.splitlines() if l and not l.startswith('#') and not l.startswith('kernel')}
-    # the one-launch step exists at every placement of its batch loop modulo 32 bytes, one s_nop (4 bytes) apart (variant k: a 32-byte
-    # boundary + k x s_nop, then the loop's prologue and the loop: whatever the prologue's length, the eight cover all eight residues)
+    # the one-launch step exists at every placement of its batch loop modulo 32 bytes, one s_nop (4 bytes) apart
     for k in range(8):
         assert rows['cw_render_step_kernel<%d>' % k][-1] == str(4 * k), rows['cw_render_step_kernel<%d>' % k]
     # ... and they are the same kernel otherwise (registers, spills, LDS)
