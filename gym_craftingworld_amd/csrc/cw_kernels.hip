@@ -1271,10 +1271,8 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     // of the loop body, with the box, and would move with the compiler (profiles/r03_placement.txt).  So the placement is a TUNED parameter,
     // not a pinned one: the one-launch step is built at all eight placements modulo 32 bytes (PLACE x s_nop after a 32-byte boundary,
     // executed once per wave; cw_render_step_kernel<0..7>) and cw_step measures which one this process should run (cw_engine.cpp: adapt_tick).
-    asm volatile(".p2align 5");
-#pragma unroll
-    for (int z = 0; z < PLACE; z++) asm volatile("s_nop 0");
-    asm volatile("cw_sweep_head_%=:" ::);             // (a local symbol: tools/isa_report.py reads the loop's address off the code object)
+    // (one asm block: nothing can be scheduled between the boundary, the s_nops and the symbol tools/isa_report.py reads the address from)
+    asm volatile(".p2align 5\n\t.rept %0\n\ts_nop 0\n\t.endr\ncw_sweep_head_%=:" ::"i"(PLACE));
     Rec nxt = fetch(0);
     for (int base = 0; base < q_mine; base += CW_WAVE) {
         const Rec cur = nxt;
