@@ -21,6 +21,8 @@ int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
+hipError_t cwk_launch_resident(const CwParams *P, CwResident *R, uint32_t seq0, int paint_dirty, unsigned long long idle_ticks,
+                               unsigned long long life_ticks, hipStream_t st);
 hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, int n_states, uint16_t *out, hipStream_t st);
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
@@ -32,6 +34,8 @@ int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset)
 hipError_t cwk_launch_idle(hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
+
+#include <time.h>
 
 static thread_local char g_err[512] = "";
 
@@ -80,6 +84,11 @@ struct cw_engine {
     std::vector<CwMenuDev> menus;
     uint32_t *seed_scratch = nullptr;  // [N] device: seeds of cw_seed_int
     int n = 0, S = 0, ncell = 0, K = 0;
+    // resident stepper of the single-env loop (cw_step_resident; cw_kernels.hip: cw_resident_kernel)
+    CwResident *res = nullptr;         // pinned coherent host memory, or null (engine not eligible)
+    hipStream_t res_stream = nullptr;
+    bool res_running = false;          // a cw_resident_kernel may be on the card
+    uint32_t res_seq = 0;              // last sequence number rung
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
     hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -113,6 +122,20 @@ struct cw_engine {
     } adapt;
 };
 enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24 };
+
+// ------------------------------------------------------------------------------ resident stepper (host side)
+// Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
+static int resident_park(cw_engine *e)
+{
+    if (!e->res_running) return CW_OK;
+    __atomic_store_n(&e->res->stop, 1u, __ATOMIC_RELEASE);
+    HIP_TRY(hipStreamSynchronize(e->res_stream));        // the kernel leaves within one poll of seeing the flag
+    e->res_running = false;
+    __atomic_store_n(&e->res->stop, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&e->res->exited, 0u, __ATOMIC_RELEASE);
+    return CW_OK;
+}
+#define PARK(e) do { if ((e)->res_running) { const int _rc = resident_park(e); if (_rc != CW_OK) return _rc; } } while (0)
 
 // ------------------------------------------------------------------------------ MT19937 (host)
 // numpy RandomState (key, pos)  <->  the engine's consume-and-replace form (cw_mt.h).
@@ -217,7 +240,7 @@ static int host_alloc(cw_engine *e, T **out, size_t count)
     void *p = nullptr, *d = nullptr;
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = 16;
-    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocCoherent));       // (fine-grained: a resident kernel's stores must reach the host while it runs)
     e->host_allocs.push_back(p);
     memset(p, 0, bytes);
     HIP_TRY(hipHostGetDevicePointer(&d, p, 0));
@@ -737,6 +760,18 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         delete e;
         return rc;
     }
+    if (cfg->host_outputs && e->n == 1 && !e->auto_reset && e->obs_mode != CW_OBS_PIXELS_FULL) {     // the single-env loop: resident stepper
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(CwResident), hipHostMallocCoherent) == hipSuccess &&
+            hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking) == hipSuccess) {
+            memset(p, 0, sizeof(CwResident));
+            e->host_allocs.push_back(p);
+            e->res = (CwResident *)p;
+        } else {
+            if (p) (void)hipHostFree(p);
+            e->res_stream = nullptr;                 // (no resident stepper: cw_step_resident reports it)
+        }
+    }
     *out = e;
     // default stream: env i seeded like numpy RandomState(i); callers normally reseed
     std::vector<uint32_t> seeds(N);
@@ -772,8 +807,11 @@ int cw_destroy(cw_engine *e)
     if (!e) return CW_OK;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
+    (void)resident_park(e);
     (void)hipDeviceSynchronize();
     prof_free(e);
+    if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
@@ -791,6 +829,7 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_seed_mt: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     const size_t N = (size_t)e->n;
     for (size_t i = 0; i < N; i++)
         if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
@@ -807,6 +846,7 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     if (!e || !seeds) return fail(CW_ERR_INVALID, "cw_seed_int: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, nullptr));
@@ -819,6 +859,7 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     if (!e || !keys || !pos) return fail(CW_ERR_INVALID, "cw_get_mt: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
     HIP_TRY(hipDeviceSynchronize());
@@ -834,6 +875,7 @@ int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
     if (e->K == 0) return CW_OK;
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_pool(&e->P, &e->tune, (hipStream_t)stream));
     // one-time, off the hot path: the pool and the advanced RNG streams are complete before any other stream can reset from them
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -845,6 +887,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
     if (!e) return fail(CW_ERR_INVALID, "cw_reset: null engine");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     e->has_reset = true;
     return CW_OK;
@@ -857,6 +900,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     if (e->adapt.on) {                               // full-frame mode: the sweep's extra sleeps beside resets follow what the steps measure (adapt_tick)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -878,6 +922,60 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     return CW_OK;
 }
 
+// One step of the single-env loop WITHOUT a kernel launch: ring the resident kernel's doorbell, spin on its answer (cw_kernels.hip:
+// cw_resident_kernel).  The kernel is (re)launched on demand -- the first call, after it idled out (2 ms without a request), after its
+// time slice (200 ms), after any other entry point parked it -- and a request that raced with its exit is served by the next instance:
+// `ack` says which sequence number was served last, and a new instance starts from there.
+int cw_step_resident(cw_engine *e, int32_t action)
+{
+    if (!e) return fail(CW_ERR_INVALID, "cw_step_resident: null engine");
+    if (!e->res) return fail(CW_ERR_INVALID, "cw_step_resident needs num_envs == 1, host_outputs, auto_reset == 0 and obs_mode state or pixels_dirty");
+    if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step_resident called before cw_reset");
+    if (action < 0 || action > 255) return fail(CW_ERR_INVALID, "cw_step_resident: action %d outside 0..255", action);
+    CwResident *R = e->res;
+    const uint32_t seq = (++e->res_seq) & 0xFFFFFFu;
+    __atomic_store_n(&R->doorbell, (seq << 8) | (uint32_t)action, __ATOMIC_RELEASE);
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; spins++) {
+        if (e->res_running && __atomic_load_n(&R->ack, __ATOMIC_ACQUIRE) == seq) return CW_OK;
+        if (!e->res_running || __atomic_load_n(&R->exited, __ATOMIC_ACQUIRE) != 0) {
+            // no kernel on the card, or it has left (idle, time slice): wait for it to be gone, then start one that continues after `ack`
+            DeviceGuard guard(e->device);
+            if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+            if (e->res_running) HIP_TRY(hipStreamSynchronize(e->res_stream));
+            e->res_running = false;
+            if (__atomic_load_n(&R->ack, __ATOMIC_ACQUIRE) == seq) {            // it answered on its way out
+                __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
+                return CW_OK;
+            }
+            __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
+            __atomic_store_n(&R->ack, (seq - 1u) & 0xFFFFFFu, __ATOMIC_RELEASE);
+            HIP_TRY(cwk_launch_resident(&e->P, R, (seq - 1u) & 0xFFFFFFu, e->obs_mode == CW_OBS_PIXELS_DIRTY ? 1 : 0,
+                                        200000ull /* 2 ms idle */, 20000000ull /* 200 ms slice */, e->res_stream));
+            e->res_running = true;
+            continue;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) {
+                (void)resident_park(e);
+                return fail(CW_ERR_HIP, "cw_step_resident: no answer from the resident kernel within 5 s (parked)");
+            }
+        }
+    }
+}
+
+int cw_resident_stop(cw_engine *e)
+{
+    if (!e) return fail(CW_ERR_INVALID, "cw_resident_stop: null engine");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    return resident_park(e);
+}
+
 int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *rewards, uint8_t *dones, cw_stream_t stream)
 {
     if (!e || !actions) return fail(CW_ERR_INVALID, "cw_rollout: null argument");
@@ -887,6 +985,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_rollout called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
@@ -897,6 +996,7 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_render called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
@@ -907,6 +1007,7 @@ int cw_render_onehot(cw_engine *e, const uint8_t *onehot, int32_t n_states, uint
     if (n_states < 1) return fail(CW_ERR_INVALID, "cw_render_onehot: n_states must be >= 1");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_render_onehot(&e->P, onehot, n_states, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
@@ -916,6 +1017,7 @@ int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_grid: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 0, 0, (hipStream_t)stream));
     return CW_OK;
 }
@@ -925,6 +1027,7 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_export_onehot: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, 0, (hipStream_t)stream));
     return CW_OK;
 }
@@ -936,6 +1039,7 @@ int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t strea
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_export_onehot_of called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, which, (hipStream_t)stream));
     return CW_OK;
 }
@@ -945,6 +1049,7 @@ int cw_profile_begin(cw_engine *e, int max_steps)
     if (!e || max_steps < 1 || max_steps > 100000) return fail(CW_ERR_INVALID, "cw_profile_begin: bad argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     prof_free(e);
     e->prof_ev.resize((size_t)max_steps * 6);
     for (auto &ev : e->prof_ev) HIP_TRY(hipEventCreate(&ev));
@@ -957,6 +1062,7 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_profile_end: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
@@ -1036,6 +1142,7 @@ int cw_synchronize(cw_engine *e, cw_stream_t stream)
     if (!e) return fail(CW_ERR_INVALID, "cw_synchronize: null engine");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return CW_OK;
 }
@@ -1053,6 +1160,7 @@ int cw_get_state(cw_engine *e, cw_state_view *v)
     if (!e || !v) return fail(CW_ERR_INVALID, "cw_get_state: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     const size_t N = (size_t)e->n;
     const int S = e->S, nc = e->ncell;
     std::vector<uint32_t> hdr(N * 4), goal_codes(N);
@@ -1090,6 +1198,7 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_set_state called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     const size_t N = (size_t)e->n;
     const int S = e->S, nc = e->ncell;
     std::vector<uint32_t> hdr(N * 4);
@@ -1262,6 +1371,7 @@ int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity)
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_checkpoint_save called before cw_reset");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     const CwCkptHeader h = ckpt_header(e);
     if (capacity < h.total_bytes) return fail(CW_ERR_INVALID, "cw_checkpoint_save: buffer of %zu bytes, %llu needed", capacity, (unsigned long long)h.total_bytes);
     HIP_TRY(hipDeviceSynchronize());
@@ -1280,6 +1390,7 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (!e || !buf) return fail(CW_ERR_INVALID, "cw_checkpoint_load: null argument");
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
     CwCkptHeader h;
     if (length < sizeof(h)) return fail(CW_ERR_INVALID, "cw_checkpoint_load: %zu bytes is not a checkpoint", length);
     memcpy(&h, buf, sizeof(h));

@@ -880,6 +880,77 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
     }
 }
 
+// The RESIDENT stepper of the single-env loop (N == 1, host-mapped outputs, no auto-reset; state-only or dirty-cell frames): ONE wavefront
+// that stays on the card for a bounded time slice and turns `step()` from "launch a kernel, wait for the stream" (~17 us, the reference's own
+// step time) into "store a doorbell word, spin on an answer word".  It polls a word in pinned coherent host memory (system-scope acquire
+// loads: one PCIe read each), and for every new sequence number runs the same step_env / render_edit as cw_step_kernel on the env's state,
+// which it keeps in registers and writes back every step (so the records in device memory are current whenever it has answered), writes
+// the step outputs and the <= 2 repainted cells straight into the host-mapped buffers, and releases the answer word.  It LEAVES -- every
+// path of the loop reaches one of these within one poll -- when the host raises `stop`, when no request has come for `idle_ticks`, or when
+// its time slice `life_ticks` is used up (100 MHz ticks); the host side relaunches it on demand and re-serves a request that raced with an exit
+// (cw_engine.cpp: cw_step_resident).  A process that dies leaves a kernel that idles out within `idle_ticks`.
+__global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResident *R, uint32_t seq0, int paint_dirty,
+                                                              unsigned long long idle_ticks, unsigned long long life_ticks)
+{
+    const int lane = threadIdx.x;
+    uint4 h = P.hdr[0];
+    uint32_t sp[8];
+    unpack_pos(P.pos[0], sp);
+    const uint4 ip = P.init_pos[0];
+    uint32_t last = seq0;
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_last = t_start;
+    uint32_t reason = 0;
+    for (;;) {
+        const uint32_t d = __hip_atomic_load(&R->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t seq = d >> 8;
+        if (seq != last) {
+            if (lane == 0) {
+                const int a = (int)(d & 0xFFu);
+                const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
+                P.hdr[0] = h;
+                P.pos[0] = pack_pos(sp);
+                P.reward[0] = o.reward;
+                P.done[0] = o.done ? 1 : 0;
+                P.achieved_out[0] = (uint16_t)o.achieved;
+                P.desired_out[0] = (uint16_t)o.desired;
+                if (o.done) P.episode_length[0] = (int32_t)o.step_num;
+                if (paint_dirty && o.changed) {                                  // render_edit, ray.py:522-557 (as in cw_step_kernel)
+                    uint8_t *frame = P.obs;
+                    const uint32_t hold = (h.x >> 16) & 0xFFu;
+                    const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+                    if (P.raster == 1) {
+                        const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
+                        alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
+                        if (o.dirty1 != 0xFFFFFFFFu) {
+                            const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
+                            alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
+                        }
+                        alt_paint_strip(frame, P.size, hold, 0, 1, false);
+                    } else {
+                        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+                        if (o.dirty1 != 0xFFFFFFFFu)
+                            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+                    }
+                }
+                atomicAdd(&P.counters[0], 1ull);
+                if (o.done) atomicAdd(&P.counters[1], 1ull);
+                if (o.success) atomicAdd(&P.counters[2], 1ull);
+                if (o.invalid) atomicAdd(&P.counters[3], 1ull);
+                __hip_atomic_store(&R->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // everything above is visible to the host first
+            }
+            last = seq;
+            t_last = wall_clock64();
+            continue;
+        }
+        const unsigned long long now = wall_clock64();
+        if (__hip_atomic_load(&R->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { reason = 1; break; }
+        if (now - t_last > idle_ticks) { reason = 2; break; }
+        if (now - t_start > life_ticks) { reason = 3; break; }
+    }
+    if (lane == 0) __hip_atomic_store(&R->exited, reason | (last << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One cw_step with auto-reset as a SINGLE launch (state-only and dirty-cell pixel modes): a wavefront owns `epw`
 // consecutive envs (8..64, one per lane), steps them, and resets the ones that finished itself, one after the
 // other with all 64 lanes (reset_env_wave) -- painting their frames in the pixel mode.  No done list, no second
@@ -1720,6 +1791,13 @@ hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, in
     if (blocks < 1) blocks = 1;
     if (P->raster == 1) hipLaunchKernelGGL(cw_render_onehot_alt_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
     else hipLaunchKernelGGL(cw_render_onehot_kernel, dim3(blocks), dim3(256), 0, st, onehot, n_states, P->size, P->div_magic, out);
+    return hipGetLastError();
+}
+
+hipError_t cwk_launch_resident(const CwParams *P, CwResident *R, uint32_t seq0, int paint_dirty, unsigned long long idle_ticks,
+                               unsigned long long life_ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(cw_resident_kernel, dim3(1), dim3(CW_WAVE), 0, st, *P, R, seq0, paint_dirty, idle_ticks, life_ticks);
     return hipGetLastError();
 }
 

@@ -63,6 +63,17 @@ struct CwTuning {
                                     // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x2100; cw_step tunes bits 12-15)
 };
 
+// Control block of the RESIDENT stepper (cw_step_resident: the single-env loop, a step without a kernel launch): pinned, coherent host memory
+// the device polls.  One 128-byte line per direction so that the host's doorbell stores and the device's answers never share a line.
+struct CwResident {
+    uint32_t doorbell;       // host -> device: (seq << 8) | action, seq = 1, 2, ... (a new seq is a new step request)
+    uint32_t stop;           // host -> device: 1 = leave now (cw_resident_stop and every entry point that touches the engine's state)
+    uint32_t pad0[30];
+    uint32_t ack;            // device -> host: the last seq whose outputs (reward, done, masks, repainted cells, state) are visible
+    uint32_t exited;         // device -> host: 0 while resident; else reason (1 stop, 2 idle, 3 time slice used up) | last seq served << 8
+    uint32_t pad1[30];
+};
+
 // Everything the kernels need, passed by value.
 struct CwParams {
     // per-env state (SoA of 16-byte records unless noted)

@@ -33,7 +33,7 @@ class CraftingWorldEnv:
 
     def __init__(self, size=None, fixed_init_state=0, max_steps=None, store_gif=False, render_save_rate=1,
                  task_list=TASK_LIST, selected_tasks=TASK_LIST, number_of_tasks=None, stacking=True,
-                 reward_style=None, device=None, reference_dtypes=False, seed=None):
+                 reward_style=None, device=None, reference_dtypes=False, seed=None, resident=None):
         size = self._default_size if size is None else size
         max_steps = self._default_max_steps if max_steps is None else max_steps
         self._vec = CraftingWorldVecEnv(1, size=size, fixed_init_state=fixed_init_state, max_steps=max_steps,
@@ -75,6 +75,10 @@ class CraftingWorldEnv:
         self._lib, self._eng, self._stream = v._lib, v._h, v._stream()
         self._act = v._host_actions
         self._act_p = C.c_void_p(self._act.ctypes.data)
+        # step() without a kernel launch: a resident single-wave kernel polls a doorbell in pinned host memory (cw_step_resident; it leaves by
+        # itself after 2 ms without a request and is parked by every other call).  resident=False (or CW_RESIDENT=0) keeps "launch + stream sync".
+        import os
+        self._resident = (os.environ.get('CW_RESIDENT', '1') != '0') if resident is None else bool(resident)
         self.store_gif, self.render_save_rate = False, render_save_rate            # ray.py:135-136
         self._gif_frames = None
         if store_gif:                                                              # ray.py:142-143
@@ -196,11 +200,14 @@ class CraftingWorldEnv:
         a = int(action)
         if not 0 <= a < len(self.ACTIONS):
             raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
-        self._act[0] = a
-        rc = self._lib.cw_step(self._eng, self._act_p, 0, self._stream)            # 0 = CW_ACT_I32
-        self._after_step_enqueue()
-        if rc == 0:
-            rc = self._lib.cw_synchronize(self._eng, self._stream)
+        if self._resident:
+            rc = self._lib.cw_step_resident(self._eng, a)                          # doorbell + spin: no launch, no stream sync
+        else:
+            self._act[0] = a
+            rc = self._lib.cw_step(self._eng, self._act_p, 0, self._stream)        # 0 = CW_ACT_I32
+            self._after_step_enqueue()
+            if rc == 0:
+                rc = self._lib.cw_synchronize(self._eng, self._stream)
         if rc != 0:
             from . import _lib as L
             L.check(rc, 'cw_step')
@@ -287,6 +294,7 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
+        self._resident = False                      # (every step is followed by the one-hot export kernel: the launch path)
         S = self.STATE_W
         oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=int)  # noqa: E731
         self.observation_space = Dict(dict(observation=oh(), desired_goal=oh(), achieved_goal=oh(),

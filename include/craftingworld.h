@@ -174,6 +174,16 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
 int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *rewards, uint8_t *dones,
                cw_stream_t stream);
 
+/* step(action) of the SINGLE-ENV loop without a kernel launch (ray.py:301-378 called from host code, docs/source/envs/gen_info.rst:62-82).
+ * For engines with num_envs == 1, host_outputs, auto_reset == 0 and obs_mode CW_OBS_STATE or CW_OBS_PIXELS_DIRTY: a resident
+ * single-wavefront kernel polls a doorbell word in pinned host memory; this call rings it and spins until the step's outputs (reward, done,
+ * masks, the <= 2 repainted cells of the host-mapped frame) are visible -- a few microseconds instead of a launch plus a stream
+ * synchronisation.  Results are those of cw_step with the same action.  The kernel is started on demand and leaves by itself: after 2 ms
+ * without a request, after a 200-ms time slice, or when any other entry point of this engine is called (they park it first; cw_resident_stop
+ * does only that).  Synchronous; do not mix with cw_step on a stream that has work pending for this engine. */
+int cw_step_resident(cw_engine *e, int32_t action);
+int cw_resident_stop(cw_engine *e);
+
 /* render(state=None) for every env into a caller-supplied DEVICE buffer [N][P][P][3] (works in
  * every obs_mode; ray.py:442-520). */
 int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);

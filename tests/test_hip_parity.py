@@ -1369,6 +1369,54 @@ def test_altobs_facade_render_of_a_supplied_state():
     env.close(); other.close()
 
 
+@pytest.mark.parametrize('cls_name,kw', [('CraftingWorldEnv', dict(size=(7, 7), max_steps=40)), ('CraftingWorldEnv', dict()),
+                                         ('CraftingWorldEnvFlat', dict()), ('CraftingWorldEnvAltObs', dict(size=(6, 6), max_steps=30)),
+                                         ('CraftingWorldEnv', dict(size=(5, 5), max_steps=25, reference_dtypes=True))])
+def test_resident_stepper_equals_the_launch_path(cls_name, kw):
+    """step() of the N=1 classes rings a resident kernel's doorbell instead of launching a kernel (cw_step_resident): same observations,
+    rewards, dones, masks, state, counters and random streams as the launch + stream-sync path (resident=False), step for step over many
+    episodes -- with the kernel idling out between steps (a 5-ms pause: it leaves after 2 ms and is started again), parked by other calls
+    in mid-episode (render(), obs_one_hot, the RNG state) and by every reset()."""
+    import time
+    import gym_craftingworld_amd as cw
+    cls = getattr(cw, cls_name)
+    a_env, b_env = cls(resident=True, **kw), cls(resident=False, **kw)
+    assert a_env._resident and not b_env._resident
+    for e in (a_env, b_env):
+        e.seed(123)
+    rng = np.random.RandomState(2)
+
+    def same(x, y):
+        if isinstance(x, dict):
+            return all(np.array_equal(x[k], y[k]) for k in x)
+        return np.array_equal(x, y)
+
+    assert same(a_env.reset(), b_env.reset())
+    episodes = 0
+    for t in range(900):
+        a = int(rng.randint(6))
+        oa, ra, da, ia = a_env.step(a)
+        ob, rb, db, ib = b_env.step(a)
+        assert ra == rb and da == db and same(oa, ob), t
+        assert np.array_equal(ia['achieved_goal'], ib['achieved_goal']) and np.array_equal(ia['desired_goal'], ib['desired_goal']), t
+        if t % 97 == 5:
+            time.sleep(0.005)                                    # the resident kernel idles out (2 ms) and is started again by the next step
+        if t % 131 == 7:                                         # other entry points park it in mid-episode
+            assert np.array_equal(a_env.render(), b_env.render()) and np.array_equal(a_env.obs_one_hot, b_env.obs_one_hot)
+            assert a_env.agent_pos == b_env.agent_pos
+        if da:
+            episodes += 1
+            ka, pa = a_env.get_rng_state()
+            kb, pb = b_env.get_rng_state()
+            assert pa == pb and np.array_equal(ka[1:], kb[1:])
+            assert same(a_env.reset(), b_env.reset())
+    assert episodes >= 3
+    assert torch.equal(a_env._vec.counters, b_env._vec.counters) and torch.equal(a_env._vec.hdr, b_env._vec.hdr)
+    with pytest.raises(IndexError):
+        a_env.step(6)
+    a_env.close(); b_env.close()
+
+
 def test_facade_store_gif_files_and_rng_draw(tmp_path, monkeypatch):
     """store_gif=True on the single-env class (ray.py:142-143,160-167,205-216,370-374,769-782): the env id is one
     randint(0, 1000000) taken from the env's own stream at construction (so later placements shift exactly as the
