@@ -49,7 +49,7 @@ class cw_buffer_table(C.Structure):
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('achieved', C.c_void_p),
                 ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('hdr', C.c_void_p),
                 ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t),
-                ('host_actions', C.c_void_p)]
+                ('host_actions', C.c_void_p), ('host_onehot', C.c_void_p)]
 
 
 class cw_state_view(C.Structure):

@@ -767,6 +767,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
             memset(p, 0, sizeof(CwResident));
             e->host_allocs.push_back(p);
             e->res = (CwResident *)p;
+            if (host_alloc(e, &e->P.res_onehot, (size_t)e->ncell * 12) != CW_OK) e->P.res_onehot = nullptr;
         } else {
             if (p) (void)hipHostFree(p);
             e->res_stream = nullptr;                 // (no resident stepper: cw_step_resident reports it)
@@ -1134,6 +1135,7 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out)
     out->counters = (uint64_t *)P.counters;
     out->frame_bytes = P.frame_bytes;
     out->host_actions = e->host_actions;
+    out->host_onehot = P.res_onehot;
     return CW_OK;
 }
 

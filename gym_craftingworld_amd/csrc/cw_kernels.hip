@@ -937,8 +937,26 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
                 if (o.done) atomicAdd(&P.counters[1], 1ull);
                 if (o.success) atomicAdd(&P.counters[2], 1ull);
                 if (o.invalid) atomicAdd(&P.counters[3], 1ull);
-                __hip_atomic_store(&R->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);       // everything above is visible to the host first
             }
+            if (P.res_onehot) {                                                  // CraftingWorldEnvOneHot: obs_one_hot itself is the observation
+                const uint32_t hx = __builtin_amdgcn_readlane(h.x, 0), codes = __builtin_amdgcn_readlane(h.w, 0);   // (onehot.py:369-371)
+                uint32_t bp[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) bp[k] = __builtin_amdgcn_readlane(sp[k], 0);
+                const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu), hold = (hx >> 16) & 0xFFu;
+                for (int cell = lane; cell < P.ncell; cell += CW_WAVE) {
+                    const uint32_t code = code_of(codes, slot_at(bp, (uint32_t)cell));
+                    uint32_t bits = code ? (1u << (code - 1)) : 0u;
+                    if ((uint32_t)cell == agent_cell) bits |= (1u << 8) | (hold ? (1u << (8 + hold)) : 0u);
+                    u32x3 dd;
+                    dd.x = (bits & 1u) | ((bits >> 1 & 1u) << 8) | ((bits >> 2 & 1u) << 16) | ((bits >> 3 & 1u) << 24);
+                    dd.y = (bits >> 4 & 1u) | ((bits >> 5 & 1u) << 8) | ((bits >> 6 & 1u) << 16) | ((bits >> 7 & 1u) << 24);
+                    dd.z = (bits >> 8 & 1u) | ((bits >> 9 & 1u) << 8) | ((bits >> 10 & 1u) << 16) | ((bits >> 11 & 1u) << 24);
+                    *(u32x3_a4 *)(P.res_onehot + 12 * cell) = dd;
+                }
+            }
+            __threadfence_system();                                              // every lane's stores, then (lane 0) the answer
+            if (lane == 0) __hip_atomic_store(&R->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             last = seq;
             t_last = wall_clock64();
             continue;

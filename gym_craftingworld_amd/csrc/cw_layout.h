@@ -117,6 +117,7 @@ struct CwParams {
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
     int32_t tune_reset_prio; // s_setprio 3 for: 2 the render waves and the resets inlined in the fused / rollout kernels (default), 1 every resetting wave, 0 nobody
+    uint8_t *res_onehot;     // resident stepper only (else null): host-mapped [S][S][12] one-hot state, rewritten after every resident step
     int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
     int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
     int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)

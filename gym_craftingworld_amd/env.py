@@ -294,7 +294,9 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
-        self._resident = False                      # (every step is followed by the one-hot export kernel: the launch path)
+        # resident steps leave obs_one_hot in the engine's pinned host buffer (cw_buffer_table.host_onehot); the launch path exports it
+        # with a kernel of its own after every step
+        self._resident = self._resident and self._vec._host_onehot is not None
         S = self.STATE_W
         oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=int)  # noqa: E731
         self.observation_space = Dict(dict(observation=oh(), desired_goal=oh(), achieved_goal=oh(),
@@ -325,7 +327,7 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def step(self, action):
         _, r, d, info = super().step(action)
-        self._oh[...] = self._oh_pin_np
+        self._oh[...] = self._vec._host_onehot if self._resident else self._oh_pin_np
         return self._oh_dict(), r, d, info
 
 

@@ -169,6 +169,7 @@ class CraftingWorldVecEnv:
         dv = lambda p, shape, dt: tensor_view(p, shape, dt, di)  # noqa: E731
         v = (lambda p, shape, dt: _host_view(p, shape, dt)) if self.host_outputs else dv  # noqa: E731
         self._host_actions = _host_view(tab.host_actions, (N,), torch.int32).numpy() if self.host_outputs else None
+        self._host_onehot = _host_view(tab.host_onehot, (self.size, self.size, 12), torch.uint8).numpy() if (self.host_outputs and tab.host_onehot) else None
         self._obs = v(tab.obs, fs, torch.uint8)
         self._desired_img = v(tab.desired_goal, fs, torch.uint8)
         self._init_img = v(tab.init_obs, fs, torch.uint8)

@@ -116,6 +116,8 @@ typedef struct cw_buffer_table {
     uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
     size_t frame_bytes;      /* P*P*3 (CW_RASTER_RAY) or (3S+3)*3S*3 (CW_RASTER_ALT) */
     int32_t *host_actions;   /* [N]  cw_config.host_outputs only (else NULL): mapped host buffer usable as cw_step's actions (CW_ACT_I32) */
+    uint8_t *host_onehot;    /* [S][S][12] engines that can run cw_step_resident only (else NULL): obs_one_hot (ray.py:119) of the env in pinned host
+                              * memory, rewritten by every cw_step_resident (CraftingWorldEnvOneHot returns it as the observation, onehot.py:369-371) */
 } cw_buffer_table;
 
 /* Host-side dense snapshot for parity injection / checkpointing (cw_get_state, cw_set_state).

@@ -1371,7 +1371,8 @@ def test_altobs_facade_render_of_a_supplied_state():
 
 @pytest.mark.parametrize('cls_name,kw', [('CraftingWorldEnv', dict(size=(7, 7), max_steps=40)), ('CraftingWorldEnv', dict()),
                                          ('CraftingWorldEnvFlat', dict()), ('CraftingWorldEnvAltObs', dict(size=(6, 6), max_steps=30)),
-                                         ('CraftingWorldEnv', dict(size=(5, 5), max_steps=25, reference_dtypes=True))])
+                                         ('CraftingWorldEnv', dict(size=(5, 5), max_steps=25, reference_dtypes=True)),
+                                         ('CraftingWorldEnvOneHot', dict(size=(6, 6), max_steps=30)), ('CraftingWorldEnvOneHot', dict())])
 def test_resident_stepper_equals_the_launch_path(cls_name, kw):
     """step() of the N=1 classes rings a resident kernel's doorbell instead of launching a kernel (cw_step_resident): same observations,
     rewards, dones, masks, state, counters and random streams as the launch + stream-sync path (resident=False), step for step over many
