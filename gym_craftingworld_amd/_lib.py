@@ -95,7 +95,7 @@ ABI = {
     'cw_profile_begin': (C.c_int, [_VP, C.c_int]),
     'cw_profile_end': (C.c_int, [_VP, C.POINTER(cw_profile)]),
     'cw_tuner': (C.c_int, [_VP, C.POINTER(cw_tuner_state)]),
-    'cw_step_resident': (C.c_int, [_VP, C.c_int32]),
+    'cw_step_resident': (C.c_int, [_VP, C.c_int32, C.c_int32]),
     'cw_resident_stop': (C.c_int, [_VP]),
     'cw_render_kernel_name': (C.c_char_p, [_VP]),
     'cw_buffers': (C.c_int, [_VP, C.POINTER(cw_buffer_table)]),

@@ -927,15 +927,16 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
 // cw_resident_kernel).  The kernel is (re)launched on demand -- the first call, after it idled out (2 ms without a request), after its
 // time slice (200 ms), after any other entry point parked it -- and a request that raced with its exit is served by the next instance:
 // `ack` says which sequence number was served last, and a new instance starts from there.
-int cw_step_resident(cw_engine *e, int32_t action)
+int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
 {
     if (!e) return fail(CW_ERR_INVALID, "cw_step_resident: null engine");
     if (!e->res) return fail(CW_ERR_INVALID, "cw_step_resident needs num_envs == 1, host_outputs, auto_reset == 0 and obs_mode state or pixels_dirty");
     if (!e->has_reset) return fail(CW_ERR_STATE, "cw_step_resident called before cw_reset");
-    if (action < 0 || action > 255) return fail(CW_ERR_INVALID, "cw_step_resident: action %d outside 0..255", action);
+    if (action < 0 || action > 127) return fail(CW_ERR_INVALID, "cw_step_resident: action %d outside 0..127", action);
+    if (want_onehot && !e->P.res_onehot) return fail(CW_ERR_INVALID, "cw_step_resident: no host one-hot buffer on this engine");
     CwResident *R = e->res;
     const uint32_t seq = (++e->res_seq) & 0xFFFFFFu;
-    __atomic_store_n(&R->doorbell, (seq << 8) | (uint32_t)action, __ATOMIC_RELEASE);
+    __atomic_store_n(&R->doorbell, (seq << 8) | (want_onehot ? 0x80u : 0u) | (uint32_t)action, __ATOMIC_RELEASE);
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spins = 0;; spins++) {

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
         const uint32_t seq = d >> 8;
         if (seq != last) {
             if (lane == 0) {
-                const int a = (int)(d & 0xFFu);
+                const int a = (int)(d & 0x7Fu);                                  // (bit 7: also leave obs_one_hot in P.res_onehot)
                 const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
                 P.hdr[0] = h;
                 P.pos[0] = pack_pos(sp);
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
                 if (o.success) atomicAdd(&P.counters[2], 1ull);
                 if (o.invalid) atomicAdd(&P.counters[3], 1ull);
             }
-            if (P.res_onehot) {                                                  // CraftingWorldEnvOneHot: obs_one_hot itself is the observation
+            if (P.res_onehot && (d & 0x80u)) {                                   // CraftingWorldEnvOneHot: obs_one_hot itself is the observation
                 const uint32_t hx = __builtin_amdgcn_readlane(h.x, 0), codes = __builtin_amdgcn_readlane(h.w, 0);   // (onehot.py:369-371)
                 uint32_t bp[8];
 #pragma unroll

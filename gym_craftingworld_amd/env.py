@@ -79,6 +79,7 @@ class CraftingWorldEnv:
         # itself after 2 ms without a request and is parked by every other call).  resident=False (or CW_RESIDENT=0) keeps "launch + stream sync".
         import os
         self._resident = (os.environ.get('CW_RESIDENT', '1') != '0') if resident is None else bool(resident)
+        self._want_onehot = 0                       # (the one-hot class: the resident step also leaves obs_one_hot in pinned host memory)
         self.store_gif, self.render_save_rate = False, render_save_rate            # ray.py:135-136
         self._gif_frames = None
         if store_gif:                                                              # ray.py:142-143
@@ -201,7 +202,7 @@ class CraftingWorldEnv:
         if not 0 <= a < len(self.ACTIONS):
             raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
         if self._resident:
-            rc = self._lib.cw_step_resident(self._eng, a)                          # doorbell + spin: no launch, no stream sync
+            rc = self._lib.cw_step_resident(self._eng, a, self._want_onehot)        # doorbell + spin: no launch, no stream sync
         else:
             self._act[0] = a
             rc = self._lib.cw_step(self._eng, self._act_p, 0, self._stream)        # 0 = CW_ACT_I32
@@ -297,6 +298,7 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
         # resident steps leave obs_one_hot in the engine's pinned host buffer (cw_buffer_table.host_onehot); the launch path exports it
         # with a kernel of its own after every step
         self._resident = self._resident and self._vec._host_onehot is not None
+        self._want_onehot = 1 if self._resident else 0
         S = self.STATE_W
         oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=int)  # noqa: E731
         self.observation_space = Dict(dict(observation=oh(), desired_goal=oh(), achieved_goal=oh(),

@@ -180,10 +180,10 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
  * For engines with num_envs == 1, host_outputs, auto_reset == 0 and obs_mode CW_OBS_STATE or CW_OBS_PIXELS_DIRTY: a resident
  * single-wavefront kernel polls a doorbell word in pinned host memory; this call rings it and spins until the step's outputs (reward, done,
  * masks, the <= 2 repainted cells of the host-mapped frame) are visible -- a few microseconds instead of a launch plus a stream
- * synchronisation.  Results are those of cw_step with the same action.  The kernel is started on demand and leaves by itself: after 2 ms
+ * synchronisation.  Results are those of cw_step with the same action (0..127; larger ids than 5 are the counted no-op of cw_step).  The kernel is started on demand and leaves by itself: after 2 ms
  * without a request, after a 200-ms time slice, or when any other entry point of this engine is called (they park it first; cw_resident_stop
  * does only that).  Synchronous; do not mix with cw_step on a stream that has work pending for this engine. */
-int cw_step_resident(cw_engine *e, int32_t action);
+int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot /* 1: also rewrite cw_buffer_table.host_onehot */);
 int cw_resident_stop(cw_engine *e);
 
 /* render(state=None) for every env into a caller-supplied DEVICE buffer [N][P][P][3] (works in
