@@ -404,13 +404,14 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             continue;
         }
         if (p < 0 || !timed) continue;
+        // is the held placement still what it was?  (CONSECUTIVE windows: one holding an all-env reset step is followed by a normal one;
+        // counted before the outlier filter below, which would take a placement that has tipped by 17 % for a reset storm 80 windows long)
+        if (a.place_on && !a.surveying && a.place_ms > 0 && p == a.cur) a.place_bad = ms > 1.04f * a.place_ms ? a.place_bad + 1 : 0;
         const bool known = a.stat[p] > 0 && cw - a.stat_window[p] < 80;
         if (known && ms > 1.06f * a.stat[p]) continue;                           // a reset storm inside the window
         a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
         a.stat_window[p] = cw;
         moved = true;
-        if (a.place_on && !a.surveying && a.place_ms > 0 && p == a.cur)          // is the held placement still what it was?
-            a.place_bad = ms > 1.04f * a.place_ms ? a.place_bad + 1 : 0;
     }
     if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
         // Every survey window has been read.  WHICH placement to hold: not the fastest.  Placements come in three kinds (profiles/
