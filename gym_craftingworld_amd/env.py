@@ -68,6 +68,7 @@ class CraftingWorldEnv:
         self.INIT_OBS = self._h_init if self._live else np.zeros(fs, self._dtype)
         self.observation = None
         self.desired_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)  # ray.py:112
+        self._masks_seen = (-1, -1)                 # the (achieved, desired) masks the two vectors currently show
         self.achieved_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)
         self._bit_rows = ((np.arange(1 << len(self.task_list))[:, None] >> np.arange(len(self.task_list))) & 1) \
             if len(self.task_list) <= 12 else None                                # mask -> 0/1 row
@@ -79,6 +80,7 @@ class CraftingWorldEnv:
         # itself after 2 ms without a request and is parked by every other call).  resident=False (or CW_RESIDENT=0) keeps "launch + stream sync".
         import os
         self._resident = (os.environ.get('CW_RESIDENT', '1') != '0') if resident is None else bool(resident)
+        self._step_resident = self._lib.cw_step_resident
         self._want_onehot = 0                       # (the one-hot class: the resident step also leaves obs_one_hot in pinned host memory)
         self.store_gif, self.render_save_rate = False, render_save_rate            # ray.py:135-136
         self._gif_frames = None
@@ -160,8 +162,11 @@ class CraftingWorldEnv:
         k, p = self._vec.get_rng_states()
         return k[0], int(p[0])
 
-    def _pull_goals(self):
-        ach, des = int(self._h_ach[0]), int(self._h_des[0])
+    def _pull_goals(self, force=False):
+        ach, des = self._h_ach.item(0), self._h_des.item(0)
+        if not force and ach == self._masks_seen[0] and des == self._masks_seen[1]:
+            return                                  # (most steps change neither vector: nothing to rewrite)
+        self._masks_seen = (ach, des)
         if self._bit_rows is not None:
             self.achieved_goal_vector[0, :] = self._bit_rows[ach]                 # mutated in place, like ray.py:659
             self.desired_goal_vector[0, :] = self._bit_rows[des]
@@ -186,7 +191,7 @@ class CraftingWorldEnv:
             self.obs_image[...] = self._h_obs
             self.desired_goal[...] = self._h_goal
             self.INIT_OBS[...] = self._h_init
-        self._pull_goals()
+        self._pull_goals(force=True)                # (the caller may have written into the vectors it was handed)
         if self.store_gif:                                                        # ray.py:205-216
             self._gif_frames = [self._gif_frame()] if self.ep_no % self.render_save_rate == 0 else []
         return self._obs_dict()
@@ -199,10 +204,10 @@ class CraftingWorldEnv:
 
     def step(self, action):
         a = int(action)
-        if not 0 <= a < len(self.ACTIONS):
+        if not 0 <= a < 6:
             raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
         if self._resident:
-            rc = self._lib.cw_step_resident(self._eng, a, self._want_onehot)        # doorbell + spin: no launch, no stream sync
+            rc = self._step_resident(self._eng, a, self._want_onehot)               # doorbell + spin: no launch, no stream sync
         else:
             self._act[0] = a
             rc = self._lib.cw_step(self._eng, self._act_p, 0, self._stream)        # 0 = CW_ACT_I32
@@ -221,7 +226,7 @@ class CraftingWorldEnv:
             self._gif_frames.append(self._gif_frame())
         info = {'task_success': self.achieved_goal_vector, 'desired_goal': self.desired_goal_vector,
                 'achieved_goal': self.achieved_goal_vector}                        # ray.py:376-378
-        return self._obs_dict(), int(self._h_reward[0]), bool(self._h_done[0]), info
+        return self._obs_dict(), self._h_reward.item(0), self._h_done.item(0) != 0, info
 
     def render(self, state=None, mode='Non', tile_size=4):
         """render() of ray.py:442-520: the current state, or a caller-supplied (S,S,12) one-hot `state` of any content -- the image
