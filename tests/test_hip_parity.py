@@ -66,6 +66,8 @@ def test_golden_fixture_replay(name, obs_mode):
         assert crc(view(obs, 'init_observation')) == g['r_init_img_crc'][ri]
         assert g['r_at_step'][ri] == t
         assert st['ep_no'][0] == g['r_ep_no'][ri]
+        # the MT19937 stream position after EVERY reset is the reference's (numpy holds 624 where the engine holds 0: the same point of the stream)
+        assert env.get_rng_states()[1][0] % 624 == g['r_rng_pos'][ri] % 624, (name, 'rng position', ri)
         if onehot:
             assert np.array_equal(st['goal_grid'][0], g['r_goal_grid'][ri]) and tuple(st['goal_agent_rc'][0]) == tuple(g['r_goal_agent'][ri])
         if ri < len(g['img_desired']):
