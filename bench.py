@@ -189,7 +189,7 @@ def main():
     ap.add_argument('--mixed-menus', action='store_true',
                     help='BASELINE configs[3] shape: env i uses ordered task list i mod 8 of a fixed menu of eight (heterogeneous selected_tasks / '
                          'number_of_tasks / stacking / reward_style per env)')
-    ap.add_argument('--prewarm-steps', type=int, default=288,
+    ap.add_argument('--prewarm-steps', type=int, default=320,
                     help='untimed steps before the W warm-up steps (0: none): a card that idled through set-up runs its first ~100 launches 3-5 %% '
                          'slower, and the engine surveys the eight placements of its sweep loop over its first 256 steps (cw_engine.cpp: adapt_tick); '
                          'reported as prewarm_steps / warmup_total')
@@ -365,6 +365,13 @@ def main():
     # launches after that run 3-6 % slower than the steady state the K timed steps are meant to show (K=20, W=5 without it: 2.60-2.67 x 10^8
     # in the first region, 2.74-2.77 in the next two; profiles/history/r02_pace.txt T).  Untimed, like the W steps that follow it.
     prewarm_steps = 0 if args.rollout else max(args.prewarm_steps, 0)
+    if prewarm_steps > 0 and not args.desync and K < args.max_steps:
+        # A short timed region (the driver's K may be 20 steps) either holds one of the steps on which every env times out at once (every
+        # max_steps-th step with synchronized phases, ~4x a plain step: 1 in 20 instead of 1 in 300, +15 %) or none.  It is placed between
+        # two of them; metric_window is the figure that includes them in their true proportion.
+        first = prewarm_steps + W + 1                    # 1-based step number of the first timed step
+        if (first - 1) // args.max_steps != (first + K - 1) // args.max_steps:
+            prewarm_steps += args.max_steps - (first - 1) % args.max_steps + 8
     if prewarm_steps > 0:
         run((prewarm_steps // G) * G if G > 0 else prewarm_steps, 0)
         torch.cuda.synchronize(dev)
