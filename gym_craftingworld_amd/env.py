@@ -305,15 +305,20 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
         self._resident = self._resident and self._vec._host_onehot is not None
         self._want_onehot = 1 if self._resident else 0
         S = self.STATE_W
-        oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=int)  # noqa: E731
+        oh = lambda: Box(low=0, high=1, shape=(S, S, 12), dtype=self._dtype)  # noqa: E731
         self.observation_space = Dict(dict(observation=oh(), desired_goal=oh(), achieved_goal=oh(),
-                                           init_observation=oh()))                # onehot.py:84-103
-        self._oh = np.zeros((S, S, 12), dtype=int)
-        self._oh_goal = np.zeros((S, S, 12), dtype=int)
-        self._oh_init = np.zeros((S, S, 12), dtype=int)
-        self._oh_pin = torch.zeros((1, S, S, 12), dtype=torch.uint8).pin_memory()   # GPU-visible host memory
+                                           init_observation=oh()))                # onehot.py:84-103 (dtype=int there; uint8 here unless reference_dtypes)
+        self._oh_pin = torch.zeros((1, S, S, 12), dtype=torch.uint8).pin_memory()   # GPU-visible host memory (launch path, reset exports)
         self._oh_pin_np = self._oh_pin.numpy()[0]
         self._oh_pin_p = C.c_void_p(self._oh_pin.data_ptr())
+        # where a step leaves obs_one_hot: the engine's pinned buffer (resident steps) or ours (the launch path's export kernel)
+        self._oh_src = self._vec._host_onehot if self._resident else self._oh_pin_np
+        self._oh_src_p = C.c_void_p(self._oh_src.ctypes.data)
+        # default dtype uint8: `observation` IS that buffer, mutated in place by later steps like the frames of the other classes (and like
+        # the reference's obs_one_hot, onehot.py:369-371); reference_dtypes=True: int64 copies
+        self._oh = self._oh_src if self._live else np.zeros((S, S, 12), dtype=int)
+        self._oh_goal = np.zeros((S, S, 12), dtype=self._dtype)
+        self._oh_init = np.zeros((S, S, 12), dtype=self._dtype)
 
     def _after_step_enqueue(self):
         self._lib.cw_export_onehot(self._eng, self._oh_pin_p, self._stream)         # onehot.py:369-371
@@ -325,16 +330,20 @@ class CraftingWorldEnvOneHot(CraftingWorldEnv):
 
     def reset(self, render_next=False):
         super().reset()
-        for which, dst in ((1, self._oh_goal), (0, self._oh)):                    # goal state (onehot.py:310), current state
-            self._lib.cw_export_onehot_of(self._eng, which, self._oh_pin_p, self._stream)
-            self._lib.cw_synchronize(self._eng, self._stream)
-            dst[...] = self._oh_pin_np
-        self._oh_init[...] = self._oh                                             # onehot.py:203
+        self._lib.cw_export_onehot_of(self._eng, 1, self._oh_pin_p, self._stream)   # goal state (onehot.py:310)
+        self._lib.cw_synchronize(self._eng, self._stream)
+        self._oh_goal[...] = self._oh_pin_np
+        self._lib.cw_export_onehot_of(self._eng, 0, self._oh_src_p, self._stream)   # current state, into the buffer the steps rewrite
+        self._lib.cw_synchronize(self._eng, self._stream)
+        if not self._live:
+            self._oh[...] = self._oh_src
+        self._oh_init[...] = self._oh_src                                         # onehot.py:203
         return self._oh_dict()
 
     def step(self, action):
         _, r, d, info = super().step(action)
-        self._oh[...] = self._vec._host_onehot if self._resident else self._oh_pin_np
+        if not self._live:
+            self._oh[...] = self._oh_src
         return self._oh_dict(), r, d, info
 
 
