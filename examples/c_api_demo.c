@@ -7,12 +7,17 @@
  *
  * Creates 1024 envs (21x21, dirty-cell pixel mode), seeds them like numpy RandomState(i), runs 600
  * random steps with auto-reset, reads back rewards/counters and one frame, and prints a checksum that
- * tests/test_c_api_demo.py compares with the CPU oracle's.
+ * tests/test_c_api_demo.py compares with the CPU oracle's.  Then the single-env loop of the reference
+ * (docs/source/envs/gen_info.rst:62-82) through cw_step_resident: one env with host-mapped outputs, 3000
+ * steps without a kernel launch (a resident kernel polls a doorbell word), reset() whenever done -- a
+ * second line of checksums, and the time per step.
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c99 */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include "craftingworld.h"
 
@@ -70,5 +75,38 @@ int main(void)
     printf("envs %d steps %d env_steps %llu episodes %llu successes %llu reward_sum_sampled %lld frame17_fnv %08x\n", N, T,
            (unsigned long long)counters[0], (unsigned long long)counters[1], (unsigned long long)counters[2], reward_sum, fnv);
     CHECK_CW(cw_destroy(eng));
+
+    /* ---- the single-env loop: step() = a doorbell word and a spin, no launch (cw_step_resident) ---- */
+    enum { T1 = 3000 };
+    cfg.num_envs = 1; cfg.max_steps = 120; cfg.auto_reset = 0; cfg.host_outputs = 1;     /* gym.Env semantics; outputs in pinned host memory */
+    cw_engine *one = NULL;
+    CHECK_CW(cw_create(&cfg, 0, &one));
+    uint32_t seed1 = 7777u;
+    CHECK_CW(cw_seed_int(one, &seed1));
+    CHECK_CW(cw_reset(one, st));
+    CHECK_CW(cw_synchronize(one, st));
+    cw_buffer_table hb;
+    CHECK_CW(cw_buffers(one, &hb));                      /* host pointers: reward, done, obs are readable as plain memory */
+    long long rsum = 0;
+    int episodes = 0;
+    uint32_t rs1 = 99u, trace = 2166136261u;
+    struct timespec ta, tb;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
+    for (int t = 0; t < T1; t++) {
+        CHECK_CW(cw_step_resident(one, (int32_t)(lcg(&rs1) % 6u), 0));
+        rsum += hb.reward[0];
+        trace = (trace ^ (uint32_t)hb.achieved[0]) * 16777619u;
+        if (hb.done[0]) {                                /* the caller resets, as in the reference loop (this parks the resident kernel) */
+            episodes++;
+            CHECK_CW(cw_reset(one, st));
+            CHECK_CW(cw_synchronize(one, st));
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &tb);
+    uint32_t fnv1 = 2166136261u;
+    for (size_t i = 0; i < hb.frame_bytes; i++) fnv1 = (fnv1 ^ hb.obs[i]) * 16777619u;
+    printf("single_env steps %d episodes %d reward_sum %lld achieved_trace %08x frame_fnv %08x us_per_step_incl_resets %.2f\n", T1, episodes, rsum, trace,
+           fnv1, ((tb.tv_sec - ta.tv_sec) * 1e9 + (tb.tv_nsec - ta.tv_nsec)) / 1e3 / T1);
+    CHECK_CW(cw_destroy(one));
     return 0;
 }

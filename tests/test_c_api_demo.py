@@ -52,3 +52,26 @@ def test_c_demo_matches_oracle():
     assert int(m.group(3)) == int((rew == 300).sum())
     assert int(m.group(4)) == sampled
     assert m.group(5) == '%08x' % fnv
+    # second line: the single-env loop through cw_step_resident (no kernel launch per step), against the oracle's single env
+    from oracle import OracleEnv
+    m1 = re.search(r'single_env steps (\d+) episodes (\d+) reward_sum (-?\d+) achieved_trace ([0-9a-f]{8}) frame_fnv ([0-9a-f]{8}) us_per_step_incl_resets ([0-9.]+)', out)
+    assert m1, out
+    st = np.random.RandomState(7777).get_state()
+    env = OracleEnv(rng_state=(st[1], st[2]), size=(21, 21), max_steps=120)
+    obs = env.reset()
+    x, rsum, episodes, trace = 99, 0, 0, 2166136261
+    for t in range(3000):
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        obs, r, d, info = env.step((x >> 8) % 6)
+        rsum += r
+        ach = sum(int(b) << i for i, b in enumerate(np.asarray(info['achieved_goal']).reshape(-1)))
+        trace = ((trace ^ ach) * 16777619) & 0xFFFFFFFF
+        if d:
+            episodes += 1
+            obs = env.reset()
+    f1 = 2166136261
+    for b in np.asarray(obs['observation'], dtype=np.uint8).reshape(-1).tolist():
+        f1 = ((f1 ^ b) * 16777619) & 0xFFFFFFFF
+    assert (int(m1.group(1)), int(m1.group(2)), int(m1.group(3))) == (3000, episodes, rsum)
+    assert m1.group(4) == '%08x' % trace and m1.group(5) == '%08x' % f1
+    assert float(m1.group(6)) < 16.0                     # (the launch path and the reference's own step are ~17 us)
