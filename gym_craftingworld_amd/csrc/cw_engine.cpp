@@ -128,10 +128,11 @@ enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW
 static int resident_park(cw_engine *e)
 {
     if (!e->res_running) return CW_OK;
-    __atomic_store_n(&e->res->stop, 1u, __ATOMIC_RELEASE);
+    const unsigned long long low = __atomic_load_n(&e->res->bell, __ATOMIC_RELAXED) & 0xFFFFFFFFull;
+    __atomic_store_n(&e->res->bell, low | (1ull << 32), __ATOMIC_RELEASE);
     HIP_TRY(hipStreamSynchronize(e->res_stream));        // the kernel leaves within one poll of seeing the flag
     e->res_running = false;
-    __atomic_store_n(&e->res->stop, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&e->res->bell, low, __ATOMIC_RELEASE);
     __atomic_store_n(&e->res->exited, 0u, __ATOMIC_RELEASE);
     return CW_OK;
 }
@@ -937,7 +938,7 @@ int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
     if (want_onehot && !e->P.res_onehot) return fail(CW_ERR_INVALID, "cw_step_resident: no host one-hot buffer on this engine");
     CwResident *R = e->res;
     const uint32_t seq = (++e->res_seq) & 0xFFFFFFu;
-    __atomic_store_n(&R->doorbell, (seq << 8) | (want_onehot ? 0x80u : 0u) | (uint32_t)action, __ATOMIC_RELEASE);
+    __atomic_store_n(&R->bell, (unsigned long long)((seq << 8) | (want_onehot ? 0x80u : 0u) | (uint32_t)action), __ATOMIC_RELEASE);
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spins = 0;; spins++) {

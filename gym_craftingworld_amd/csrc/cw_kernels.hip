@@ -902,7 +902,8 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
     unsigned long long t_last = t_start;
     uint32_t reason = 0;
     for (;;) {
-        const uint32_t d = __hip_atomic_load(&R->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long bell = __hip_atomic_load(&R->bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t d = (uint32_t)bell;
         const uint32_t seq = d >> 8;
         if (seq != last) {
             if (lane == 0) {
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
             continue;
         }
         const unsigned long long now = wall_clock64();
-        if (__hip_atomic_load(&R->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { reason = 1; break; }
+        if (bell >> 32) { reason = 1; break; }
         if (now - t_last > idle_ticks) { reason = 2; break; }
         if (now - t_start > life_ticks) { reason = 3; break; }
     }

@@ -66,8 +66,8 @@ struct CwTuning {
 // Control block of the RESIDENT stepper (cw_step_resident: the single-env loop, a step without a kernel launch): pinned, coherent host memory
 // the device polls.  One 128-byte line per direction so that the host's doorbell stores and the device's answers never share a line.
 struct CwResident {
-    uint32_t doorbell;       // host -> device: (seq << 8) | action, seq = 1, 2, ... (a new seq is a new step request)
-    uint32_t stop;           // host -> device: 1 = leave now (cw_resident_stop and every entry point that touches the engine's state)
+    unsigned long long bell; // host -> device, ONE word so that a poll is one PCIe read: low half (seq << 8) | action, seq = 1, 2, ... (a new seq is a
+                             // new step request); high half 1 = leave now (cw_resident_stop and every entry point that touches the engine's state)
     uint32_t pad0[30];
     uint32_t ack;            // device -> host: the last seq whose outputs (reward, done, masks, repainted cells, state) are visible
     uint32_t exited;         // device -> host: 0 while resident; else reason (1 stop, 2 idle, 3 time slice used up) | last seq served << 8
