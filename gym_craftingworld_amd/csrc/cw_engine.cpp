@@ -211,6 +211,22 @@ void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, c
     return m;
 }
 
+// The placement survey's decision (adapt_tick), as a pure function: med[k] = median ms/step of placement k (<= 0: no figure), struck = bit
+// mask of placements not to hold again.  Of the placements within 6 % of the fastest (off the cliff) the MEDIAN one -- the fastest are
+// bistable (profiles/r03_placement.txt C).  -> the placement, or -1 if none has a figure; *n_candidates for the log.
+int cwh_choose_place(const float *med, unsigned struck, int *n_candidates)
+{
+    float fastest = 0.f;
+    for (int k = 0; k < 8; k++)
+        if (med[k] > 0.f && !((struck >> k) & 1u) && (fastest == 0.f || med[k] < fastest)) fastest = med[k];
+    int cand[8], n = 0;
+    for (int k = 0; k < 8; k++)
+        if (med[k] > 0.f && !((struck >> k) & 1u) && med[k] <= 1.06f * fastest) cand[n++] = k;
+    std::sort(cand, cand + n, [&](int x, int y) { return med[x] < med[y] || (med[x] == med[y] && x < y); });
+    if (n_candidates) *n_candidates = n;
+    return n > 0 ? cand[(n - 1) / 2] : -1;
+}
+
 void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
 {
     s[0] = seed;
@@ -421,8 +437,8 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         // tells which it will be.  So: drop what is more than 6 % above the fastest (the cliff), and of the rest hold the MEDIAN one --
         // neither on the cliff nor on the edge.  A placement that later reads > 4 % above its survey figure for CW_PLACE_BAD_WINDOWS
         // windows is struck off (a.place_struck) and the survey repeated.
-        int best = a.place;
-        float best_ms = 0.f, fastest = 0.f, med[CW_PLACES];
+        int best = a.place, n_cand = 0;
+        float best_ms = 0.f, med[CW_PLACES];
         char log[256] = "";
         size_t len = 0;
         for (int k = 0; k < CW_PLACES; k++) {
@@ -431,14 +447,9 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             if (m[0] <= 0 || m[1] <= 0 || m[2] <= 0) continue;                   // (a lost sample: the placement does not compete)
             med[k] = std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2]));
             if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f%s", k, med[k], ((a.place_struck >> k) & 1) ? "x" : "");
-            if ((a.place_struck >> k) & 1) { med[k] = 0.f; continue; }
-            if (fastest == 0.f || med[k] < fastest) fastest = med[k];
         }
-        int cand[CW_PLACES], n_cand = 0;
-        for (int k = 0; k < CW_PLACES; k++)
-            if (med[k] > 0.f && med[k] <= 1.06f * fastest) cand[n_cand++] = k;
-        std::sort(cand, cand + n_cand, [&](int x, int y) { return med[x] < med[y]; });
-        if (n_cand > 0) { best = cand[(n_cand - 1) / 2]; best_ms = med[best]; }
+        const int pick = cwh_choose_place(med, a.place_struck, &n_cand);
+        if (pick >= 0) { best = pick; best_ms = med[pick]; }
         if (verbose) fprintf(stderr, "[craftingworld] placement survey %u (window %u), median ms/step by placement:%s -> %d (median of the %d within 6 %% of the fastest)\n",
                              a.surveys, w, log, best, n_cand);
         a.place = best;

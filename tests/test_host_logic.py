@@ -238,3 +238,33 @@ def test_batch_space_adds_a_leading_axis():
     assert b['hdr'].shape == (7, 16) and b['slot_pos'].shape == (7, 8) and b['slot_pos'].dtype == np.int16
     assert int(b['slot_pos'].low.min()) == -2 and int(b['slot_pos'].high.max()) == 32767 and int(b['observation'].high.max()) == 255
     assert batch_space(Discrete(6), 5).nvec.tolist() == [6] * 5
+
+
+def test_placement_survey_holds_the_median_placement_off_the_cliff():
+    """The decision of cw_step's placement survey (cwh_choose_place, cw_engine.cpp: adapt_tick) on survey vectors recorded on MI355X boxes
+    (profiles/r03_placement.txt): of the placements within 6 % of the fastest the MEDIAN one -- never one on the cliff, never the lone
+    fast outlier while a plateau exists (it is bistable), the lone survivor when everything else is on the cliff; struck placements and
+    placements without a figure do not compete."""
+    import ctypes as C
+    from gym_craftingworld_amd import _lib
+    lib = _lib.load()
+
+    def choose(med, struck=0):
+        arr = (C.c_float * 8)(*med)
+        n = C.c_int(0)
+        return lib.cwh_choose_place(arr, struck, C.byref(n)), n.value
+
+    headline = [0.2369, 0.2359, 0.2299, 0.2346, 0.2363, 0.2343, 0.2378, 0.2424]      # 65 536 envs: 2 is the bistable fast outlier, all within 6 %
+    k, n = choose(headline)
+    assert n == 8 and k == 1 and headline[k] == sorted(headline)[3]
+    mixed = [0.4693, 0.4629, 0.5521, 0.5738, 0.5732, 0.5531, 0.4716, 0.4749]         # 131 072 envs: 2-5 are 20 % slower
+    k, n = choose(mixed)
+    assert n == 4 and k == 0
+    lone = [4.6112, 4.4330, 3.7898, 4.8034, 4.8254, 4.8369, 4.8117, 4.7773]           # 2^20 envs in 1792-round chunks: everything but 2 on the cliff
+    assert choose(lone) == (2, 1)
+    desync = [0.2568, 0.2816, 0.2890, 0.2829, 0.2815, 0.2741, 0.2526, 0.2532]        # phases spread out: 1-5 are 10 % slower
+    k, n = choose(desync)
+    assert n == 3 and k == 7
+    assert choose(headline, struck=1 << 1)[0] == 4                                  # the held placement fell out of its regime: next survey without it
+    assert choose([0, 0, 0.25, 0, 0, 0, 0, 0]) == (2, 1) and choose([0.0] * 8) == (-1, 0)
+    assert choose([0.25, 0.24, 0, 0, 0, 0, 0, 0], struck=3) == (-1, 0)
