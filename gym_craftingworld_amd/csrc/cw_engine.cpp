@@ -89,6 +89,8 @@ struct cw_engine {
     hipStream_t res_stream = nullptr;
     bool res_running = false;          // a cw_resident_kernel may be on the card
     uint32_t res_seq = 0;              // last sequence number rung
+    hipStream_t last_stream = nullptr; // the stream of the last cw_reset / cw_step / cw_rollout: a resident kernel starts only after that work
+    bool last_stream_set = false;
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
     hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -904,6 +906,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
     PARK(e);
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     e->has_reset = true;
+    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     return CW_OK;
 }
 
@@ -915,6 +918,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     if (e->adapt.on) {                               // full-frame mode: the sweep's extra sleeps beside resets follow what the steps measure (adapt_tick)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -964,6 +968,8 @@ int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
                 __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
                 return CW_OK;
             }
+            // (the new instance reads the env's records: whatever cw_reset / cw_step enqueued last on the caller's stream comes first)
+            if (e->last_stream_set) { HIP_TRY(hipStreamSynchronize(e->last_stream)); e->last_stream_set = false; }
             __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
             __atomic_store_n(&R->ack, (seq - 1u) & 0xFFFFFFu, __ATOMIC_RELEASE);
             HIP_TRY(cwk_launch_resident(&e->P, R, (seq - 1u) & 0xFFFFFFu, e->obs_mode == CW_OBS_PIXELS_DIRTY ? 1 : 0,
@@ -1001,6 +1007,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }

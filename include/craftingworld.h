@@ -182,7 +182,8 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
  * masks, the <= 2 repainted cells of the host-mapped frame) are visible -- a few microseconds instead of a launch plus a stream
  * synchronisation.  Results are those of cw_step with the same action (0..127; larger ids than 5 are the counted no-op of cw_step).  The kernel is started on demand and leaves by itself: after 2 ms
  * without a request, after a 200-ms time slice, or when any other entry point of this engine is called (they park it first; cw_resident_stop
- * does only that).  Synchronous; do not mix with cw_step on a stream that has work pending for this engine. */
+ * does only that).  Synchronous.  A new instance of the kernel waits for the stream of the engine's last cw_reset / cw_step / cw_rollout first, so
+ * `cw_reset(e, s); cw_step_resident(e, a, 0);` needs no synchronisation in between. */
 int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot /* 1: also rewrite cw_buffer_table.host_onehot */);
 int cw_resident_stop(cw_engine *e);
 
