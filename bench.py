@@ -161,6 +161,19 @@ def single_env_latency(device, steps=200, repeats=5):
                      'measured in the build container (BASELINE.md §2)')
 
 
+def place_short_region(prewarm, warmup, steps, max_steps):
+    """-> the number of untimed device warm-up steps to take so that a timed region SHORTER than an episode holds none of the steps on which
+    every env times out at once (every max_steps-th step with synchronized phases, ~4x a plain step).  Such a region (the driver's K may be 20
+    steps) would hold one of them or none -- 1 in 20 instead of 1 in 300, +15 % either way; metric_window is the figure that includes them in
+    their true proportion.  Regions of max_steps steps or more are left where they are."""
+    if steps >= max_steps:
+        return prewarm
+    first = prewarm + warmup + 1                         # 1-based number of the first timed step since reset()
+    if (first - 1) // max_steps != (first + steps - 1) // max_steps:
+        prewarm += max_steps - (first - 1) % max_steps + 8
+    return prewarm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -365,13 +378,8 @@ def main():
     # launches after that run 3-6 % slower than the steady state the K timed steps are meant to show (K=20, W=5 without it: 2.60-2.67 x 10^8
     # in the first region, 2.74-2.77 in the next two; profiles/history/r02_pace.txt T).  Untimed, like the W steps that follow it.
     prewarm_steps = 0 if args.rollout else max(args.prewarm_steps, 0)
-    if prewarm_steps > 0 and not args.desync and K < args.max_steps:
-        # A short timed region (the driver's K may be 20 steps) either holds one of the steps on which every env times out at once (every
-        # max_steps-th step with synchronized phases, ~4x a plain step: 1 in 20 instead of 1 in 300, +15 %) or none.  It is placed between
-        # two of them; metric_window is the figure that includes them in their true proportion.
-        first = prewarm_steps + W + 1                    # 1-based step number of the first timed step
-        if (first - 1) // args.max_steps != (first + K - 1) // args.max_steps:
-            prewarm_steps += args.max_steps - (first - 1) % args.max_steps + 8
+    if prewarm_steps > 0 and not args.desync:
+        prewarm_steps = place_short_region(prewarm_steps, W, K, args.max_steps)
     if prewarm_steps > 0:
         run((prewarm_steps // G) * G if G > 0 else prewarm_steps, 0)
         torch.cuda.synchronize(dev)

@@ -124,3 +124,18 @@ def test_eight_ranks_start_rendezvous_over_gloo_and_relay_one_line(tmp_path):
     d = json.loads(lines[-1])
     assert d['n_gpus'] == 8 and abs(d['worst'] - 0.008) < 1e-12 and d['per_rank'] == [0.001 * (i + 1) for i in range(8)]
     assert (d['lo'], d['hi']) == (0, 1001)
+
+
+def test_bench_places_a_short_timed_region_between_all_env_time_outs():
+    """bench.py's untimed warm-up is lengthened so that a timed region shorter than an episode never straddles a multiple of max_steps
+    (the step on which every env of the synchronized benchmark times out: 4x a plain step); longer regions are left alone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cw_bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for prewarm, W, K in ((320, 5, 20), (288, 5, 20), (320, 0, 100), (320, 10, 280), (320, 290, 20), (320, 275, 20), (0, 295, 10), (1000, 3, 299)):
+        p = bench.place_short_region(prewarm, W, K, 300)
+        first, last = p + W + 1, p + W + K
+        assert p >= prewarm and not any(first <= m <= last for m in range(300, last + 1, 300)), (prewarm, W, K, p)
+    assert bench.place_short_region(320, 5, 20, 300) == 320 and bench.place_short_region(288, 5, 20, 300) > 288
+    assert bench.place_short_region(320, 20, 600, 300) == 320 and bench.place_short_region(320, 20, 300, 300) == 320
