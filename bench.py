@@ -170,7 +170,7 @@ def place_short_region(prewarm, warmup, steps, max_steps):
         return prewarm
     first = prewarm + warmup + 1                         # 1-based number of the first timed step since reset()
     if (first - 1) // max_steps != (first + steps - 1) // max_steps:
-        prewarm += max_steps - (first - 1) % max_steps + 8
+        prewarm += max_steps - (first - 1) % max_steps + min(8, max_steps - steps - 1)   # just past the time-out step (a few steps of slack if they fit)
     return prewarm
 
 
