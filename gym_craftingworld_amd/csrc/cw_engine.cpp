@@ -18,6 +18,7 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
+int cwk_render_is_alt_sweep(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
@@ -378,6 +379,70 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     return CW_OK;
 }
 
+// median launch time of the per-step render as currently configured (launches queued back to back, one wait: see calibrate_render_pace)
+static int timed_render_median(cw_engine *e, double *out)
+{
+    enum { LAUNCHES = 9, SKIP = 3 };
+    hipEvent_t evs[2 * LAUNCHES] = {};
+    bool ok = true;
+    for (hipEvent_t &ev : evs) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    int blocks = 0, wpb = 0;
+    for (int rep = 0; rep < LAUNCHES && ok; rep++)
+        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess &&
+             cwk_launch_render_calib(&e->P, &e->tune, nullptr, e->tune.render_q_all, e->tune.render_fast_parity, &blocks, &wpb) == hipSuccess &&
+             hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    float ms[LAUNCHES];
+    for (int rep = 0; rep < LAUNCHES && ok; rep++) ok = hipEventElapsedTime(&ms[rep], evs[2 * rep], evs[2 * rep + 1]) == hipSuccess;
+    for (hipEvent_t &ev : evs) if (ev) (void)hipEventDestroy(ev);
+    if (!ok) return fail(CW_ERR_HIP, "cw_create: render calibration failed");
+    std::sort(ms + SKIP, ms + LAUNCHES);
+    *out = ms[SKIP + (LAUNCHES - SKIP) / 2];
+    return CW_OK;
+}
+
+// AltObs raster: frame-per-wave painter (as calibrated so far) or the aligned-piece sweep (cw_kernels.hip: render_alt_sweep) for the per-step
+// render?  The sweep's pace (quarter sleeps per 1-KiB store) is measured, then the faster of the two is kept.
+static int calibrate_alt_sweep(cw_engine *e)
+{
+    CwTuning &tn = e->tune;
+    if (e->P.raster != CW_RASTER_ALT || !tn.alt_sweep || !cwk_render_is_alt_sweep(&e->P, &tn)) return CW_OK;
+    {   // the extra (quarter) sleeps while envs are reset beside the sweep: bits 12-15 of render_pace, the number cw_step's tuner follows
+        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
+        tn.render_pace = (tn.render_pace & ~0xF000) | (((beside ? atoi(beside) : 2) & 15) << 12);
+    }
+#ifdef CW_EXPERIMENT
+    const char *forced = getenv("CW_TUNE_ALT_SWEEP_PACE");
+#else
+    const char *forced = nullptr;
+#endif
+    if (forced) { tn.alt_sweep_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; return CW_OK; }
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;
+    double frames_ms = 0, t = 0, best_ms = 0;
+    tn.alt_sweep = 0;
+    int rc = timed_render_median(e, &frames_ms);
+    tn.alt_sweep = 1;
+    // 2 (a sleep after every other store) is the optimum on every box measured, by a margin the launches timed here cannot resolve against
+    // its neighbours (profiles/r03_alt_sweep.txt; the same experience as with the Ray sweep's pace): another candidate has to beat it by 3 %
+    static const int quarters[] = {2, 0, 1, 4, 6, 8};
+    int best = 2;
+    char log[256] = "";
+    size_t len = 0;
+    for (size_t i = 0; i < sizeof(quarters) / sizeof(quarters[0]) && rc == CW_OK; i++) {
+        tn.alt_sweep_pace = quarters[i];
+        rc = timed_render_median(e, &t);
+        if (rc == CW_OK && (best_ms == 0 || t < 0.97 * best_ms)) { best_ms = t; best = quarters[i]; }
+        if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", quarters[i], t);
+    }
+    if (rc != CW_OK) return rc;
+    tn.alt_sweep_pace = best;
+    if (best_ms >= frames_ms) tn.alt_sweep = 0;
+    if (getenv("CW_TUNE_VERBOSE"))
+        fprintf(stderr, "[craftingworld] AltObs render: frame per wave %.4f ms; sweep of aligned pieces, ms per launch by quarter sleeps per store%s -> %s\n",
+                frames_ms, log, tn.alt_sweep ? "sweep" : "frame per wave");
+    return CW_OK;
+}
+
 // Online tuner of the one-launch full-frame step: (1) the sweep's extra sleeps beside resets, (2) the placement of its batch loop.
 // Neither can be predicted from launches timed at cw_create (profiles/history/r02_pace.txt, r02_fused_render.txt, r03_placement.txt), so cw_step
 // keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and the time between
@@ -690,6 +755,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
 #ifdef CW_EXPERIMENT
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);
+        tn.alt_sweep = geti("CW_TUNE_ALT_SWEEP", tn.alt_sweep);
         tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
         tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
         const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
@@ -793,18 +859,22 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
+    const int want_alt_sweep = e->tune.alt_sweep;
+    e->tune.alt_sweep = 0;                                       // (the frame-per-wave painter first: its pace and shares also serve the frames of resets)
     if (rc == CW_OK) rc = calibrate_render_pace(e, false);
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
+    e->tune.alt_sweep = want_alt_sweep;
+    if (rc == CW_OK) rc = calibrate_alt_sweep(e);
     if (rc == CW_OK) e->tune.render_pace |= (e->tune.render_pace_fine & 0xFF) << 16;
-    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions && cwk_render_is_linear(&e->P, &e->tune) &&
-        !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
+    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
+        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_alt_sweep(&e->P, &e->tune)) && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
         a.cur = (e->tune.render_pace >> 12) & 15;
         if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
         a.pace_on = !getenv("CW_TUNE_RENDER_PACE_BESIDE");
         a.place = e->tune.render_place;
-        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) && cwk_render_is_linear(&e->P, &e->tune);
         if (a.pace_on || a.place_on) {
             for (hipEvent_t &ev : a.ev)
                 if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
@@ -1121,6 +1191,7 @@ const char *cw_render_kernel_name(const cw_engine *e)
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
+    if (cwk_render_is_alt_sweep(&e->P, &e->tune)) return one_launch ? "cw_render_alt_step_kernel" : "cw_render_alt_kernel";
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
 }

@@ -637,20 +637,23 @@ def test_config4_shard_shape_mixed_menus_131072():
     env.close()
 
 
-@pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty'])
-def test_altobs_raster_vs_oracle(obs_mode):
+@pytest.mark.parametrize('obs_mode,S,N', [('pixels', 6, 200), ('pixels_dirty', 6, 200), ('pixels', 13, 151), ('pixels', 21, 67)])
+def test_altobs_raster_vs_oracle(obs_mode, S, N):
     """the AltObs rasteriser (3x3-px CPV tiles + holding strip) in both pixel modes
-    vs the oracle: all three frames, cw_render, terminal frames; includes sticks held over sticks (2 x colour)."""
+    vs the oracle: all three frames, cw_render, terminal frames; includes sticks held over sticks (2 x colour).
+    (6x6 frames are painted frame per wave; frames of >= 4 KiB -- 13x13, 21x21 -- by the sweep of aligned 4-KiB pieces, whose pieces
+    here overlap two frames, one of them often being reset, and end in a partial piece.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from oracle import OracleBatch
-    N, T, kw = 200, 90, dict(size=(6, 6), max_steps=30)
+    T, kw = 90, dict(size=(S, S), max_steps=30)
     keys, pos = _np_states(N, 6060)
     env = CraftingWorldVecEnv(N, obs_mode=obs_mode, raster='alt', keep_terminal_obs=True, **kw)
     env.set_rng_states(keys, pos)
     ora = OracleBatch(N, rng_states=list(zip(keys, pos)), alt_obs=True, **kw)
     obs = env.reset()
     ora.reset()
-    assert tuple(obs['observation'].shape) == (N, 21, 18, 3)
+    assert tuple(obs['observation'].shape) == (N, 3 * S + 3, 3 * S, 3)
+    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_alt_kernel' if S >= 13 else 'cw_render_frames_kernel')      # (keep_terminal_obs: render and resets on two streams)
     acts = np.random.RandomState(2).randint(0, 6, size=(T, N)).astype(np.int32)
     dacts = torch.as_tensor(acts, device=env.device)
     for t in range(T):
@@ -671,11 +674,11 @@ def test_altobs_raster_vs_oracle(obs_mode):
                 assert np.array_equal(ren[i], s['obs']), (t, i)
                 assert np.array_equal(des[i], s['desired_img']) and np.array_equal(ini[i], s['init_img']), (t, i)
     # the double-count corner: sticks in hand, standing on sticks -> blue channel 2*160 mod 256 = 64
-    grid = np.zeros((N, 6, 6), np.uint8)
+    grid = np.zeros((N, S, S), np.uint8)
     grid[:, 2, 3] = 1
     env.set_state(grid=grid, agent_rc=np.tile(np.array([[2, 3]], np.uint8), (N, 1)), hold=np.ones(N, np.uint8))
     fr = env.render()[0].cpu().numpy()
-    assert fr[6, 9].tolist() == [90, 164, 64] and fr[8, 11].tolist() == [0, 0, 255] and fr[18:, 3:6].min() == 255
+    assert fr[6, 9].tolist() == [90, 164, 64] and fr[8, 11].tolist() == [0, 0, 255] and fr[3 * S:, 3:6].min() == 255
     env.close()
 
 
@@ -1094,7 +1097,8 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, exp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
-                                           (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'),
+                                           (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'), (2999, 12, 'alt'),
+                                           (3000, 21, 'alt-frames'), (65536, 21, 'alt-frames'), (1501, 32, 'alt-frames'),
                                            (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked')])
 def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch, experiment_build):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
@@ -1106,6 +1110,13 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch,
     if raster == 'ray-chunked':      # large batches are swept in several launches over consecutive env ranges (cw_sweep_chunks): here 5 / 14 of them,
         raster = 'ray'               # the last one shorter, the resetting workgroups on the first
         monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '5' if N < 10000 else '35')
+    alt_sweep = False
+    if raster == 'alt':              # AltObs frames of at least 4 KiB: the per-step render is the sweep of aligned 4-KiB pieces (render_alt_sweep) ...
+        alt_sweep = 27 * size * (size + 1) >= 4096
+        monkeypatch.setenv('CW_TUNE_ALT_SWEEP_PACE', '1')       # (forced: cw_create would otherwise keep whichever painter it measures faster)
+    elif raster == 'alt-frames':     # ... or the frame-per-wave painter (smaller frames, very large batches, or when cw_create measures it faster)
+        raster = 'alt'
+        monkeypatch.setenv('CW_TUNE_ALT_SWEEP', '0')
     kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
     engines = {}
     for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
@@ -1114,7 +1125,7 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch,
         engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
         if var:
             monkeypatch.delenv(var)
-    stem = 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_frames'      # linear sweep; else the frame-per-wave painter
+    stem = 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_alt' if alt_sweep else 'cw_render_frames'      # linear sweeps; else the frame-per-wave painter
     assert engines['one launch'].render_kernel_name() == stem + '_step_kernel'
     assert engines['two streams'].render_kernel_name() == stem + '_kernel'
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
