@@ -15,7 +15,7 @@ ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only
 are the timing barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt), with
-  roofline     -- dominant kernel (cw_render_step_kernel) vs the HBM roof, from HIP events recorded by the
+  roofline     -- dominant kernel (cw_render_pieces_step_kernel, or cw_render_step_kernel where cw_create measured that one faster) vs the HBM roof, from HIP events recorded by the
                   library on the launch stream (cw_profile_begin/end) over a second, identical
                   K-step region (the first region, without events, gives `value`);
   cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) on this host's cores,
@@ -571,7 +571,8 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dominant,
                          # the one-launch step exists at eight placements of its sweep loop, and the engine measures which one to launch: a
                          # rocprofv3 trace lists them as cw_render_step_kernel<0..7>, this is the one the profiled region ran
-                         'kernel_in_trace': ('%s<%d>' % (dominant, tuner['place'])) if dominant == 'cw_render_step_kernel' else dominant,
+                         'kernel_in_trace': (('%s<%d>' % (dominant, tuner['place'])) if dominant == 'cw_render_step_kernel' else
+                                             ('%s<%d>' % (dominant, 1 if args.raster == 'alt' else 0)) if dominant.startswith('cw_render_pieces') else dominant),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation

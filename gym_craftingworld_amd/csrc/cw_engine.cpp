@@ -18,7 +18,7 @@ extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
                            hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
-int cwk_render_is_alt_sweep(const CwParams *P, const CwTuning *T);
+int cwk_render_is_piece_sweep(const CwParams *P, const CwTuning *T);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
@@ -401,45 +401,51 @@ static int timed_render_median(cw_engine *e, double *out)
     return CW_OK;
 }
 
-// AltObs raster: frame-per-wave painter (as calibrated so far) or the aligned-piece sweep (cw_kernels.hip: render_alt_sweep) for the per-step
-// render?  The sweep's pace (quarter sleeps per 1-KiB store) is measured, then the faster of the two is kept.
-static int calibrate_alt_sweep(cw_engine *e)
+// The per-step render: the painter calibrated so far (the Ray raster's linear sweep of cell rows, or frame per wave) or the sweep of aligned
+// 4-KiB pieces (cw_kernels.hip: render_pieces)?  The latter's pace (eighths of a sleep per 1-KiB store) is checked, then the faster of the two
+// is kept -- the same launches, queued the same way, for both.
+static int calibrate_piece_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
-    if (e->P.raster != CW_RASTER_ALT || !tn.alt_sweep || !cwk_render_is_alt_sweep(&e->P, &tn)) return CW_OK;
-    {   // the extra (quarter) sleeps while envs are reset beside the sweep: bits 12-15 of render_pace, the number cw_step's tuner follows
+    if (!tn.piece_sweep || !cwk_render_is_piece_sweep(&e->P, &tn)) return CW_OK;
+    // the extra QUARTER sleeps per store while envs are being reset beside the sweep: bits 12-15 of render_pace, the number cw_step's tuner follows
+    // from here (episode phases spread out, 65 536 envs: 0 / 2 / 4 / 6 / 8 / 12 extra = 0.250-0.260 / 0.236-0.257 / 0.238-0.248 / 0.234-0.237 /
+    // 0.241 / 0.241-0.248 ms, profiles/r03_pieces.txt; AltObs: 4)
+    auto set_beside = [&]() {
         const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = (tn.render_pace & ~0xF000) | (((beside ? atoi(beside) : 2) & 15) << 12);
-    }
+        tn.render_pace = (tn.render_pace & ~0xF000) | (((beside ? atoi(beside) : e->P.raster == CW_RASTER_ALT ? 4 : 6) & 15) << 12);
+    };
 #ifdef CW_EXPERIMENT
-    const char *forced = getenv("CW_TUNE_ALT_SWEEP_PACE");
+    const char *forced = getenv("CW_TUNE_PIECE_PACE");
 #else
     const char *forced = nullptr;
 #endif
-    if (forced) { tn.alt_sweep_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; return CW_OK; }
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;
+    if (forced) { tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; set_beside(); return CW_OK; }
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (64ll << 20)) { set_beside(); return CW_OK; }
     double frames_ms = 0, t = 0, best_ms = 0;
-    tn.alt_sweep = 0;
+    tn.piece_sweep = 0;
     int rc = timed_render_median(e, &frames_ms);
-    tn.alt_sweep = 1;
-    // 2 (a sleep after every other store) is the optimum on every box measured, by a margin the launches timed here cannot resolve against
-    // its neighbours (profiles/r03_alt_sweep.txt; the same experience as with the Ray sweep's pace): another candidate has to beat it by 3 %
-    static const int quarters[] = {2, 0, 1, 4, 6, 8};
+    tn.piece_sweep = 1;
+    // 2 eighths (one s_sleep(1) after every fourth 1-KiB store) is the optimum in every step sequence measured (profiles/r03_pieces.txt: 0.2168 ms
+    // against 0.2208 at 3, 0.2240 at 4; unpaced is bistable, 0.214 or 0.250), by a margin the launches timed here cannot resolve against its
+    // neighbours -- the same experience as with the cell-row sweep's pace: another candidate has to beat it by 3 %
+    static const int eighths[] = {2, 0, 3, 4, 6, 8, 12};
     int best = 2;
     char log[256] = "";
     size_t len = 0;
-    for (size_t i = 0; i < sizeof(quarters) / sizeof(quarters[0]) && rc == CW_OK; i++) {
-        tn.alt_sweep_pace = quarters[i];
+    for (size_t i = 0; i < sizeof(eighths) / sizeof(eighths[0]) && rc == CW_OK; i++) {
+        tn.piece_pace = eighths[i];
         rc = timed_render_median(e, &t);
-        if (rc == CW_OK && (best_ms == 0 || t < 0.97 * best_ms)) { best_ms = t; best = quarters[i]; }
-        if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", quarters[i], t);
+        if (rc == CW_OK && (best_ms == 0 || t < 0.97 * best_ms)) { best_ms = t; best = eighths[i]; }
+        if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", eighths[i], t);
     }
     if (rc != CW_OK) return rc;
-    tn.alt_sweep_pace = best;
-    if (best_ms >= frames_ms) tn.alt_sweep = 0;
+    tn.piece_pace = best;
+    if (best_ms >= frames_ms) tn.piece_sweep = 0;
+    if (tn.piece_sweep) set_beside();
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] AltObs render: frame per wave %.4f ms; sweep of aligned pieces, ms per launch by quarter sleeps per store%s -> %s\n",
-                frames_ms, log, tn.alt_sweep ? "sweep" : "frame per wave");
+        fprintf(stderr, "[craftingworld] per-step render: %s %.4f ms; sweep of aligned pieces, ms per launch by eighths of a sleep per store%s -> %s\n",
+                cwk_render_is_linear(&e->P, &tn) ? "sweep of cell rows" : "frame per wave", frames_ms, log, tn.piece_sweep ? "pieces" : "the former");
     return CW_OK;
 }
 
@@ -753,9 +759,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         P.tune_reset_prio = 2;                               // the render waves raise their priority, the reset kernel beside them does not
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
         tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
+        tn.piece_sweep = geti("CW_TUNE_PIECE_SWEEP", tn.piece_sweep);
 #ifdef CW_EXPERIMENT
         P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);
-        tn.alt_sweep = geti("CW_TUNE_ALT_SWEEP", tn.alt_sweep);
         tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
         tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
         const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
@@ -859,22 +865,23 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
-    const int want_alt_sweep = e->tune.alt_sweep;
-    e->tune.alt_sweep = 0;                                       // (the frame-per-wave painter first: its pace and shares also serve the frames of resets)
+    const int want_piece_sweep = e->tune.piece_sweep;
+    e->tune.piece_sweep = 0;                                       // (the frame-per-wave painter first: its pace and shares also serve the frames of resets)
     if (rc == CW_OK) rc = calibrate_render_pace(e, false);
     if (rc == CW_OK) rc = calibrate_render_shares(e);
     if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
-    e->tune.alt_sweep = want_alt_sweep;
-    if (rc == CW_OK) rc = calibrate_alt_sweep(e);
+    e->tune.piece_sweep = want_piece_sweep;
+    if (rc == CW_OK) rc = calibrate_piece_sweep(e);
     if (rc == CW_OK) e->tune.render_pace |= (e->tune.render_pace_fine & 0xFF) << 16;
     if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
-        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_alt_sweep(&e->P, &e->tune)) && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
+        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_piece_sweep(&e->P, &e->tune)) && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
         a.cur = (e->tune.render_pace >> 12) & 15;
         if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
         a.pace_on = !getenv("CW_TUNE_RENDER_PACE_BESIDE");
         a.place = e->tune.render_place;
-        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) && cwk_render_is_linear(&e->P, &e->tune);
+        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) && cwk_render_is_linear(&e->P, &e->tune) &&
+                     !cwk_render_is_piece_sweep(&e->P, &e->tune);          // (the placements are render_groups': nothing to survey for the sweep of pieces)
         if (a.pace_on || a.place_on) {
             for (hipEvent_t &ev : a.ev)
                 if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
@@ -1191,7 +1198,7 @@ const char *cw_render_kernel_name(const cw_engine *e)
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
     const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
-    if (cwk_render_is_alt_sweep(&e->P, &e->tune)) return one_launch ? "cw_render_alt_step_kernel" : "cw_render_alt_kernel";
+    if (cwk_render_is_piece_sweep(&e->P, &e->tune)) return one_launch ? "cw_render_pieces_step_kernel" : "cw_render_pieces_kernel";
     if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
     return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
 }

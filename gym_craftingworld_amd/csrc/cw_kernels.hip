@@ -1411,18 +1411,25 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
     if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
-// ---- AltObs frames as a linear sweep of the frame array ---------------------------------------------------------------
-// An AltObs frame is a zero fill plus <= 19 lit pixels (render_frame_alt), so the sweep's jobs need not follow the frames at all: job j is
-// the j-th ALIGNED 4-KiB piece of the whole [N][3(S+1)][3S][3] array -- four 1-KiB stores of zeros, every lane a 16-byte chunk, no head or
-// tail bytes whatever the frame size -- followed by those bytes of the lit pixels of the one or two frames the piece overlaps that fall
-// inside it (three byte stores; lanes 0-31 hold the pixels of the first frame, 32-63 of the second).  Jobs go to the waves in address
-// order, four consecutive ones per workgroup, like render_groups' jobs (a CU writes 16 KiB contiguous; profiles/r03_wave_order.txt).
-// A frame whose env finished is left to its resetting wave: the piece's fill is clipped to the other frame byte by byte (rare path).
-// Records (agent, codes, positions, done flag of both frames of a job) are fetched a batch of 32 jobs ahead, one (job, frame) per lane.
-#define CW_ALT_JOB 4096u
+// ---- the frame array as a sweep of ALIGNED 4-KiB PIECES ---------------------------------------------------------------
+// Both rasters' frames are almost all zeros.  An AltObs frame is a zero fill plus <= 19 lit pixels (render_frame_alt); a Ray frame is
+// black (COLORS_N[0], ray.py:28) except the 4x4-pixel cells of its <= 8 objects and the agent's 2x2 mark (ray.py:476-486).  So the
+// sweep's jobs need not follow the frames, the pixel rows or the cells at all: job j is the j-th aligned 4-KiB piece of the frame array --
+// four 1-KiB stores of zeros, every lane one 16-byte chunk, the shape of a plain fill whatever the frame size -- followed by those bytes
+// of the lit items of the one or two frames the piece overlaps that fall inside it (lanes 0-31 hold the items of the first frame, 32-63
+// of the second; a wave's stores to one address are performed in program order, so the items land on the zeros):
+//   AltObs: lane = pixel (8 objects, agent, held item, 9 flag pixels of the strip), three byte stores;
+//   Ray   : lane = (object slot, pixel row of its cell): the 12 bytes of that row as three dwords, then (lanes of slot 0, rows 1 and 2)
+//           the agent's mark over whatever is there: bytes 3..8 of its cell's rows 1 and 2 = a byte, a dword, a byte.
+// Jobs go to the waves in address order, four consecutive ones per workgroup, like render_groups' jobs (a CU writes 16 KiB contiguous;
+// profiles/r03_wave_order.txt).  A frame whose env finished is left to its resetting wave: the piece's fill is clipped to the other
+// frame (rare path).  Records (agent, codes, positions, done flag of both frames of a job) are fetched a batch of 32 jobs ahead, one
+// (job, frame) per lane, and handed to the lanes that paint with ds_bpermute: no branch in the job but the pace loops.
+// The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
+#define CW_PIECE 4096u
 // the rare piece: one of its two frames belongs to a resetting wave, or it is the array's last, partial one -- zeros for the bytes of [a0, a1)
 // whose frame is not done (frame A before `bnd`, frame B from there on), 16-byte chunks where a whole chunk qualifies, single bytes otherwise
-__device__ __attribute__((noinline)) void alt_fill_clipped(uint8_t *dst_base, uint32_t a0, uint32_t a1, uint32_t bnd, uint32_t done_a, uint32_t done_b, int lane)
+__device__ __attribute__((noinline)) void piece_fill_clipped(uint8_t *dst_base, uint32_t a0, uint32_t a1, uint32_t bnd, uint32_t done_a, uint32_t done_b, int lane)
 {
     for (int s = 0; s < 4; s++) {
         const uint32_t c = a0 + 1024u * s + 16u * lane;
@@ -1434,30 +1441,37 @@ __device__ __attribute__((noinline)) void alt_fill_clipped(uint8_t *dst_base, ui
                 if (!(b < bnd ? done_a : done_b)) dst_base[b] = 0;
     }
 }
-__device__ __forceinline__ void render_alt_sweep(const CwParams &P, int skip_done, uint8_t *dst_base, int pace, int bid, int n_blocks)
+template <int RASTER>
+__device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, uint8_t *frames, int pace, int bid, int n_blocks, int env_lo, int env_n)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = bid * wpb + wave_in_block;
     const int n_waves = n_blocks * wpb;
-    const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = 9u * S;
-    const uint32_t total = (uint32_t)P.n_envs * FB;                          // (cw_alt_sweep: < 2^31)
-    const int n_jobs = (int)((total + CW_ALT_JOB - 1u) / CW_ALT_JOB);
+    const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = (RASTER == 1 ? 9u : 12u) * S;
+    uint8_t *const dst_base = frames + (size_t)env_lo * FB;
+    const uint32_t total = (uint32_t)env_n * FB;                             // (cw_piece_chunks: < 2^32)
+    const int n_jobs = (int)((total + CW_PIECE - 1u) / CW_PIECE);
     if (wave >= n_jobs) return;
     const int q_mine = (n_jobs + n_waves - 1) / n_waves;
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31u;
-    const uint32_t v_cpv = cpv_color(lane & 15);                            // lane k <= 8: CPV_COLORS[k]
-    const uint32_t m_slot = pl < 8u ? 0xFFFFFFFFu : 0u, m_agent = pl == 8u ? 0xFFFFFFFFu : 0u, m_held = pl == 9u ? 0xFFFFFFFFu : 0u;   // what lane pl paints
+    // what lane pl paints.  AltObs: pl = pixel (0..7 object slots, 8 agent, 9 held item, 10..18 flag).  Ray: pl = 4 slot + pixel row.
+    const uint32_t slot = RASTER == 1 ? (pl & 7u) : (pl >> 2), dy = pl & 3u;
+    const uint32_t v_table = RASTER == 1 ? cpv_color(lane & 15) : rgb_of_code((uint32_t)lane);       // lane k: CPV_COLORS[k] / COLORS_N[k]
+    const uint32_t m_slot = (RASTER != 1 || pl < 8u) ? 0xFFFFFFFFu : 0u, m_agent = pl == 8u ? 0xFFFFFFFFu : 0u, m_held = pl == 9u ? 0xFFFFFFFFu : 0u;
     const uint32_t m_flag = (pl >= 10u && pl < 19u) ? 0xFFFFFFFFu : 0u;
-    const uint32_t sh_pos = 16u * (pl & 1u), sh_item = 4u * (pl & 7u);
-    const uint32_t m_p0 = (pl & 6u) == 0u ? 0xFFFFFFFFu : 0u, m_p1 = (pl & 6u) == 2u ? 0xFFFFFFFFu : 0u;         // the positions dword of slot pl & 7
-    const uint32_t m_p2 = (pl & 6u) == 4u ? 0xFFFFFFFFu : 0u, m_p3 = (pl & 6u) == 6u ? 0xFFFFFFFFu : 0u;
+    const uint32_t sh_pos = 16u * (slot & 1u), sh_item = 4u * slot;
+    const uint32_t m_p0 = (slot & 6u) == 0u ? 0xFFFFFFFFu : 0u, m_p1 = (slot & 6u) == 2u ? 0xFFFFFFFFu : 0u;      // the positions dword of the slot
+    const uint32_t m_p2 = (slot & 6u) == 4u ? 0xFFFFFFFFu : 0u, m_p3 = (slot & 6u) == 6u ? 0xFFFFFFFFu : 0u;
     const uint32_t fj = pl >= 10u ? pl - 10u : 0u, fjr = (fj >= 6u) ? 2u : (fj >= 3u) ? 1u : 0u;
-    const uint32_t off_flag = (3u * S + fjr) * row_bytes + 9u + 3u * (fj - 3u * fjr);      // lanes pl 10..18: the strip's nine flag pixels
+    const uint32_t off_flag = (3u * S + fjr) * row_bytes + 9u + 3u * (fj - 3u * fjr);      // AltObs lanes pl 10..18: the strip's nine flag pixels
+    const bool marks = slot == 0u && (dy == 1u || dy == 2u);                 // Ray: the lanes that paint the agent's mark
     if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    // `pace`: quarter sleeps per 1-KiB store (bits 0-7), and bits 12-15 more while envs are being reset beside the sweep (as in render_groups)
-    const int pace_base = pace & 0xFF, pace_beside = skip_done ? ((pace >> 12) & 15) : 0;
+    // `pace`: EIGHTHS of a sleep per 1-KiB store (bits 0-7: 4 = an s_sleep(1) after every other store), and bits 12-15 QUARTERS more while
+    // envs are being reset beside the sweep (as in render_groups)
+    const int pace_base = pace & 0xFF, pace_beside = skip_done ? 2 * ((pace >> 12) & 15) : 0;
+    int owed = 0;
     struct Rec { int env, cnt; uint32_t hx, hw, done; uint4 p; };
     auto fetch = [&](int base) {
         Rec r;
@@ -1467,14 +1481,14 @@ __device__ __forceinline__ void render_alt_sweep(const CwParams &P, int skip_don
         r.env = -1; r.hx = 0; r.hw = 0; r.done = 0;
         r.p = make_uint4(0, 0, 0, 0);
         if (i < q_mine && id < n_jobs) {
-            const int f = (int)(((uint32_t)id * CW_ALT_JOB) / FB) + (lane & 1);
-            if (f < P.n_envs) {
+            const int f = (int)(((uint32_t)id * CW_PIECE) / FB) + (lane & 1);       // (frame index inside the chunk)
+            if (f < env_n) {
                 r.env = f;
-                const uint32_t *h = (const uint32_t *)(P.hdr + f);
+                const uint32_t *h = (const uint32_t *)(P.hdr + env_lo + f);
                 r.hx = h[0];
                 r.hw = h[3];
-                r.p = P.pos[f];
-                if (skip_done) r.done = P.done[f];
+                r.p = P.pos[env_lo + f];
+                if (skip_done) r.done = P.done[env_lo + f];
             }
         }
         return r;
@@ -1489,8 +1503,8 @@ __device__ __forceinline__ void render_alt_sweep(const CwParams &P, int skip_don
             const int env_a = __builtin_amdgcn_readlane(cur.env, 2 * k);
             if (env_a < 0) continue;                                         // (past the last job)
             const int env_b = __builtin_amdgcn_readlane(cur.env, 2 * k + 1);
-            const uint32_t a0 = (uint32_t)((base + k) * n_waves + wave) * CW_ALT_JOB;
-            const uint32_t a1 = min(a0 + CW_ALT_JOB, total);
+            const uint32_t a0 = (uint32_t)((base + k) * n_waves + wave) * CW_PIECE;
+            const uint32_t a1 = min(a0 + CW_PIECE, total);
             const uint32_t bnd = (uint32_t)(env_a + 1) * FB;                 // first byte of the second frame
             const bool two = bnd < a1 && env_b >= 0;
             const uint32_t done_a = __builtin_amdgcn_readlane(cur.done, 2 * k);
@@ -1498,16 +1512,14 @@ __device__ __forceinline__ void render_alt_sweep(const CwParams &P, int skip_don
             if (done_a && done_b) continue;
             // ---- the fill
             uint8_t *const job = dst_base + a0;
-            int owed = 0;
-            if (!(done_a | done_b) && a1 - a0 == CW_ALT_JOB) {
+            if (!(done_a | done_b) && a1 - a0 == CW_PIECE) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     *(uint4 *)(job + 1024 * s + 16 * lane) = make_uint4(0, 0, 0, 0);
-                    for (owed += pace_now; owed >= 4; owed -= 4) __builtin_amdgcn_s_sleep(1);  // (quarter sleeps per store, PACING above)
+                    for (owed += pace_now; owed >= 8; owed -= 8) __builtin_amdgcn_s_sleep(1);  // (PACING above)
                 }
-            } else alt_fill_clipped(dst_base, a0, a1, bnd, done_a, done_b, lane);
-            // ---- the lit pixels of both frames: lane (half, pl) = pixel pl of frame `half` (branch-free: the record by ds_bpermute from the
-            //      lane that fetched it, the colour from the table register)
+            } else piece_fill_clipped(dst_base, a0, a1, bnd, done_a, done_b, lane);
+            // ---- the lit items of both frames (branch-free: the record by ds_bpermute from the lane that fetched it, colours from the table register)
             const int src = (int)((2u * (uint32_t)k + half) << 2);
             const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hx);
             const uint32_t hw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hw);
@@ -1515,30 +1527,52 @@ __device__ __forceinline__ void render_alt_sweep(const CwParams &P, int skip_don
                                 ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.w) & m_p3);
             const bool frame_on = half ? (two && !done_b) : !done_a;
             const uint32_t f_base = half ? bnd : bnd - FB;
-            const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+            const uint32_t win = a1 - a0;                                    // (x - a0 < win: x inside the piece)
             const uint32_t hold = (hx >> 16) & 0xFFu;
-            // pl 0..7: object slots; 8: the agent, pixel 8 (altobs.py:536); 9: the held item, on its own object pixel at the agent's cell
-            const uint32_t pos = (((pd >> sh_pos) & 0xFFFFu) & m_slot) | (agent_cell & ~m_slot);
-            const uint32_t item = (((hw >> sh_item) & 15u) & m_slot) | (9u & m_agent) | (hold & m_held);
-            const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
-            const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
-            const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
-            const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_cpv);
-            const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
-            const bool is_flag = (m_flag & hold) != 0;                                // the strip's flag (altobs.py:557-559)
-            uint32_t p_off = is_obj ? off_obj : is_flag ? off_flag : 0xFFFFFFFFu;
-            uint32_t p_val = is_obj ? col_obj : 0x00FFFFFFu;
-            // the held item's pixel on top of an object's: one store of the sum, byte-wise modulo 256 (render_frame_alt)
-            const uint32_t held_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & 32u) + 9u) << 2), (int)p_off);
-            const bool twice = pl < 8u && p_off != 0xFFFFFFFFu && p_off == held_off;
-            p_val = twice ? (((2u * (p_val & 0xFFu)) & 0xFFu) | ((2u * (p_val & 0xFF00u)) & 0xFF00u) | ((2u * (p_val & 0xFF0000u)) & 0xFF0000u)) : p_val;
-            const unsigned long long m_twice = CW_BALLOT(twice);
-            p_off = (pl == 9u && ((m_twice >> (32u * half)) & 0xFFFFFFFFull)) ? 0xFFFFFFFFu : p_off;
-            if (frame_on && p_off != 0xFFFFFFFFu) {
-                const uint32_t at = f_base + p_off;
-                if (at >= a0 && at < a1) dst_base[at] = (uint8_t)p_val;
-                if (at + 1u >= a0 && at + 1u < a1) dst_base[at + 1u] = (uint8_t)(p_val >> 8);
-                if (at + 2u >= a0 && at + 2u < a1) dst_base[at + 2u] = (uint8_t)(p_val >> 16);
+            if (RASTER == 1) {
+                const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+                // pl 0..7: object slots; 8: the agent, pixel 8 (altobs.py:536); 9: the held item, on its own object pixel at the agent's cell
+                const uint32_t pos = (((pd >> sh_pos) & 0xFFFFu) & m_slot) | (agent_cell & ~m_slot);
+                const uint32_t item = (((hw >> sh_item) & 15u) & m_slot) | (9u & m_agent) | (hold & m_held);
+                const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
+                const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
+                const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
+                const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_table);
+                const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
+                const bool is_flag = (m_flag & hold) != 0;                            // the strip's flag (altobs.py:557-559)
+                uint32_t p_off = is_obj ? off_obj : is_flag ? off_flag : 0xFFFFFFFFu;
+                uint32_t p_val = is_obj ? col_obj : 0x00FFFFFFu;
+                // the held item's pixel on top of an object's: one store of the sum, byte-wise modulo 256 (render_frame_alt)
+                const uint32_t held_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & 32u) + 9u) << 2), (int)p_off);
+                const bool twice = pl < 8u && p_off != 0xFFFFFFFFu && p_off == held_off;
+                p_val = twice ? (((2u * (p_val & 0xFFu)) & 0xFFu) | ((2u * (p_val & 0xFF00u)) & 0xFF00u) | ((2u * (p_val & 0xFF0000u)) & 0xFF0000u)) : p_val;
+                const unsigned long long m_twice = CW_BALLOT(twice);
+                p_off = (pl == 9u && ((m_twice >> (32u * half)) & 0xFFFFFFFFull)) ? 0xFFFFFFFFu : p_off;
+                if (frame_on && p_off != 0xFFFFFFFFu) {
+                    const uint32_t at = f_base + p_off;
+                    if (at - a0 < win) dst_base[at] = (uint8_t)p_val;
+                    if (at + 1u - a0 < win) dst_base[at + 1u] = (uint8_t)(p_val >> 8);
+                    if (at + 2u - a0 < win) dst_base[at + 2u] = (uint8_t)(p_val >> 16);
+                }
+            } else {
+                // the object of this lane's slot: pixel row dy of its cell, 12 bytes R G B R | G B R G | B R G B (ray.py:476-481)
+                const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
+                const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
+                const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
+                const u32x3 d = cell_row_dwords((uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table));
+                const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
+                if (is_obj && seg - a0 < win) *(uint32_t *)(dst_base + seg) = d.x;
+                if (is_obj && seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
+                if (is_obj && seg + 8u - a0 < win) *(uint32_t *)(dst_base + seg + 8u) = d.z;
+                // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
+                // the colour of what it holds (ray.py:483-486)
+                const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
+                const uint32_t held_rgb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hold & 15u) << 2), (int)v_table);
+                const uint32_t o = (dy == 2u && hold != 0) ? held_rgb : 0x00FFFFFFu;
+                const bool is_mark = frame_on && marks;
+                if (is_mark && aseg - a0 < win) dst_base[aseg + 3u] = (uint8_t)o;
+                if (is_mark && aseg + 4u - a0 < win) *(uint32_t *)(dst_base + aseg + 4u) = (o >> 8) | (o << 16);
+                if (is_mark && aseg + 8u - a0 < win) dst_base[aseg + 8u] = (uint8_t)(o >> 16);
             }
         }
     }
@@ -1571,15 +1605,17 @@ __global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, 
     if ((int)blockIdx.x < render_blocks) render_jobs<3>(P, 1, nullptr, q_all, fast_parity, pace, (int)blockIdx.x, render_blocks);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
-// the AltObs raster's sweep (render_alt_sweep), alone (cw_render / calibration) and with the step's resetting workgroups beside it
-__global__ __launch_bounds__(256) void cw_render_alt_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace)
+// the sweep of aligned pieces (render_pieces), alone (cw_render / two-stream step / calibration) and with the step's resetting workgroups beside it
+template <int RASTER>
+__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace, int env_lo, int env_n)
 {
-    render_alt_sweep(P, skip_done, mode == 2 ? ext_out : P.obs, pace, (int)blockIdx.x, (int)gridDim.x);
+    render_pieces<RASTER>(P, skip_done, mode == 2 ? ext_out : P.obs, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
 }
-__global__ __launch_bounds__(256) void cw_render_alt_step_kernel(CwParams P, int render_blocks, int pace)
+template <int RASTER>
+__global__ __launch_bounds__(256) void cw_render_pieces_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_alt_sweep(P, 1, P.obs, pace, (int)blockIdx.x, render_blocks);
+    if ((int)blockIdx.x < render_blocks) render_pieces<RASTER>(P, 1, P.obs, pace, (int)blockIdx.x, render_blocks, env_lo, env_n);
     else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
 }
 // the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
@@ -1776,10 +1812,28 @@ static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
     if (!tn.render_linear || P.raster != 0 || P.grp_rows <= 0) return 0;
     return (long long)P.n_envs * P.grp_per_frame < (1ll << 30);
 }
-// AltObs raster: the aligned-piece sweep (render_alt_sweep) where a piece overlaps at most two frames and 32-bit offsets do
-static inline int cw_alt_sweep(const CwParams &P, const CwTuning &tn)
+// the sweep of aligned pieces (render_pieces): frames of at least one piece, so that a piece overlaps at most two of them.  AltObs frames are
+// not multiples of 16 bytes, so only a sweep from env 0 is aligned: one launch, 32-bit offsets
+static inline int cw_piece_sweep(const CwParams &P, const CwTuning &tn)
 {
-    return tn.alt_sweep && P.raster == 1 && P.frame_bytes >= CW_ALT_JOB && (long long)P.n_envs * P.frame_bytes < (1ll << 31);
+    if (!tn.piece_sweep || P.frame_bytes < CW_PIECE) return 0;
+    return P.raster == 1 ? (long long)P.n_envs * P.frame_bytes < (1ll << 31) : (long long)P.n_envs * P.frame_bytes / CW_PIECE < (1ll << 30);
+}
+// ... in chunks of consecutive envs (Ray frames are multiples of 16 bytes: every chunk starts aligned) of about as many bytes as the linear
+// sweep's chunks, cw_sweep_chunks below: render_chunk_rounds jobs of 3 KB per wave, 2.8 GB -- 32-bit offsets inside a chunk
+static inline int cw_piece_chunks(const CwParams &P, const CwTuning &tn, int *per)
+{
+    *per = P.n_envs;
+    if (P.raster == 1) return 1;
+    const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
+    const long long cap = (long long)(tn.render_chunk_rounds > 0 ? tn.render_chunk_rounds : 1 << 20) * waves * 3072;
+    const long long bytes = (long long)P.n_envs * P.frame_bytes;
+    int n = (int)((bytes + cap - 1) / cap);
+    if (n < 1) n = 1;
+    *per = (P.n_envs + n - 1) / n;
+    if (n > 1) *per = (int)(((long long)*per + waves - 1) / waves * waves);
+    while ((long long)*per * P.frame_bytes >= (1ll << 32)) *per = (*per + 1) / 2;      // (tiny chunk_rounds settings aside, never taken)
+    return (P.n_envs + *per - 1) / *per;
 }
 // -> number of chunks; *per = envs per chunk (the last one may be shorter)
 static inline int cw_sweep_chunks(const CwParams &P, const CwTuning &tn, int *per)
@@ -1816,14 +1870,20 @@ static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int m
                                     int fast_parity, hipStream_t st)
 {
     const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_render_linear(P, tn)) {
+    if (cw_piece_sweep(P, tn) && (mode == 2 || mode == 3)) {
+        int per = 0;
+        const int n_chunks = cw_piece_chunks(P, tn, &per);
+        const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
+        for (int c = 0; c < n_chunks; c++)
+            if (P.raster == 1) hipLaunchKernelGGL(cw_render_pieces_kernel<1>, grid, block, 0, st, P, mode, skip_done, ext_out, pace, c * per, min(per, P.n_envs - c * per));
+            else hipLaunchKernelGGL(cw_render_pieces_kernel<0>, grid, block, 0, st, P, mode, skip_done, ext_out, pace, c * per, min(per, P.n_envs - c * per));
+    } else if (cw_render_linear(P, tn)) {
         int per = 0;
         const int n_chunks = cw_sweep_chunks(P, tn, &per);
         for (int c = 0; c < n_chunks; c++)
             hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace, c * per,
                                min(per, P.n_envs - c * per));
-    } else if (cw_alt_sweep(P, tn) && (mode == 2 || mode == 3))
-        hipLaunchKernelGGL(cw_render_alt_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, tn.alt_sweep_pace | (tn.render_pace & 0xF000));
+    }
     else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
@@ -1886,7 +1946,18 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
         // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/history/r02_fused_render.txt H)
         int reset_blocks = (int)reset_grid.x;
         if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-        if (cw_render_linear(*P, tn)) {
+        if (cw_piece_sweep(*P, tn)) {
+            int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
+            const int n_chunks = cw_piece_chunks(*P, tn, &per);
+            const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
+            for (int c = 0; c < n_chunks; c++)
+                if (P->raster == 1)
+                    hipLaunchKernelGGL(cw_render_pieces_step_kernel<1>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
+                                       c * per, min(per, n - c * per));
+                else
+                    hipLaunchKernelGGL(cw_render_pieces_step_kernel<0>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
+                                       c * per, min(per, n - c * per));
+        } else if (cw_render_linear(*P, tn)) {
             typedef void (*StepRenderFn)(CwParams, int, int, int, int);
             static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
                                                                cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
@@ -1897,8 +1968,6 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
                 hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
                                    render_blocks, tn.render_pace, c * per, min(per, n - c * per));
         }
-        else if (cw_alt_sweep(*P, tn))
-            hipLaunchKernelGGL(cw_render_alt_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks, tn.alt_sweep_pace | (tn.render_pace & 0xF000));
         else
             hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
                                tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
@@ -2009,10 +2078,10 @@ hipError_t cwk_launch_idle(hipStream_t st)
 }
 
 int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
-int cwk_render_is_alt_sweep(const CwParams *P, const CwTuning *T) { return cw_alt_sweep(*P, *T); }
+int cwk_render_is_piece_sweep(const CwParams *P, const CwTuning *T) { return cw_piece_sweep(*P, *T); }
 int cwk_render_jobs(const CwParams *P, const CwTuning *T)
 {
-    if (cw_alt_sweep(*P, *T)) return (int)(((long long)P->n_envs * P->frame_bytes + CW_ALT_JOB - 1) / CW_ALT_JOB);
+    if (cw_piece_sweep(*P, *T)) return (int)(((long long)P->n_envs * P->frame_bytes + CW_PIECE - 1) / CW_PIECE);
     return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs;
 }
 

@@ -51,8 +51,8 @@ struct CwTuning {
     int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
-    int alt_sweep = 1;              // AltObs raster: the per-step render as a sweep of aligned 4-KiB pieces (render_alt_sweep); cw_create keeps it if it measures faster than frame-per-wave
-    int alt_sweep_pace = 2;         // ... quarter sleeps per 1-KiB store (cw_create calibrates)
+    int piece_sweep = 1;            // the per-step render as a sweep of aligned 4-KiB pieces (render_pieces); cw_create keeps it if it measures faster than the other painter
+    int piece_pace = 2;             // ... eighths of an s_sleep(1) per 1-KiB store (2 = one after every fourth store; cw_create checks the neighbours)
     int render_linear = 1;          // full-frame render as a linear sweep (job = a run of whole grid rows); 0: frame per wave
     int render_chunk_rounds = 896;  // ... in launches of at most this many rounds per wave over consecutive env ranges: 131 072 envs at 21x21 (0: one launch whatever the batch)
     int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;

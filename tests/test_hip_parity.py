@@ -653,7 +653,7 @@ def test_altobs_raster_vs_oracle(obs_mode, S, N):
     obs = env.reset()
     ora.reset()
     assert tuple(obs['observation'].shape) == (N, 3 * S + 3, 3 * S, 3)
-    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_alt_kernel' if S >= 13 else 'cw_render_frames_kernel')      # (keep_terminal_obs: render and resets on two streams)
+    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_pieces_kernel' if S >= 13 else 'cw_render_frames_kernel')      # (keep_terminal_obs: render and resets on two streams)
     acts = np.random.RandomState(2).randint(0, 6, size=(T, N)).astype(np.int32)
     dacts = torch.as_tensor(acts, device=env.device)
     for t in range(T):
@@ -1069,6 +1069,7 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, exp
     from gym_craftingworld_amd import CraftingWorldVecEnv
     kw = dict(size=(21, 21), max_steps=9, seed=13)
     monkeypatch.setenv('CW_TUNE_RENDER_LINEAR', '0')
+    monkeypatch.setenv('CW_TUNE_PIECE_SWEEP', '0')
     if shares == 'off':
         monkeypatch.setenv('CW_TUNE_RENDER_SHARES', '0')
     else:
@@ -1078,6 +1079,7 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, exp
     monkeypatch.delenv('CW_TUNE_RENDER_SHARES', raising=False)
     monkeypatch.delenv('CW_TUNE_RENDER_QALL', raising=False)
     monkeypatch.delenv('CW_TUNE_RENDER_LINEAR')
+    monkeypatch.delenv('CW_TUNE_PIECE_SWEEP')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     of, od = full.reset(), dirty.reset()
     full.obs_fill = of['observation'].fill_(7)            # poison: a frame the kernel skipped would keep this value
@@ -1097,9 +1099,11 @@ def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, exp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
+                                           (3001, 10, 'ray'), (133, 128, 'ray'),
                                            (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'), (2999, 12, 'alt'),
                                            (3000, 21, 'alt-frames'), (65536, 21, 'alt-frames'), (1501, 32, 'alt-frames'),
-                                           (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked')])
+                                           (3000, 21, 'ray-rows'), (65536, 21, 'ray-rows'), (2000, 32, 'ray-rows'), (701, 70, 'ray-rows'),
+                                           (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked'), (3001, 21, 'ray-rows-chunked'), (70000, 21, 'ray-rows-chunked')])
 def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch, experiment_build):
     """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
     sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
@@ -1107,16 +1111,16 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch,
     (CW_TUNE_OVERLAP=0) -- and all three must leave exactly the frames, results and random streams of the dirty-cell engine,
     with episodes ending on every step (phases spread out) and all at once."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
-    if raster == 'ray-chunked':      # large batches are swept in several launches over consecutive env ranges (cw_sweep_chunks): here 5 / 14 of them,
-        raster = 'ray'               # the last one shorter, the resetting workgroups on the first
+    if raster.endswith('-chunked'):  # large batches are swept in several launches over consecutive env ranges (cw_piece_chunks / cw_sweep_chunks): here
+        raster = raster[:-8]         # 3-5 / 7-14 of them, the last one shorter, the resetting workgroups on the first
         monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '5' if N < 10000 else '35')
-    alt_sweep = False
-    if raster == 'alt':              # AltObs frames of at least 4 KiB: the per-step render is the sweep of aligned 4-KiB pieces (render_alt_sweep) ...
-        alt_sweep = 27 * size * (size + 1) >= 4096
-        monkeypatch.setenv('CW_TUNE_ALT_SWEEP_PACE', '1')       # (forced: cw_create would otherwise keep whichever painter it measures faster)
-    elif raster == 'alt-frames':     # ... or the frame-per-wave painter (smaller frames, very large batches, or when cw_create measures it faster)
-        raster = 'alt'
-        monkeypatch.setenv('CW_TUNE_ALT_SWEEP', '0')
+    # frames of at least 4 KiB: the per-step render is the sweep of aligned 4-KiB pieces (render_pieces) ...
+    pieces = raster in ('ray', 'alt') and (27 * size * (size + 1) if raster == 'alt' else 48 * size * size) >= 4096
+    if pieces:
+        monkeypatch.setenv('CW_TUNE_PIECE_PACE', '2')           # (forced: cw_create would otherwise keep whichever painter it measures faster)
+    else:                            # ... or the older painters (smaller frames, or when cw_create measures them faster): the Ray raster's sweep of
+        raster = raster[:3]          # cell rows (grids up to 64x64), else frame per wave
+        monkeypatch.setenv('CW_TUNE_PIECE_SWEEP', '0')
     kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
     engines = {}
     for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
@@ -1125,7 +1129,7 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch,
         engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
         if var:
             monkeypatch.delenv(var)
-    stem = 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_alt' if alt_sweep else 'cw_render_frames'      # linear sweeps; else the frame-per-wave painter
+    stem = 'cw_render_pieces' if pieces else 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_frames'
     assert engines['one launch'].render_kernel_name() == stem + '_step_kernel'
     assert engines['two streams'].render_kernel_name() == stem + '_kernel'
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
@@ -1819,7 +1823,7 @@ def test_bench_json_line_carries_the_contract():
     assert abs(d['value'] - 8192 * 40 / (d['ms_per_step'] * 40e-3)) < 1e-6 * d['value']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and 'traffic' in r
-    assert r['kernel'] == 'cw_render_step_kernel'
+    assert r['kernel'] in ('cw_render_pieces_step_kernel', 'cw_render_step_kernel')          # (whichever painter cw_create measured faster)
     assert r['avg_launch_ms'] > 0 and r['median_launch_ms'] > 0 and r['launch_ms_min_max'][0] <= r['median_launch_ms'] <= r['launch_ms_min_max'][1]
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1 and 0 < r['frac_at_median_launch'] < 1
     assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
@@ -1845,7 +1849,7 @@ def test_headline_perf_floor_of_the_sweep_kernel():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])                # the JSON line is the LAST line of rank 0's stdout
     r = d['roofline']
-    assert r['kernel'] == 'cw_render_step_kernel' and d['config']['envs_per_gpu'] == 65536
+    assert r['kernel'] in ('cw_render_pieces_step_kernel', 'cw_render_step_kernel') and d['config']['envs_per_gpu'] == 65536
     assert r['frac_at_median_launch'] >= 0.72, r
     assert d['value'] >= 2.45e8, d['value']                         # ... and the whole step (round 1: 2.30e8, rounds 2-3: 2.72-2.80e8)
 
@@ -1865,6 +1869,7 @@ def test_every_placement_of_the_sweep_loop_paints_the_same_frames():
     want = (ref._obs.clone(), ref._desired_img.clone(), ref._init_img.clone(), ref.reward.clone(), ref.hdr.clone(), ref.get_rng_states())
     ref.close()
     old = os.environ.get('CW_TUNE_RENDER_PLACE')
+    os.environ['CW_TUNE_PIECE_SWEEP'] = '0'                # (the placements are the cell-row sweep's)
     try:
         for k in range(8):
             os.environ['CW_TUNE_RENDER_PLACE'] = str(k)
@@ -1879,6 +1884,7 @@ def test_every_placement_of_the_sweep_loop_paints_the_same_frames():
             assert np.array_equal(keys[:, 1:], want[5][0][:, 1:]) and np.array_equal(pos, want[5][1]), k
             env.close()
     finally:
+        os.environ.pop('CW_TUNE_PIECE_SWEEP', None)
         if old is None:
             os.environ.pop('CW_TUNE_RENDER_PLACE', None)
         else:

@@ -28,7 +28,7 @@ for rep in $(seq 1 "$REPS"); do
       continue
     fi
     env $envs timeout -k 10 600 python bench.py --quick --steps 600 --warmup 20 $args 2>gpurun_out/last_arm.err | python -c "$fmt" "$label" | tee -a "$OUT"
-    grep -h "craftingworld\] placement\|craftingworld\] AltObs" gpurun_out/last_arm.err | cut -c1-260 | sed 's/^/      /' | tee -a "$OUT"
+    grep -h "craftingworld\] placement\|craftingworld\] per-step render" gpurun_out/last_arm.err | cut -c1-260 | sed 's/^/      /' | tee -a "$OUT"
   done < "$SPEC"
 done
 true

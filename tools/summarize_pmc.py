@@ -48,7 +48,7 @@ def main(out):
                                                 'median_bytes': v2[len(v2) // 2] * 1024.0}
     res['kernels'] = kern
     # the kernel of the full-frame render: one launch with the auto-resets (default) or the linear sweep alone
-    dom = 'cw_render_step_kernel' if 'cw_render_step_kernel' in kern else 'cw_render_kernel'
+    dom = next((k for k in ('cw_render_pieces_step_kernel', 'cw_render_step_kernel', 'cw_render_pieces_kernel') if k in kern), 'cw_render_kernel')
     r = kern.get(dom, {})
     if 'WRITE_SIZE' in r and 'FETCH_SIZE' in r:
         w, f = r['WRITE_SIZE']['median_bytes'], r['FETCH_SIZE']['median_bytes']
