@@ -408,6 +408,7 @@ static int calibrate_piece_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
     if (!tn.piece_sweep || !cwk_render_is_piece_sweep(&e->P, &tn)) return CW_OK;
+    tn.piece_pace = e->P.raster == CW_RASTER_ALT ? 4 : 0;
     // the extra QUARTER sleeps per store while envs are being reset beside the sweep: bits 12-15 of render_pace, the number cw_step's tuner follows
     // from here (episode phases spread out, 65 536 envs: 0 / 2 / 4 / 6 / 8 / 12 extra = 0.250-0.260 / 0.236-0.257 / 0.238-0.248 / 0.234-0.237 /
     // 0.241 / 0.241-0.248 ms, profiles/r03_pieces.txt; AltObs: 4)
@@ -426,14 +427,17 @@ static int calibrate_piece_sweep(cw_engine *e)
     tn.piece_sweep = 0;
     int rc = timed_render_median(e, &frames_ms);
     tn.piece_sweep = 1;
-    // 2 eighths (one s_sleep(1) after every fourth 1-KiB store) is the optimum in every step sequence measured (profiles/r03_pieces.txt: 0.2168 ms
-    // against 0.2208 at 3, 0.2240 at 4; unpaced is bistable, 0.214 or 0.250), by a margin the launches timed here cannot resolve against its
-    // neighbours -- the same experience as with the cell-row sweep's pace: another candidate has to beat it by 3 %
-    static const int eighths[] = {2, 0, 3, 4, 6, 8, 12};
-    int best = 2;
+    // Unpaced is the optimum in every step sequence measured since the job's LDS round trip left its critical path (profiles/r03_pieces.txt F:
+    // 0.2107-0.2121 ms in eight fresh processes on two boxes, 0.2137-0.2151 at one eighth, 0.2183 at two), by a margin the launches timed here
+    // cannot resolve against its neighbours -- the same experience as with the cell-row sweep's pace.  The write path has a slower, saturated
+    // regime (the first version of this sweep read 0.214 or 0.250 ms unpaced): a paced candidate replaces it when it reads 3 % faster
+    // (AltObs: 4 eighths, a sleep after every other store -- 0.1304-0.1322 ms on four boxes, profiles/r03_alt_sweep.txt)
+    static const int eighths_ray[] = {0, 1, 2, 4, 8}, eighths_alt[] = {4, 0, 2, 8, 12};
+    const int *eighths = e->P.raster == CW_RASTER_ALT ? eighths_alt : eighths_ray;
+    int best = eighths[0];
     char log[256] = "";
     size_t len = 0;
-    for (size_t i = 0; i < sizeof(eighths) / sizeof(eighths[0]) && rc == CW_OK; i++) {
+    for (size_t i = 0; i < 5 && rc == CW_OK; i++) {
         tn.piece_pace = eighths[i];
         rc = timed_render_median(e, &t);
         if (rc == CW_OK && (best_ms == 0 || t < 0.97 * best_ms)) { best_ms = t; best = eighths[i]; }

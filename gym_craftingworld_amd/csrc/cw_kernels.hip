@@ -1424,14 +1424,19 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
 // Jobs go to the waves in address order, four consecutive ones per workgroup, like render_groups' jobs (a CU writes 16 KiB contiguous;
 // profiles/r03_wave_order.txt).  A frame whose env finished is left to its resetting wave: the piece's fill is clipped to the other
 // frame (rare path).  Records (agent, codes, positions, done flag of both frames of a job) are fetched a batch of 32 jobs ahead, one
-// (job, frame) per lane, and handed to the lanes that paint with ds_bpermute: no branch in the job but the pace loops.
+// (job, frame) per lane, and handed to the lanes that paint with ds_bpermute -- asked for before the fill's stores, used after them; no other
+// LDS or memory round trip and no branch in a job but the pace loops and the stores' own predicates.
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
-#define CW_PIECE 4096u
+#ifndef CW_PIECE_BYTES
+#define CW_PIECE_BYTES 4096
+#endif
+#define CW_PIECE ((uint32_t)CW_PIECE_BYTES)
+#define CW_PIECE_STORES (CW_PIECE_BYTES / 1024)
 // the rare piece: one of its two frames belongs to a resetting wave, or it is the array's last, partial one -- zeros for the bytes of [a0, a1)
 // whose frame is not done (frame A before `bnd`, frame B from there on), 16-byte chunks where a whole chunk qualifies, single bytes otherwise
 __device__ __attribute__((noinline)) void piece_fill_clipped(uint8_t *dst_base, uint32_t a0, uint32_t a1, uint32_t bnd, uint32_t done_a, uint32_t done_b, int lane)
 {
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < CW_PIECE_STORES; s++) {
         const uint32_t c = a0 + 1024u * s + 16u * lane;
         const bool in_a = c + 16u <= bnd, in_b = c >= bnd;
         const bool whole = c + 16u <= a1 && (in_a ? !done_a : in_b ? !done_b : false);
@@ -1447,8 +1452,16 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = bid * wpb + wave_in_block;
     const int n_waves = n_blocks * wpb;
+#if defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 1
+    const int wave = wave_in_block * n_blocks + bid;
+#elif defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 2
+    const int wave = ((wave_in_block >> 1) * n_blocks + bid) * 2 + (wave_in_block & 1);
+#elif defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 5
+    const int wave = (bid & 7) * (n_waves >> 3) + (bid >> 3) * wpb + wave_in_block;
+#else
+    const int wave = bid * wpb + wave_in_block;
+#endif
     const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = (RASTER == 1 ? 9u : 12u) * S;
     uint8_t *const dst_base = frames + (size_t)env_lo * FB;
     const uint32_t total = (uint32_t)env_n * FB;                             // (cw_piece_chunks: < 2^32)
@@ -1458,7 +1471,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31u;
     // what lane pl paints.  AltObs: pl = pixel (0..7 object slots, 8 agent, 9 held item, 10..18 flag).  Ray: pl = 4 slot + pixel row.
     const uint32_t slot = RASTER == 1 ? (pl & 7u) : (pl >> 2), dy = pl & 3u;
-    const uint32_t v_table = RASTER == 1 ? cpv_color(lane & 15) : rgb_of_code((uint32_t)lane);       // lane k: CPV_COLORS[k] / COLORS_N[k]
+    const uint32_t v_cpv = cpv_color(lane & 15);                            // AltObs: lane k <= 8 holds CPV_COLORS[k]
     const uint32_t m_slot = (RASTER != 1 || pl < 8u) ? 0xFFFFFFFFu : 0u, m_agent = pl == 8u ? 0xFFFFFFFFu : 0u, m_held = pl == 9u ? 0xFFFFFFFFu : 0u;
     const uint32_t m_flag = (pl >= 10u && pl < 19u) ? 0xFFFFFFFFu : 0u;
     const uint32_t sh_pos = 16u * (slot & 1u), sh_item = 4u * slot;
@@ -1472,13 +1485,13 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
     // envs are being reset beside the sweep (as in render_groups)
     const int pace_base = pace & 0xFF, pace_beside = skip_done ? 2 * ((pace >> 12) & 15) : 0;
     int owed = 0;
-    struct Rec { int env, cnt; uint32_t hx, hw, done; uint4 p; };
+    struct Rec { int env, cnt; uint32_t hx, hw, done, o2; uint4 p; };       // (o2, Ray: the colour of row 2 of the agent's mark -- what it holds, else white)
     auto fetch = [&](int base) {
         Rec r;
         r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const int i = base + (lane >> 1);
         const int id = i * n_waves + wave;
-        r.env = -1; r.hx = 0; r.hw = 0; r.done = 0;
+        r.env = -1; r.hx = 0; r.hw = 0; r.done = 0; r.o2 = 0;
         r.p = make_uint4(0, 0, 0, 0);
         if (i < q_mine && id < n_jobs) {
             const int f = (int)(((uint32_t)id * CW_PIECE) / FB) + (lane & 1);       // (frame index inside the chunk)
@@ -1489,6 +1502,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
                 r.hw = h[3];
                 r.p = P.pos[env_lo + f];
                 if (skip_done) r.done = P.done[env_lo + f];
+                if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
             }
         }
         return r;
@@ -1510,21 +1524,31 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
             const uint32_t done_a = __builtin_amdgcn_readlane(cur.done, 2 * k);
             const uint32_t done_b = two ? (uint32_t)__builtin_amdgcn_readlane(cur.done, 2 * k + 1) : done_a;
             if (done_a && done_b) continue;
+            // ---- the records of the job's two frames, from the lanes that fetched them to the lanes that paint (asked for before the fill's stores
+            //      and sleeps, used after them: the LDS round trip is off the job's critical path)
+            //      (Ray raster.  The AltObs sweep keeps them after the fill, where they were when its pace was found: with them hoisted its launches
+            //      turn bimodal, 0.133 or 0.15 ms against a steady 0.131 -- profiles/r03_alt_sweep.txt C; the job's own delays are part of the pace)
+            const int src = (int)((2u * (uint32_t)k + half) << 2);
+            uint32_t hx = 0, hw = 0, o2 = 0, pd = 0;
+            auto gather = [&]() {
+                hx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hx);
+                hw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hw);
+                o2 = RASTER != 1 ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.o2) : 0u;
+                pd = ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.x) & m_p0) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.y) & m_p1) |
+                     ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.w) & m_p3);
+            };
+            if (RASTER != 1) gather();
             // ---- the fill
             uint8_t *const job = dst_base + a0;
             if (!(done_a | done_b) && a1 - a0 == CW_PIECE) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s < CW_PIECE_STORES; s++) {
                     *(uint4 *)(job + 1024 * s + 16 * lane) = make_uint4(0, 0, 0, 0);
                     for (owed += pace_now; owed >= 8; owed -= 8) __builtin_amdgcn_s_sleep(1);  // (PACING above)
                 }
             } else piece_fill_clipped(dst_base, a0, a1, bnd, done_a, done_b, lane);
-            // ---- the lit items of both frames (branch-free: the record by ds_bpermute from the lane that fetched it, colours from the table register)
-            const int src = (int)((2u * (uint32_t)k + half) << 2);
-            const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hx);
-            const uint32_t hw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hw);
-            const uint32_t pd = ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.x) & m_p0) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.y) & m_p1) |
-                                ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.w) & m_p3);
+            // ---- the lit items of both frames (branch-free: colours from select chains / the table register)
+            if (RASTER == 1) gather();
             const bool frame_on = half ? (two && !done_b) : !done_a;
             const uint32_t f_base = half ? bnd : bnd - FB;
             const uint32_t win = a1 - a0;                                    // (x - a0 < win: x inside the piece)
@@ -1537,7 +1561,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
                 const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
                 const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
                 const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
-                const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_table);
+                const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_cpv);      // (a select chain here compiles to branches)
                 const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
                 const bool is_flag = (m_flag & hold) != 0;                            // the strip's flag (altobs.py:557-559)
                 uint32_t p_off = is_obj ? off_obj : is_flag ? off_flag : 0xFFFFFFFFu;
@@ -1559,7 +1583,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
                 const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
                 const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
                 const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
-                const u32x3 d = cell_row_dwords((uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table));
+                const u32x3 d = cell_row_dwords(rgb_of_code(code));
                 const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
                 if (is_obj && seg - a0 < win) *(uint32_t *)(dst_base + seg) = d.x;
                 if (is_obj && seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
@@ -1567,8 +1591,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
                 // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
                 // the colour of what it holds (ray.py:483-486)
                 const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
-                const uint32_t held_rgb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hold & 15u) << 2), (int)v_table);
-                const uint32_t o = (dy == 2u && hold != 0) ? held_rgb : 0x00FFFFFFu;
+                const uint32_t o = dy == 2u ? o2 : 0x00FFFFFFu;
                 const bool is_mark = frame_on && marks;
                 if (is_mark && aseg - a0 < win) dst_base[aseg + 3u] = (uint8_t)o;
                 if (is_mark && aseg + 4u - a0 < win) *(uint32_t *)(dst_base + aseg + 4u) = (o >> 8) | (o << 16);

@@ -52,7 +52,7 @@ struct CwTuning {
     int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
     int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
     int piece_sweep = 1;            // the per-step render as a sweep of aligned 4-KiB pieces (render_pieces); cw_create keeps it if it measures faster than the other painter
-    int piece_pace = 2;             // ... eighths of an s_sleep(1) per 1-KiB store (2 = one after every fourth store; cw_create checks the neighbours)
+    int piece_pace = 0;             // ... eighths of an s_sleep(1) per 1-KiB store (Ray raster: unpaced, AltObs: 4, unless cw_create measures another pace 3 % faster)
     int render_linear = 1;          // full-frame render as a linear sweep (job = a run of whole grid rows); 0: frame per wave
     int render_chunk_rounds = 896;  // ... in launches of at most this many rounds per wave over consecutive env ranges: 131 072 envs at 21x21 (0: one launch whatever the batch)
     int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;
