@@ -243,9 +243,11 @@ typedef struct cw_profile {
 int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
 /* Name of the kernel that ms_render_kernel brackets for this engine (what a rocprofv3 kernel trace of the same run lists it as):
- * "cw_render_step_kernel" / "cw_render_frames_step_kernel" (full-frame render + the auto-resets beside it, one launch; linear
- * sweep -- a trace lists its eight placements as cw_render_step_kernel<0> .. <7>, cw_step measures which one to launch -- / frame per wave), "cw_render_kernel" / "cw_render_frames_kernel" (the render alone), the step kernel's name in
- * CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
+ * "cw_render_pieces_step_kernel" / "cw_render_step_kernel" / "cw_render_frames_step_kernel" (full-frame render + the auto-resets beside it, one
+ * launch: the sweep of aligned 4-KiB pieces -- a trace lists it as cw_render_pieces_step_kernel<0> (Ray raster) or <1> (AltObs) --, the sweep of
+ * cell rows -- its eight placements are cw_render_step_kernel<0> .. <7>, cw_step measures which one to launch -- or frame per wave; cw_create
+ * times the painters on the engine's batch and keeps the fastest), "cw_render_pieces_kernel" / "cw_render_kernel" / "cw_render_frames_kernel"
+ * (the render alone), the step kernel's name in CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
 /* What cw_step's online tuner currently holds (full-frame mode, one-launch step): the placement k of the sweep's batch loop

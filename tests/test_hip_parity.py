@@ -1836,9 +1836,10 @@ def test_bench_json_line_carries_the_contract():
 @pytest.mark.gpu
 def test_headline_perf_floor_of_the_sweep_kernel():
     """The performance regime of the dominant kernel is a tested property: a fresh `bench.py --quick --steps 300` (BASELINE configs[2]:
-    65 536 envs, 21x21, full frames) must paint at >= 0.72 of the 8 TB/s HBM peak at its median launch (rounds 2-3 measured 0.756-0.785;
-    a build on the placement cliff of profiles/history/r02_pace.txt O reads 0.65).  The engine's survey of the eight loop placements runs inside
-    bench.py's untimed warm-up."""
+    65 536 envs, 21x21, full frames) must paint at >= 0.72 of the 8 TB/s HBM peak at its median launch (the sweep of aligned pieces measures
+    0.83-0.85, rounds 2-3's cell-row sweep 0.756-0.785 -- cw_create keeps whichever it times faster --; a build on the placement cliff of
+    profiles/history/r02_pace.txt O reads 0.65, the saturated regime of the piece sweep 0.70).  The engine's calibrations and surveys run at
+    cw_create and inside bench.py's untimed warm-up."""
     import json
     import subprocess
     import sys
