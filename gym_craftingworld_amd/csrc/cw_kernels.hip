@@ -2110,7 +2110,8 @@ int cwk_render_jobs(const CwParams *P, const CwTuning *T)
 
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
-    const CwTuning &tn = *T;
+    CwTuning tn = *T;
+    if ((uintptr_t)out & 15u) tn.piece_sweep = 0;      // (the pieces' 16-byte stores want an aligned array: any other pointer takes the older painters)
     cw_launch_render(*P, tn, 2, 0, out, tn.render_q_all, tn.render_fast_parity, st);
     return hipGetLastError();
 }

@@ -188,7 +188,8 @@ int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot /* 1: als
 int cw_resident_stop(cw_engine *e);
 
 /* render(state=None) for every env into a caller-supplied DEVICE buffer [N][P][P][3] (works in
- * every obs_mode; ray.py:442-520). */
+ * every obs_mode; ray.py:442-520).  Any pointer the rasteriser's stores accept (Ray: 4-byte aligned); a 16-byte
+ * aligned one is painted by the fastest kernel. */
 int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream);
 
 /* render(state) (ray.py:442-486) for caller-supplied one-hot states of ANY content: onehot is a DEVICE array [n_states][S][S][12]

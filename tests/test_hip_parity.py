@@ -682,6 +682,29 @@ def test_altobs_raster_vs_oracle(obs_mode, S, N):
     env.close()
 
 
+@pytest.mark.parametrize('raster,shift', [('ray', 4), ('ray', 12), ('alt', 1), ('alt', 6)])
+def test_render_into_a_buffer_of_any_alignment(raster, shift):
+    """cw_render paints a caller-supplied array: a 16-byte aligned one with the sweep of aligned pieces, any other pointer the rasteriser's
+    stores accept with the older painters -- the same frames either way, and nothing outside them."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N = 777
+    env = CraftingWorldVecEnv(N, size=(21, 21), max_steps=50, obs_mode='pixels', raster=raster, seed=3)
+    env.reset()
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    for t in range(12):
+        env.step(torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen))
+    want = env.render()
+    assert want.data_ptr() % 16 == 0 and torch.equal(want, env._obs)
+    n = want.numel()
+    raw = torch.full((n + 64,), 7, dtype=torch.uint8, device='cuda')
+    view = raw[shift:shift + n].view(want.shape)
+    assert view.data_ptr() % 16 == shift
+    got = env.render(out=view)
+    assert torch.equal(got, want)
+    assert int(raw[:shift].min()) == 7 and int(raw[shift + n:].min()) == 7 and int(raw[shift + n:].max()) == 7
+    env.close()
+
+
 def test_compute_reward_batch_matches_reference_rules():
     from gym_craftingworld_amd import CraftingWorldVecEnv
     env = CraftingWorldVecEnv(4, size=(5, 5), max_steps=77, obs_mode='state')
