@@ -1427,11 +1427,8 @@ __device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, 
 // (job, frame) per lane, and handed to the lanes that paint with ds_bpermute -- asked for before the fill's stores, used after them; no other
 // LDS or memory round trip and no branch in a job but the pace loops and the stores' own predicates.
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
-#ifndef CW_PIECE_BYTES
-#define CW_PIECE_BYTES 4096
-#endif
-#define CW_PIECE ((uint32_t)CW_PIECE_BYTES)
-#define CW_PIECE_STORES (CW_PIECE_BYTES / 1024)
+#define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/r03_pieces.txt G)
+#define CW_PIECE_STORES 4          // 1-KiB stores per piece
 // the rare piece: one of its two frames belongs to a resetting wave, or it is the array's last, partial one -- zeros for the bytes of [a0, a1)
 // whose frame is not done (frame A before `bnd`, frame B from there on), 16-byte chunks where a whole chunk qualifies, single bytes otherwise
 __device__ __attribute__((noinline)) void piece_fill_clipped(uint8_t *dst_base, uint32_t a0, uint32_t a1, uint32_t bnd, uint32_t done_a, uint32_t done_b, int lane)
@@ -1453,15 +1450,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int n_waves = n_blocks * wpb;
-#if defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 1
-    const int wave = wave_in_block * n_blocks + bid;
-#elif defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 2
-    const int wave = ((wave_in_block >> 1) * n_blocks + bid) * 2 + (wave_in_block & 1);
-#elif defined(CW_PIECE_ORDER) && CW_PIECE_ORDER == 5
-    const int wave = (bid & 7) * (n_waves >> 3) + (bid >> 3) * wpb + wave_in_block;
-#else
-    const int wave = bid * wpb + wave_in_block;
-#endif
+    const int wave = bid * wpb + wave_in_block;                             // (four consecutive pieces per workgroup)
     const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = (RASTER == 1 ? 9u : 12u) * S;
     uint8_t *const dst_base = frames + (size_t)env_lo * FB;
     const uint32_t total = (uint32_t)env_n * FB;                             // (cw_piece_chunks: < 2^32)
