@@ -122,9 +122,14 @@ struct cw_engine {
         int place_bad = 0;                     // consecutive counted windows more than 4 % above that
         unsigned surveys = 0;
         unsigned place_struck = 0;             // bit k: placement k was held and fell out of its regime (not held again in this process)
+        bool guard_on = false;                 // (3) the piece sweep runs unpaced and its regime is watched (cwh_regime_guard)
+        float guard[41] = {};
+        int guard_pace = 0;                    //     what the guard last said: 0 unpaced, 1 paced
+        bool guard_test = false;
     } adapt;
 };
-enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24 };
+enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24, CW_GUARD_PACE = 2 /* eighths */ };
+extern "C" int cwh_regime_guard(float *s, float ms, unsigned window);
 
 // ------------------------------------------------------------------------------ resident stepper (host side)
 // Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
@@ -228,6 +233,49 @@ int cwh_choose_place(const float *med, unsigned struck, int *n_candidates)
     std::sort(cand, cand + n, [&](int x, int y) { return med[x] < med[y] || (med[x] == med[y] && x < y); });
     if (n_candidates) *n_candidates = n;
     return n > 0 ? cand[(n - 1) / 2] : -1;
+}
+
+// The piece sweep's REGIME GUARD (adapt_tick), as a pure function fed one counted window (ms per step) at a time.  The unpaced sweep sits just
+// short of the write path's slower, saturated regime (profiles/r03_pieces.txt B, F, N); should a process find itself in it -- another box,
+// another driver, a neighbour on the memory system -- a paced sweep is the way out, 3 % slower than the good regime, 13 % faster than the bad.
+// So: windows more than 10 % above the best level seen, 32 in a row -> TRIAL of the paced sweep for 32 windows (the first two settle); if that is
+// 3 % faster than the 32 before it, it stays for the process (-> 2); otherwise back to unpaced, the level of those windows is the new normal
+// (the workload changed -- episode phases that spread out cost 12 % --, not the regime), and the next trial has to wait twice as long.
+// state: [0] best level, [1] bad windows in a row, [2] 0 watching / 1 trial / 2 rescued, [3] trial windows seen, [4] trial sum, [5] mean of the last
+// windows before the trial, [6] window of the earliest next trial, [7] hold-off, [8..39] ring of the last 32 levels, [40] ring position.
+// -> the pace to run from now on: 0 unpaced, 1 paced.
+int cwh_regime_guard(float *s, float ms, unsigned window)
+{
+    enum { BEST, BAD, STATE, TRIAL_N, TRIAL_SUM, BEFORE, NEXT, HOLD, RING = 8, POS = 40 };
+    if (s[STATE] == 2.f) return 1;
+    if (s[STATE] == 1.f) {
+        s[TRIAL_N] += 1.f;
+        if (s[TRIAL_N] > 2.f) s[TRIAL_SUM] += ms;
+        if (s[TRIAL_N] < 32.f) return 1;
+        const float trial = s[TRIAL_SUM] / 30.f;
+        if (trial < 0.97f * s[BEFORE]) { s[STATE] = 2.f; return 1; }
+        s[STATE] = 0.f;                                                    // no: the new normal
+        s[BEST] = s[BEFORE];
+        s[BAD] = 0.f;
+        s[HOLD] = s[HOLD] > 0.f ? 2.f * s[HOLD] : 256.f;
+        s[NEXT] = (float)window + s[HOLD];
+        return 0;
+    }
+    const int pos = (int)s[POS];
+    s[RING + pos] = ms;
+    s[POS] = (float)((pos + 1) & 31);
+    if (s[BEST] == 0.f || ms < s[BEST]) s[BEST] = ms;
+    s[BAD] = ms > 1.10f * s[BEST] ? s[BAD] + 1.f : 0.f;
+    if (s[BAD] >= 32.f && (float)window >= s[NEXT]) {
+        float sum = 0.f;
+        for (int i = 0; i < 32; i++) sum += s[RING + i];
+        s[BEFORE] = sum / 32.f;
+        s[STATE] = 1.f;
+        s[TRIAL_N] = 0.f;
+        s[TRIAL_SUM] = 0.f;
+        return 1;
+    }
+    return 0;
 }
 
 void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
@@ -508,6 +556,20 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
         a.stat_window[p] = cw;
         moved = true;
+        if (a.guard_on && p == a.cur) {                                       // (3) the unpaced piece sweep's regime
+            // (guard_test, experiment build: every watched window reads 20 % above the best level, so trials come round by themselves -- for the test
+            // that a trial changes no frame)
+            const int want = cwh_regime_guard(a.guard, a.guard_test && a.guard[2] == 0.f && a.guard[0] > 0.f ? 1.2f * a.guard[0] : ms, cw);
+            if (want != a.guard_pace) {
+                if (verbose) fprintf(stderr, "[craftingworld] regime guard (window %u): %.4f ms/step, best level %.4f -> %s\n", cw, ms, a.guard[0],
+                                     want ? (a.guard[2] == 2.f ? "the paced sweep stays" : "trying the paced sweep") : "back to the unpaced sweep (the workload changed, not the regime)");
+                a.guard_pace = want;
+                e->tune.piece_pace = want ? CW_GUARD_PACE : 0;
+            } else if (verbose && want && a.guard[2] == 2.f && a.guard[3] == 32.f) {
+                fprintf(stderr, "[craftingworld] regime guard (window %u): the paced sweep is 3 %% faster than the 32 windows before it: it stays\n", cw);
+                a.guard[3] = 33.f;
+            }
+        }
     }
     if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
         // Every survey window has been read.  WHICH placement to hold: not the fastest.  Placements come in three kinds (profiles/
@@ -888,7 +950,13 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         a.place = e->tune.render_place;
         a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) && cwk_render_is_linear(&e->P, &e->tune) &&
                      !cwk_render_is_piece_sweep(&e->P, &e->tune);          // (the placements are render_groups': nothing to survey for the sweep of pieces)
-        if (a.pace_on || a.place_on) {
+        // (3) only the Ray raster's unpaced piece sweep (AltObs runs paced already), and only if nobody forced a pace
+        a.guard_on = cwk_render_is_piece_sweep(&e->P, &e->tune) && e->P.raster != CW_RASTER_ALT && e->tune.piece_pace == 0 && !getenv("CW_TUNE_PIECE_PACE") &&
+                     !(getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 0);
+#ifdef CW_EXPERIMENT
+        a.guard_test = a.guard_on && getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 2;
+#endif
+        if (a.pace_on || a.place_on || a.guard_on) {
             for (hipEvent_t &ev : a.ev)
                 if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
             a.on = rc == CW_OK;

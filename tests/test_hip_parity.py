@@ -1184,6 +1184,44 @@ def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch,
 
 
 @pytest.mark.gpu
+def test_regime_guard_trials_change_no_frame(monkeypatch, capfd, experiment_build):
+    """cw_step's regime guard (cw_engine.cpp: cwh_regime_guard) watches the unpaced piece sweep: when its windows read 10 % above the best level seen
+    it tries the paced sweep for 32 windows and keeps it only if that is 3 % faster (decision logic: tests/test_host_logic.py).  Here the experiment
+    build's CW_TUNE_REGIME_GUARD=2 makes every watched window read "bad", so trials come round by themselves (after 32 windows, then after the
+    hold-off): the sweep's pace changes under a running step sequence -- frames, results and random streams stay those of the dirty-cell engine."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    monkeypatch.setenv('CW_TUNE_VERBOSE', '1')
+    monkeypatch.setenv('CW_TUNE_REGIME_GUARD', '2')
+    N, kw = 65536, dict(size=(21, 21), max_steps=300, seed=31)
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    monkeypatch.delenv('CW_TUNE_REGIME_GUARD')
+    if full.render_kernel_name() != 'cw_render_pieces_step_kernel':
+        pytest.skip('cw_create kept another painter on this box')
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    for e in (full, dirty):
+        e.reset()
+        e.set_state(step_num=((np.arange(N) * 7) % 300).astype(np.int32))
+    gen = torch.Generator(device='cuda').manual_seed(12)
+    acts = torch.randint(0, 6, (64, N), device='cuda', dtype=torch.uint8, generator=gen)
+    for t in range(1500):
+        of, rf, df, _ = full.step(acts[t % 64])
+        od, rd, dd, _ = dirty.step(acts[t % 64])
+        if t % 250 == 249:
+            assert torch.equal(rf, rd) and torch.equal(df, dd), t
+            for k in ('observation', 'desired_goal', 'init_observation'):
+                assert torch.equal(of[k], od[k]), (t, k)
+    torch.cuda.synchronize()
+    kf, pf = full.get_rng_states()
+    kd, pd = dirty.get_rng_states()
+    assert np.array_equal(kf, kd) and np.array_equal(pf, pd) and torch.equal(full.counters, dirty.counters)
+    err = capfd.readouterr().err
+    assert 'trying the paced sweep' in err, err[-2000:]
+    assert ('back to the unpaced sweep' in err) or ('it stays' in err), err[-2000:]
+    full.close()
+    dirty.close()
+
+
+@pytest.mark.gpu
 def test_full_frame_soak_with_the_online_tuner_equals_dirty_cell_engine(monkeypatch):
     """3 000 steps of 65 536 full-frame envs with the episode phases spread out (>= 32 resets beside every sweep, so the kernel uses
     the extra sleeps and cw_step's online tuner keeps changing them): every 250 steps all three frames, and at the end results,

@@ -268,3 +268,49 @@ def test_placement_survey_holds_the_median_placement_off_the_cliff():
     assert choose(headline, struck=1 << 1)[0] == 4                                  # the held placement fell out of its regime: next survey without it
     assert choose([0, 0, 0.25, 0, 0, 0, 0, 0]) == (2, 1) and choose([0.0] * 8) == (-1, 0)
     assert choose([0.25, 0.24, 0, 0, 0, 0, 0, 0], struck=3) == (-1, 0)
+
+
+def test_regime_guard_of_the_unpaced_piece_sweep():
+    """The decision of cw_step's regime guard (cwh_regime_guard, cw_engine.cpp: adapt_tick) on sequences of window levels (ms per step) like
+    the ones measured on MI355X (profiles/r03_pieces.txt): a steady run never leaves the unpaced sweep; the saturated regime (+17 %) is answered
+    by a trial of the paced sweep, which stays when it is 3 % faster; episode phases that spread out (+12 %, and the paced sweep no better) end
+    the trial, become the new normal, and the next trial has to wait."""
+    import ctypes as C
+    from gym_craftingworld_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+
+    def feed(state, levels, w0):
+        out = []
+        for i, ms in enumerate(levels):
+            out.append(lib.cwh_regime_guard(state, C.c_float(ms * (1 + 0.004 * rng.randn())), w0 + i))
+        return out
+
+    good, bad, paced, spread = 0.2181, 0.2560, 0.2250, 0.2462
+    s = (C.c_float * 41)()
+    assert set(feed(s, [good] * 2000, 0)) == {0}                                     # steady: nothing happens
+    assert set(feed(s, [good * 1.06] * 300, 2000)) == {0}                            # 6 % above the best level is not the other regime
+    # the saturated regime: 32 bad windows, then the trial; the paced sweep is 12 % faster than what was before it: it stays, for good
+    r = feed(s, [bad] * 40, 2300)
+    assert r[:31] == [0] * 31 and r[31:] == [1] * 9
+    r = feed(s, [paced] * 100, 2340)
+    assert set(r) == {1} and s[2] == 2.0
+    assert set(feed(s, [good] * 50, 2440)) == {1}
+    # phases that spread out: the trial (paced sweep no better) ends after 32 windows, the new level is the normal one, no further trial at that level
+    s = (C.c_float * 41)()
+    feed(s, [good] * 500, 0)
+    r = feed(s, [spread] * 32, 500)
+    assert r[-1] == 1 and r[:-1] == [0] * 31
+    r = feed(s, [spread * 0.995] * 32, 532)
+    assert r[:-1] == [1] * 31 and r[-1] == 0 and s[2] == 0.0 and abs(s[0] - spread) < 0.002
+    assert set(feed(s, [spread] * 3000, 564)) == {0}
+    # ... and should THAT level tip over (+17 % again), the next trial waits for the hold-off (256 windows after the failed one)
+    s = (C.c_float * 41)()
+    feed(s, [good] * 100, 0)
+    feed(s, [spread] * 32, 100)
+    feed(s, [spread] * 32, 132)                                                      # failed trial ends at window 163: next trial not before 163 + 256
+    r = feed(s, [spread * 1.17] * 200, 164)
+    assert set(r) == {0}
+    r = feed(s, [spread * 1.17] * 100, 364)
+    assert r.index(1) == 419 - 364 and set(r[419 - 364:419 - 364 + 31]) == {1}       # (a trial at last; this one fails too, and the hold-off doubles)
+    assert r[419 - 364 + 32] == 0 and s[7] == 512.0
