@@ -20,7 +20,7 @@ def lib_path():
         return EXP_LIB_PATH
     return LIB_PATH
 
-CW_ABI_VERSION = 2
+CW_ABI_VERSION = 3
 CW_MT_N = 624
 CW_MAX_TASKS = 16
 CW_MAX_MENUS = 256
@@ -67,7 +67,8 @@ class cw_profile(C.Structure):
 
 class cw_tuner_state(C.Structure):
     _fields_ = [('place', C.c_int32), ('surveys', C.c_int32), ('struck_mask', C.c_int32), ('sleeps_beside', C.c_int32),
-                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32)]
+                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32), ('painter', C.c_int32), ('piece_pace', C.c_int32),
+                ('guard_state', C.c_int32), ('guard_trials', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)

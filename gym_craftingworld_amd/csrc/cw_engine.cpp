@@ -126,6 +126,7 @@ struct cw_engine {
         float guard[41] = {};
         int guard_pace = 0;                    //     what the guard last said: 0 unpaced, 1 paced
         bool guard_test = false;
+        int guard_trials = 0;
     } adapt;
 };
 enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24, CW_GUARD_PACE = 2 /* eighths */ };
@@ -564,6 +565,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
                 if (verbose) fprintf(stderr, "[craftingworld] regime guard (window %u): %.4f ms/step, best level %.4f -> %s\n", cw, ms, a.guard[0],
                                      want ? (a.guard[2] == 2.f ? "the paced sweep stays" : "trying the paced sweep") : "back to the unpaced sweep (the workload changed, not the regime)");
                 a.guard_pace = want;
+                if (want) a.guard_trials++;
                 e->tune.piece_pace = want ? CW_GUARD_PACE : 0;
             } else if (verbose && want && a.guard[2] == 2.f && a.guard[3] == 32.f) {
                 fprintf(stderr, "[craftingworld] regime guard (window %u): the paced sweep is 3 %% faster than the 32 windows before it: it stays\n", cw);
@@ -1287,6 +1289,10 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
     out->sleeps_beside = a.on && a.pace_on ? a.cur : (e->tune.render_pace >> 12) & 15;
     out->place_tuned = a.on && a.place_on ? 1 : 0;
     out->sleeps_tuned = a.on && a.pace_on ? 1 : 0;
+    out->painter = cwk_render_is_piece_sweep(&e->P, &e->tune) ? 2 : cwk_render_is_linear(&e->P, &e->tune) ? 1 : 0;
+    out->piece_pace = e->tune.piece_pace;
+    out->guard_state = a.on && a.guard_on ? (int32_t)a.guard[2] : -1;
+    out->guard_trials = a.guard_trials;
     return CW_OK;
 }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 2   /* 2: cw_profile grew ms_render_kernel_median; cw_lookahead_join removed with the look-ahead prototype */
+#define CW_ABI_VERSION 3   /* 2: cw_profile grew ms_render_kernel_median; cw_lookahead_join removed with the look-ahead prototype.  3: cw_tuner_state grew painter .. guard_trials */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -257,6 +257,10 @@ const char *cw_render_kernel_name(const cw_engine *e);
  * Only performance depends on any of it. */
 typedef struct cw_tuner_state {
     int32_t place, surveys, struck_mask, sleeps_beside, place_tuned, sleeps_tuned;
+    /* which painter the full-frame step runs (cw_create timed them: 0 frame per wave, 1 sweep of cell rows, 2 sweep of aligned pieces), the
+     * piece sweep's pace in eighths of a sleep per 1-KiB store, and its regime guard: -1 off, 0 watching, 1 trial of the paced sweep under
+     * way, 2 the paced sweep was kept; how many trials it has run */
+    int32_t painter, piece_pace, guard_state, guard_trials;
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 

@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 2
+    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(lib, tmp_path):
