@@ -204,7 +204,8 @@ def main():
                          'number_of_tasks / stacking / reward_style per env)')
     ap.add_argument('--prewarm-steps', type=int, default=320,
                     help='untimed steps before the W warm-up steps (0: none): a card that idled through set-up runs its first ~100 launches 3-5 %% '
-                         'slower, and the engine surveys the eight placements of its sweep loop over its first 256 steps (cw_engine.cpp: adapt_tick); '
+                         'slower, and the engine\'s online tuner opens with surveys scheduled by step number (cw_engine.cpp: adapt_tick) -- the regime '
+                         'guard\'s paced windows against unpaced ones over steps 128-255, the cell-row sweep\'s eight placements over 256 steps; '
                          'reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')

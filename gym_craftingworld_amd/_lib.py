@@ -111,7 +111,7 @@ HOST_HELPERS = {
     'cwh_mt_to_numpy': (None, [_VP, C.c_int, _VP]),
     'cwh_mt_init_genrand': (None, [_VP, C.c_uint32]),
     'cwh_choose_place': (C.c_int, [C.POINTER(C.c_float), C.c_uint, C.POINTER(C.c_int)]),
-    'cwh_regime_guard': (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_uint]),
+    'cwh_regime_guard': (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_uint, C.c_int]),
     'cwh_dlpack_make': (_VP, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 

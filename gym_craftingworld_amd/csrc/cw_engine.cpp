@@ -28,6 +28,7 @@ hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, in
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
+hipError_t cwk_launch_step_render_calib(const CwParams *P, const CwTuning *T, int auto_reset, hipStream_t st);
 hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
                                    int *waves_per_block);
 int cwk_render_jobs(const CwParams *P, const CwTuning *T);
@@ -126,11 +127,13 @@ struct cw_engine {
         float guard[41] = {};
         int guard_pace = 0;                    //     what the guard last said: 0 unpaced, 1 paced
         bool guard_test = false;
-        int guard_trials = 0;
+        int guard_trials = 0, gpace_last = 0;
+        unsigned gsurvey_w0 = 16;
+        signed char gpace_of_window[CW_ADAPT_RING] = {};   // what the window was launched with: 0 unpaced, 1 paced, -1 the first after a change (not counted)
     } adapt;
 };
 enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24, CW_GUARD_PACE = 2 /* eighths */ };
-extern "C" int cwh_regime_guard(float *s, float ms, unsigned window);
+extern "C" int cwh_regime_guard(float *s, float ms, unsigned window, int ran_paced);
 
 // ------------------------------------------------------------------------------ resident stepper (host side)
 // Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
@@ -236,20 +239,41 @@ int cwh_choose_place(const float *med, unsigned struck, int *n_candidates)
     return n > 0 ? cand[(n - 1) / 2] : -1;
 }
 
-// The piece sweep's REGIME GUARD (adapt_tick), as a pure function fed one counted window (ms per step) at a time.  The unpaced sweep sits just
-// short of the write path's slower, saturated regime (profiles/r03_pieces.txt B, F, N); should a process find itself in it -- another box,
-// another driver, a neighbour on the memory system -- a paced sweep is the way out, 3 % slower than the good regime, 13 % faster than the bad.
-// So: windows more than 10 % above the best level seen, 32 in a row -> TRIAL of the paced sweep for 32 windows (the first two settle); if that is
-// 3 % faster than the 32 before it, it stays for the process (-> 2); otherwise back to unpaced, the level of those windows is the new normal
-// (the workload changed -- episode phases that spread out cost 12 % --, not the regime), and the next trial has to wait twice as long.
-// state: [0] best level, [1] bad windows in a row, [2] 0 watching / 1 trial / 2 rescued, [3] trial windows seen, [4] trial sum, [5] mean of the last
-// windows before the trial, [6] window of the earliest next trial, [7] hold-off, [8..39] ring of the last 32 levels, [40] ring position.
-// -> the pace to run from now on: 0 unpaced, 1 paced.
-int cwh_regime_guard(float *s, float ms, unsigned window)
+// The piece sweep's REGIME GUARD (adapt_tick), as a pure function fed one counted window at a time: its level (ms per step) and the pace it was LAUNCHED
+// with (0 unpaced, 1 paced; the host may be many windows ahead of the GPU, so what a window ran with is recorded when it starts, not inferred).
+// The unpaced sweep sits just short of the write path's slower, saturated regime (profiles/r03_pieces.txt B, F, N-P); should a process find itself in
+// it -- another build, another box, another driver, a neighbour on the memory system -- a paced sweep is the way out: 3 % slower than the good regime,
+// 13 % faster than the bad.
+//  * It opens with a SURVEY (state 3; the caller starts it with s[2] = 3, everything else 0): six unpaced windows, then six paced ones; paced 3 % faster than
+//    unpaced: it stays for the process (-> 2).  (Launches timed at cw_create, without the step kernel in between, do not show a build whose unpaced
+//    sweep is in the slower regime from its first step; and later there would be no better level to compare with.)
+//  * Watching (0): unpaced windows more than 10 % above the best level seen, 32 in a row -> TRIAL (1) of the paced sweep, 32 paced windows (the first
+//    two settle); 3 % faster than the 32 unpaced ones before it: it stays (-> 2); otherwise back to unpaced, the level of those windows is the new normal
+//    (the workload changed -- episode phases that spread out cost 12 % --, not the regime), and the next trial has to wait twice as long.
+// state: [0] best level, [1] bad windows in a row, [2] the state, [3] paced windows seen (trial) / unpaced (survey), [4] sum of them, [5] mean of the last
+// 32 unpaced windows before the trial / paced windows seen (survey), [6] window of the earliest next trial / sum of the paced ones (survey), [7] hold-off,
+// [8..39] ring of the last 32 unpaced levels, [40] ring position.
+// -> the pace to launch with from now on: 0 unpaced, 1 paced.
+int cwh_regime_guard(float *s, float ms, unsigned window, int ran_paced)
 {
     enum { BEST, BAD, STATE, TRIAL_N, TRIAL_SUM, BEFORE, NEXT, HOLD, RING = 8, POS = 40 };
     if (s[STATE] == 2.f) return 1;
+    if (s[STATE] == 3.f) {
+        if (ran_paced) { s[BEFORE] += 1.f; s[NEXT] += ms; if (ms > s[RING + 1]) s[RING + 1] = ms; }
+        else { s[TRIAL_N] += 1.f; s[TRIAL_SUM] += ms; if (ms > s[RING]) s[RING] = ms; }
+        const int n0 = (int)s[TRIAL_N], n1 = (int)s[BEFORE];
+        if (n0 < 6) return 0;
+        if (n1 < 6) return 1;
+        // (means without each side's slowest window: one may hold a step on which every env was reset)
+        const float unpaced_ms = (s[TRIAL_SUM] - s[RING]) / (float)(n0 - 1), paced_ms = (s[NEXT] - s[RING + 1]) / (float)(n1 - 1);
+        s[TRIAL_N] = s[TRIAL_SUM] = s[BEFORE] = s[NEXT] = s[RING] = s[RING + 1] = 0.f;
+        if (paced_ms < 0.97f * unpaced_ms) { s[STATE] = 2.f; s[BEST] = paced_ms; return 1; }
+        s[STATE] = 0.f;
+        s[BEST] = unpaced_ms;
+        return 0;
+    }
     if (s[STATE] == 1.f) {
+        if (!ran_paced) return 1;                                          // (launched before the trial began)
         s[TRIAL_N] += 1.f;
         if (s[TRIAL_N] > 2.f) s[TRIAL_SUM] += ms;
         if (s[TRIAL_N] < 32.f) return 1;
@@ -262,6 +286,7 @@ int cwh_regime_guard(float *s, float ms, unsigned window)
         s[NEXT] = (float)window + s[HOLD];
         return 0;
     }
+    if (ran_paced) return 0;                                               // (a straggler of a trial that has ended)
     const int pos = (int)s[POS];
     s[RING + pos] = ms;
     s[POS] = (float)((pos + 1) & 31);
@@ -428,17 +453,17 @@ static int calibrate_render_pace(cw_engine *e, bool refine)
     return CW_OK;
 }
 
-// median launch time of the per-step render as currently configured (launches queued back to back, one wait: see calibrate_render_pace)
-static int timed_render_median(cw_engine *e, double *out)
+// launch time of the per-step render as currently configured (launches queued back to back, one wait: see calibrate_render_pace): the median and the
+// 90th percentile of 20 launches -- the write path has a slower regime that a configuration may enter launch by launch (profiles/r03_pieces.txt N-P), and
+// a median does not show a configuration that does so one time in three
+static int timed_render_stats(cw_engine *e, double *median, double *p90)
 {
-    enum { LAUNCHES = 9, SKIP = 3 };
+    enum { LAUNCHES = 24, SKIP = 4 };
     hipEvent_t evs[2 * LAUNCHES] = {};
     bool ok = true;
     for (hipEvent_t &ev : evs) ok = ok && hipEventCreate(&ev) == hipSuccess;
-    int blocks = 0, wpb = 0;
     for (int rep = 0; rep < LAUNCHES && ok; rep++)
-        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess &&
-             cwk_launch_render_calib(&e->P, &e->tune, nullptr, e->tune.render_q_all, e->tune.render_fast_parity, &blocks, &wpb) == hipSuccess &&
+        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_step_render_calib(&e->P, &e->tune, e->auto_reset, nullptr) == hipSuccess &&
              hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     float ms[LAUNCHES];
@@ -446,7 +471,9 @@ static int timed_render_median(cw_engine *e, double *out)
     for (hipEvent_t &ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (!ok) return fail(CW_ERR_HIP, "cw_create: render calibration failed");
     std::sort(ms + SKIP, ms + LAUNCHES);
-    *out = ms[SKIP + (LAUNCHES - SKIP) / 2];
+    const int n = LAUNCHES - SKIP;
+    *median = ms[SKIP + n / 2];
+    *p90 = ms[SKIP + (9 * n) / 10 - 1];
     return CW_OK;
 }
 
@@ -474,33 +501,38 @@ static int calibrate_piece_sweep(cw_engine *e)
     // (batches down to 4 MB of frames are measured: which painter wins a launch-bound render depends on the shape -- 700 envs of 70x70: frame per wave
     // 0.028 ms, pieces 0.044)
     if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (4ll << 20)) { set_beside(); return CW_OK; }
-    double frames_ms = 0, t = 0, best_ms = 0;
+    double frames_ms = 0, frames_p90 = 0, t = 0, t90 = 0, best_p90 = 0;
     tn.piece_sweep = 0;
-    int rc = timed_render_median(e, &frames_ms);
+    int rc = timed_render_stats(e, &frames_ms, &frames_p90);
     tn.piece_sweep = 1;
-    // Unpaced is the optimum in every step sequence measured since the job's LDS round trip left its critical path (profiles/r03_pieces.txt F:
-    // 0.2107-0.2121 ms in eight fresh processes on two boxes, 0.2137-0.2151 at one eighth, 0.2183 at two), by a margin the launches timed here
-    // cannot resolve against its neighbours -- the same experience as with the cell-row sweep's pace.  The write path has a slower, saturated
-    // regime (the first version of this sweep read 0.214 or 0.250 ms unpaced): a paced candidate replaces it when it reads 3 % faster
-    // (AltObs: 4 eighths, a sleep after every other store -- 0.1304-0.1322 ms on four boxes, profiles/r03_alt_sweep.txt)
+    // Which pace.  The sweep runs fastest unpaced or nearly so -- just short of the write path's slower, saturated regime -- and how much pace it takes to
+    // stay clear of that regime depends on details of the build (the committed one: unpaced 0.2107-0.2121 ms in every process measured; a build two
+    // instructions per batch heavier: unpaced 0.229-0.244, one eighth bimodal 0.210 / 0.239, two eighths a steady 0.2089; profiles/r03_pieces.txt F, P).
+    // So the candidates are judged by their 90th-percentile launch, not their median: the smallest pace whose slow launches are within 1.5 % of the best
+    // candidate's.  (AltObs: 4 eighths first, a sleep after every other store -- 0.1304-0.1322 ms on four boxes, profiles/r03_alt_sweep.txt)
     static const int eighths_ray[] = {0, 1, 2, 4, 8}, eighths_alt[] = {4, 0, 2, 8, 12};
     const int *eighths = e->P.raster == CW_RASTER_ALT ? eighths_alt : eighths_ray;
-    int best = eighths[0];
-    char log[256] = "";
+    double p90s[5] = {0, 0, 0, 0, 0};
+    char log[320] = "";
     size_t len = 0;
     for (size_t i = 0; i < 5 && rc == CW_OK; i++) {
         tn.piece_pace = eighths[i];
-        rc = timed_render_median(e, &t);
-        if (rc == CW_OK && (best_ms == 0 || t < 0.97 * best_ms)) { best_ms = t; best = eighths[i]; }
-        if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f", eighths[i], t);
+        rc = timed_render_stats(e, &t, &t90);
+        p90s[i] = t90;
+        if (rc == CW_OK && (best_p90 == 0 || t90 < best_p90)) best_p90 = t90;
+        if (len < sizeof(log) - 24) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f/%.4f", eighths[i], t, t90);
     }
     if (rc != CW_OK) return rc;
+    int best = eighths[0];
+    for (size_t i = 0; i < 5; i++)
+        if (p90s[i] <= 1.015 * best_p90) { best = eighths[i]; break; }             // (the first in the list's order of preference)
     tn.piece_pace = best;
-    if (best_ms >= frames_ms) tn.piece_sweep = 0;
+    if (best_p90 >= frames_p90) tn.piece_sweep = 0;
     if (tn.piece_sweep) set_beside();
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] per-step render: %s %.4f ms; sweep of aligned pieces, ms per launch by eighths of a sleep per store%s -> %s\n",
-                cwk_render_is_linear(&e->P, &tn) ? "sweep of cell rows" : "frame per wave", frames_ms, log, tn.piece_sweep ? "pieces" : "the former");
+        fprintf(stderr, "[craftingworld] per-step render: %s %.4f/%.4f ms (median/90th percentile of 20 launches); sweep of aligned pieces by eighths of a sleep per store%s -> %s%s\n",
+                cwk_render_is_linear(&e->P, &tn) ? "sweep of cell rows" : "frame per wave", frames_ms, frames_p90, log, tn.piece_sweep ? "pieces, pace " : "the former",
+                tn.piece_sweep ? std::to_string(tn.piece_pace).c_str() : "");
     return CW_OK;
 }
 
@@ -548,6 +580,29 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             a.survey_seen++;
             continue;
         }
+        if (a.guard_on && timed) {                                            // (3) the piece sweep's regime: every timed window, whatever the extra pace beside resets
+            // (guard_test, experiment build: every watched window reads 20 % above the best level, so trials come round by themselves -- for the test
+            // that a trial changes no frame)
+            const int ran = a.gpace_of_window[cw % CW_ADAPT_RING];
+            if (ran >= 0) {                                                       // (else: the first window after a change of the pace settles)
+                const float state_before = a.guard[2];
+                const int want = cwh_regime_guard(a.guard, a.guard_test && a.guard[2] == 0.f && a.guard[0] > 0.f ? 1.2f * a.guard[0] : ms, cw, ran);
+                if (verbose && state_before == 3.f && a.guard[2] != 3.f)
+                    fprintf(stderr, "[craftingworld] regime guard, opening survey (window %u): %s (level %.4f ms/step)\n", cw,
+                            a.guard[2] == 2.f ? "the paced sweep is 3 % faster than the unpaced one: it stays" : "the unpaced sweep stays", a.guard[0]);
+                if (a.guard[2] == 3.f) {                                              // (the opening survey runs on its schedule)
+                } else if (want != a.guard_pace) {
+                    if (verbose && a.guard[2] != 3.f)
+                        fprintf(stderr, "[craftingworld] regime guard (window %u): %.4f ms/step, best level %.4f -> %s\n", cw, ms, a.guard[0],
+                                want ? (a.guard[2] == 2.f ? "the paced sweep stays" : "trying the paced sweep") : "the unpaced sweep (the paced one is not 3 % faster)");
+                    a.guard_pace = want;
+                    if (want && state_before != 3.f) a.guard_trials++;
+                } else if (verbose && want && a.guard[2] == 2.f && a.guard[3] == 32.f) {
+                    fprintf(stderr, "[craftingworld] regime guard (window %u): the paced sweep is 3 %% faster than the 32 windows before it: it stays\n", cw);
+                    a.guard[3] = 33.f;
+                }
+            }
+        }
         if (p < 0 || !timed) continue;
         // is the held placement still what it was?  (CONSECUTIVE windows: one holding an all-env reset step is followed by a normal one;
         // counted before the outlier filter below, which would take a placement that has tipped by 17 % for a reset storm 80 windows long)
@@ -557,21 +612,23 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
         a.stat_window[p] = cw;
         moved = true;
-        if (a.guard_on && p == a.cur) {                                       // (3) the unpaced piece sweep's regime
-            // (guard_test, experiment build: every watched window reads 20 % above the best level, so trials come round by themselves -- for the test
-            // that a trial changes no frame)
-            const int want = cwh_regime_guard(a.guard, a.guard_test && a.guard[2] == 0.f && a.guard[0] > 0.f ? 1.2f * a.guard[0] : ms, cw);
-            if (want != a.guard_pace) {
-                if (verbose) fprintf(stderr, "[craftingworld] regime guard (window %u): %.4f ms/step, best level %.4f -> %s\n", cw, ms, a.guard[0],
-                                     want ? (a.guard[2] == 2.f ? "the paced sweep stays" : "trying the paced sweep") : "back to the unpaced sweep (the workload changed, not the regime)");
-                a.guard_pace = want;
-                if (want) a.guard_trials++;
-                e->tune.piece_pace = want ? CW_GUARD_PACE : 0;
-            } else if (verbose && want && a.guard[2] == 2.f && a.guard[3] == 32.f) {
-                fprintf(stderr, "[craftingworld] regime guard (window %u): the paced sweep is 3 %% faster than the 32 windows before it: it stays\n", cw);
-                a.guard[3] = 33.f;
-            }
+    }
+    if (a.guard_on) {                                // what window w is launched with (the first window after a change settles and is not counted)
+        int gp = a.guard_pace;
+        bool skip = false;
+        if (a.guard[2] == 3.f) {
+            // the opening survey is SCHEDULED by window number, not steered by what has been read: a host that enqueues ahead (bench.py: hundreds of
+            // windows) gets the guard's answers that much later.  After the first 16 windows (a card that idled through set-up runs its first
+            // launches a few per cent slower): 4 unpaced, 4 paced, 4 unpaced, 4 paced (the first of each four settles), unpaced from there on until
+            // all of them have been read and the guard has decided (repeated if the windows were lost to the ring).
+            if (w >= a.gsurvey_w0 && w - a.gsurvey_w0 >= CW_ADAPT_RING + 16) a.gsurvey_w0 = w;
+            const unsigned j = w - a.gsurvey_w0;
+            gp = (w >= a.gsurvey_w0 && j < 16) ? (int)((j >> 2) & 1) : 0;
+            skip = w < a.gsurvey_w0 || (j < 16 && (j & 3) == 0) || j == 16;
         }
+        a.gpace_of_window[w % CW_ADAPT_RING] = (signed char)(gp != a.gpace_last || skip ? -1 : gp);
+        a.gpace_last = gp;
+        e->tune.piece_pace = gp ? CW_GUARD_PACE : 0;
     }
     if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
         // Every survey window has been read.  WHICH placement to hold: not the fastest.  Placements come in three kinds (profiles/
@@ -958,6 +1015,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
 #ifdef CW_EXPERIMENT
         a.guard_test = a.guard_on && getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 2;
 #endif
+        if (a.guard_on && !a.guard_test) a.guard[2] = 3.f;                    // (the opening survey)
         if (a.pace_on || a.place_on || a.guard_on) {
             for (hipEvent_t &ev : a.ev)
                 if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");

@@ -1917,6 +1917,45 @@ static int cw_envs_per_wave(int n)
     return epw;
 }
 
+// the one-launch render + resets of the full-frame step (cwk_launch_step; cw_create's calibrations time exactly this launch)
+static void cw_launch_fused_render(const CwParams &Pr, const CwTuning &tn, hipStream_t st)
+{
+    const CwParams *P = &Pr;
+    const int n = P->n_envs;
+    const dim3 reset_grid(cw_reset_grid(tn, n));
+    const int render_blocks = cw_render_grid(tn, n);
+    // resetting workgroups: one per CU.  Each costs the launch ~12 ns whether or not anything finished (+1.2 % per 256 of them on
+    // every step), and a step on which every env finishes at once is rare: 1 / 2 / 4 per CU = 2.62 / 2.60 / 2.55 x 10^8 env-steps/s
+    // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/history/r02_fused_render.txt H)
+    int reset_blocks = (int)reset_grid.x;
+    if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
+    if (cw_piece_sweep(*P, tn)) {
+        int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
+        const int n_chunks = cw_piece_chunks(*P, tn, &per);
+        const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
+        for (int c = 0; c < n_chunks; c++)
+            if (P->raster == 1)
+                hipLaunchKernelGGL(cw_render_pieces_step_kernel<1>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
+                                   c * per, min(per, n - c * per));
+            else
+                hipLaunchKernelGGL(cw_render_pieces_step_kernel<0>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
+                                   c * per, min(per, n - c * per));
+    } else if (cw_render_linear(*P, tn)) {
+        typedef void (*StepRenderFn)(CwParams, int, int, int, int);
+        static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
+                                                           cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
+                                                           cw_render_step_kernel<6>, cw_render_step_kernel<7>};
+        int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
+        const int n_chunks = cw_sweep_chunks(*P, tn, &per);
+        for (int c = 0; c < n_chunks; c++)
+            hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
+                               render_blocks, tn.render_pace, c * per, min(per, n - c * per));
+    }
+    else
+        hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
+                           tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
+}
+
 extern "C" {
 
 // FULL pixel step: render + auto-resets as one launch (cw_render_step_kernel)?
@@ -1952,37 +1991,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (ev_all) (void)hipEventRecord(ev[1], st);
     if (obs_mode == 1 && cwk_step_renders_fused(P, T, auto_reset)) {
         if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
-        const int render_blocks = cw_render_grid(tn, n);
-        // resetting workgroups: one per CU.  Each costs the launch ~12 ns whether or not anything finished (+1.2 % per 256 of them on
-        // every step), and a step on which every env finishes at once is rare: 1 / 2 / 4 per CU = 2.62 / 2.60 / 2.55 x 10^8 env-steps/s
-        // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/history/r02_fused_render.txt H)
-        int reset_blocks = (int)reset_grid.x;
-        if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-        if (cw_piece_sweep(*P, tn)) {
-            int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
-            const int n_chunks = cw_piece_chunks(*P, tn, &per);
-            const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
-            for (int c = 0; c < n_chunks; c++)
-                if (P->raster == 1)
-                    hipLaunchKernelGGL(cw_render_pieces_step_kernel<1>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
-                                       c * per, min(per, n - c * per));
-                else
-                    hipLaunchKernelGGL(cw_render_pieces_step_kernel<0>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
-                                       c * per, min(per, n - c * per));
-        } else if (cw_render_linear(*P, tn)) {
-            typedef void (*StepRenderFn)(CwParams, int, int, int, int);
-            static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
-                                                               cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
-                                                               cw_render_step_kernel<6>, cw_render_step_kernel<7>};
-            int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
-            const int n_chunks = cw_sweep_chunks(*P, tn, &per);
-            for (int c = 0; c < n_chunks; c++)
-                hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
-                                   render_blocks, tn.render_pace, c * per, min(per, n - c * per));
-        }
-        else
-            hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
-                               tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
+        cw_launch_fused_render(*P, tn, st);
         if (ev) (void)hipEventRecord(ev[5], st);
         return hipGetLastError();
     }
@@ -2075,6 +2084,15 @@ hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStre
     *blocks = cw_render_grid(tn, P->n_envs);
     *waves_per_block = tn.render_threads / CW_WAVE;
     cw_launch_render(*P, tn, 3, 0, nullptr, q_all, fast_parity, st);
+    return hipGetLastError();
+}
+// the render launch of cw_step itself, as cw_step would issue it (the one-launch kernel with its resetting workgroups, which find nothing to do):
+// where the unpaced sweep sits relative to the write path's slower regime depends on the very kernel (profiles/r03_pieces.txt N-P), so the
+// painter and the pace are chosen on this launch, not on the sweep alone
+hipError_t cwk_launch_step_render_calib(const CwParams *P, const CwTuning *T, int auto_reset, hipStream_t st)
+{
+    if (cwk_step_renders_fused(P, T, auto_reset)) cw_launch_fused_render(*P, *T, st);
+    else cw_launch_render(*P, *T, 3, auto_reset ? 1 : 0, nullptr, T->render_q_all, T->render_fast_parity, st);
     return hipGetLastError();
 }
 

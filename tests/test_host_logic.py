@@ -272,45 +272,69 @@ def test_placement_survey_holds_the_median_placement_off_the_cliff():
 
 def test_regime_guard_of_the_unpaced_piece_sweep():
     """The decision of cw_step's regime guard (cwh_regime_guard, cw_engine.cpp: adapt_tick) on sequences of window levels (ms per step) like
-    the ones measured on MI355X (profiles/r03_pieces.txt): a steady run never leaves the unpaced sweep; the saturated regime (+17 %) is answered
-    by a trial of the paced sweep, which stays when it is 3 % faster; episode phases that spread out (+12 %, and the paced sweep no better) end
-    the trial, become the new normal, and the next trial has to wait."""
+    the ones measured on MI355X (profiles/r03_pieces.txt), each window fed with the pace it was launched with -- here the host is `lag` windows
+    ahead of the GPU, as it is in a real run: the opening survey keeps the unpaced sweep where it is as fast, the paced one where the unpaced
+    sweep is in the slower regime from the start; a steady run never leaves the unpaced sweep; the saturated regime (+17 %) is answered by a
+    trial of the paced sweep, which stays when it is 3 % faster; episode phases that spread out (+12 %, and the paced sweep no better) end the
+    trial, become the new normal, and the next trial has to wait."""
     import ctypes as C
     from gym_craftingworld_amd import _lib
     lib = _lib.load()
     rng = np.random.RandomState(5)
 
-    def feed(state, levels, w0):
-        out = []
-        for i, ms in enumerate(levels):
-            out.append(lib.cwh_regime_guard(state, C.c_float(ms * (1 + 0.004 * rng.randn())), w0 + i))
-        return out
+    class Run:
+        """levels(pace) -> ms; the guard's answer takes effect `lag` windows after the window it was computed on"""
+        def __init__(self, lag, survey=True):
+            self.s = (C.c_float * 41)()
+            if survey:
+                self.s[2] = 3.0
+            self.lag, self.w, self.want, self.launched = lag, 0, 0, []
+            self.paces = []
+
+        def step(self, level_of):
+            self.launched.append(self.want)
+            if len(self.launched) > self.lag:
+                ran = self.launched[len(self.launched) - 1 - self.lag]
+                prev = self.launched[len(self.launched) - 2 - self.lag] if len(self.launched) - 2 - self.lag >= 0 else ran
+                if ran == prev:                                   # (the first window after a change settles: not fed)
+                    ms = level_of(ran) * (1 + 0.004 * rng.randn())
+                    self.want = lib.cwh_regime_guard(self.s, C.c_float(ms), self.w, ran)
+            self.w += 1
+            self.paces.append(self.want)
+
+        def run(self, n, level_of):
+            for _ in range(n):
+                self.step(level_of)
+            return self
 
     good, bad, paced, spread = 0.2181, 0.2560, 0.2250, 0.2462
-    s = (C.c_float * 41)()
-    assert set(feed(s, [good] * 2000, 0)) == {0}                                     # steady: nothing happens
-    assert set(feed(s, [good * 1.06] * 300, 2000)) == {0}                            # 6 % above the best level is not the other regime
-    # the saturated regime: 32 bad windows, then the trial; the paced sweep is 12 % faster than what was before it: it stays, for good
-    r = feed(s, [bad] * 40, 2300)
-    assert r[:31] == [0] * 31 and r[31:] == [1] * 9
-    r = feed(s, [paced] * 100, 2340)
-    assert set(r) == {1} and s[2] == 2.0
-    assert set(feed(s, [good] * 50, 2440)) == {1}
-    # phases that spread out: the trial (paced sweep no better) ends after 32 windows, the new level is the normal one, no further trial at that level
-    s = (C.c_float * 41)()
-    feed(s, [good] * 500, 0)
-    r = feed(s, [spread] * 32, 500)
-    assert r[-1] == 1 and r[:-1] == [0] * 31
-    r = feed(s, [spread * 0.995] * 32, 532)
-    assert r[:-1] == [1] * 31 and r[-1] == 0 and s[2] == 0.0 and abs(s[0] - spread) < 0.002
-    assert set(feed(s, [spread] * 3000, 564)) == {0}
-    # ... and should THAT level tip over (+17 % again), the next trial waits for the hold-off (256 windows after the failed one)
-    s = (C.c_float * 41)()
-    feed(s, [good] * 100, 0)
-    feed(s, [spread] * 32, 100)
-    feed(s, [spread] * 32, 132)                                                      # failed trial ends at window 163: next trial not before 163 + 256
-    r = feed(s, [spread * 1.17] * 200, 164)
-    assert set(r) == {0}
-    r = feed(s, [spread * 1.17] * 100, 364)
-    assert r.index(1) == 419 - 364 and set(r[419 - 364:419 - 364 + 31]) == {1}       # (a trial at last; this one fails too, and the hold-off doubles)
-    assert r[419 - 364 + 32] == 0 and s[7] == 512.0
+    for lag in (0, 3, 40):
+        # a healthy build: the survey keeps the unpaced sweep; a steady run never leaves it; 6 % above the best level is not the other regime
+        r = Run(lag).run(400, lambda p: paced if p else good)
+        assert r.s[2] == 0.0 and r.want == 0 and abs(r.s[0] - good) < 0.003, (lag, list(r.s)[:8])
+        r.run(2000, lambda p: paced if p else good)
+        r.run(300, lambda p: paced if p else good * 1.06)
+        assert r.s[2] == 0.0 and r.want == 0 and set(r.paces[400:]) == {0}, lag
+        # ... the saturated regime later on: a trial, and the paced sweep (12 % faster than what was before it) stays for good
+        r.run(400, lambda p: paced if p else bad)
+        assert r.s[2] == 2.0 and r.want == 1, (lag, list(r.s)[:8])
+        r.run(100, lambda p: paced if p else good)
+        assert r.want == 1
+        # a build / box whose unpaced sweep is in the slower regime from its first step: the survey keeps the paced sweep
+        r = Run(lag).run(400, lambda p: paced if p else bad)
+        assert r.s[2] == 2.0 and r.want == 1, lag
+        # phases that spread out (the paced sweep no better): a trial, back to unpaced, the new level is the normal one, no further trial at that level
+        r = Run(lag).run(500, lambda p: paced if p else good)
+        r.run(400, lambda p: spread * 0.995 if p else spread)
+        assert r.s[2] == 0.0 and r.want == 0 and abs(r.s[0] - spread) < 0.003 and r.s[7] == 256.0, (lag, list(r.s)[:8])
+        n_paced = sum(r.paces[500:])
+        assert 30 <= n_paced <= 34 + lag, (lag, n_paced)
+        r.run(3000, lambda p: spread * 0.995 if p else spread)
+        assert r.want == 0 and sum(r.paces[900:]) == 0
+    # the hold-off: a failed trial at window ~600, the next one not before 256 windows later even if the level tips over at once
+    r = Run(0).run(500, lambda p: paced if p else good)
+    r.run(100, lambda p: spread if p else spread)
+    t_fail = max(i for i, p in enumerate(r.paces) if p) + 1
+    r.run(600, lambda p: spread * 1.17 * 0.9 if p else spread * 1.17)
+    second = [i for i, p in enumerate(r.paces) if p and i > t_fail]
+    assert second and second[0] >= t_fail - 1 + 256 and r.s[2] == 2.0                # (... and that trial, 10 % faster, is kept)
