@@ -161,6 +161,14 @@ def single_env_latency(device, steps=200, repeats=5):
                      'measured in the build container (BASELINE.md §2)')
 
 
+def frames_per_job(frame_bytes):
+    """template parameter of cw_render_pieces_kernel as a kernel trace lists it: the most frames an aligned 4-KiB piece overlaps, as a power of two"""
+    most, fpj = 4095 // frame_bytes + 2, 2
+    while fpj < most:
+        fpj <<= 1
+    return fpj
+
+
 def place_short_region(prewarm, warmup, steps, max_steps):
     """-> the number of untimed device warm-up steps to take so that a timed region SHORTER than an episode holds none of the steps on which
     every env times out at once (every max_steps-th step with synchronized phases, ~4x a plain step).  Such a region (the driver's K may be 20
@@ -415,7 +423,7 @@ def main():
     barrier()
     elapsed_prof = time.perf_counter() - t1
     prof = env.profile_end()
-    tuner = env.tuner_state()                        # (which placement of the sweep loop the profiled launches ran at)
+    tuner = env.tuner_state()                        # (what pace the profiled launches ran at)
     t_next += K
     episodes = int(env.counters[1].item())
     resets_in_prof = episodes - episodes_before_prof      # envs reset (and repainted: 3 frames each) inside the profiled launches
@@ -473,7 +481,7 @@ def main():
         wd_resets = int(env.counters[1].item()) - ep0 - wd_episodes
         S_ = args.size
         frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
-        wd_bytes = float(N) * (S_ * S_ + frame_) + 2.0 * frame_ * wd_resets / KW_
+        wd_bytes = float(N) * (S_ * S_ + frame_)        # (the bracketed kernel is the sweep of the observation array alone)
         wd_ms = wd_prof['ms_render_kernel']
         window_desync = {'steps': KW_, 'value': float(N) * world * KW_ / wd_elapsed, 'unit': 'env-steps/s', 'ms_per_step': wd_elapsed / KW_ * 1e3,
                          'episodes_finished': wd_episodes, 'resets_per_step': wd_episodes / KW_,
@@ -520,16 +528,13 @@ def main():
             # S*S + frame bytes per env, and one launch paints N envs (+2 more frames for each env reset that step)
             # (cw_render_step_kernel: + the 2 extra frames of every env reset inside the launch, see below)
             alg_bytes = plain_alg_bytes = float(N) * (S * S + frame)
+            # (the frames of envs that finished -- INIT_OBS and desired_goal, 2 x resets_in_prof frames in the profiled region -- are painted by
+            # cw_list_kernel after the sweep, outside the bracketed kernel: not counted here)
             dominant, ms = render_kernel, prof['ms_render_kernel']
-            if dominant.endswith('_step_kernel'):
-                # the fused launch also resets the finished envs and paints their observation, desired-goal and init frames:
-                # two frames more than the one an env that goes on gets (averaged over the profiled launches)
-                alg_bytes += 2.0 * frame * resets_in_prof / max(K, 1)
         else:
             alg_bytes = plain_alg_bytes = float(N) * 48.0
             # state-only / dirty-cell: the whole auto-reset step is one launch (step + inline resets), latency-bound
-            fused = not (os.environ.get('CW_EXPERIMENT_BUILD', '0') not in ('', '0') and os.environ.get('CW_TUNE_FUSED_STEP', '1') == '0')
-            dominant, ms = ('cw_step_fused_kernel' if fused else 'cw_step_kernel'), prof['ms_step_kernel']
+            dominant, ms = 'cw_step_fused_kernel', prof['ms_step_kernel']
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
         # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)
@@ -570,10 +575,8 @@ def main():
                        'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)',
                        'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
             'roofline': {'bound': 'hbm', 'kernel': dominant,
-                         # the one-launch step exists at eight placements of its sweep loop, and the engine measures which one to launch: a
-                         # rocprofv3 trace lists them as cw_render_step_kernel<0..7>, this is the one the profiled region ran
-                         'kernel_in_trace': (('%s<%d>' % (dominant, tuner['place'])) if dominant == 'cw_render_step_kernel' else
-                                             ('%s<%d>' % (dominant, 1 if args.raster == 'alt' else 0)) if dominant.startswith('cw_render_pieces') else dominant),
+                         # (a rocprofv3 trace lists the sweep by raster and frames per job: cw_render_pieces_kernel<raster, 2> for frames of 4 KiB and more)
+                         'kernel_in_trace': (('%s<%d, %d>' % (dominant, 1 if args.raster == 'alt' else 0, frames_per_job(frame))) if dominant.startswith('cw_render_pieces') else dominant),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
@@ -585,8 +588,7 @@ def main():
                          'frac_at_median_launch': (plain_alg_bytes / (prof['ms_render_kernel_median'] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                    if args.obs_mode == 'pixels' and prof['ms_render_kernel_median'] > 0 else None),
                          'events': 'hipEventRecord on the launch stream around every kernel, %d launches' % prof['steps']},
-            # full-pixel mode brackets only the dominant render kernel (each event record costs a pipeline bubble,
-            # side-stream events perturb the overlap); an experiment build with CW_PROFILE_SIDE_STREAM=1 brackets all three
+            # full-pixel mode brackets only the dominant kernel, the sweep (each event record costs a pipeline bubble)
             'kernels_ms': {'step': prof['ms_step_kernel'] or None, 'reset': prof['ms_reset_kernel'] or None,
                            'render': prof['ms_render_kernel'] or None, 'ms_per_step_with_events': elapsed_prof / K * 1e3},
             'tuner': tuner,

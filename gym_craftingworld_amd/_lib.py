@@ -9,18 +9,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcraftingworld.so')
-EXP_LIB_PATH = os.path.join(_HERE, 'libcraftingworld_exp.so')     # the same sources with -DCW_EXPERIMENT: launch-shape knobs compiled in
 
 
 def lib_path():
-    """Which build to load: CW_LIB_PATH (any other build, A/B runs) > CW_EXPERIMENT_BUILD=1 (libcraftingworld_exp.so) > the product."""
-    if os.environ.get('CW_LIB_PATH'):
-        return os.environ['CW_LIB_PATH']
-    if os.environ.get('CW_EXPERIMENT_BUILD', '0') not in ('', '0'):
-        return EXP_LIB_PATH
-    return LIB_PATH
+    """Which build to load: CW_LIB_PATH (any other build, A/B runs) or the product."""
+    return os.environ.get('CW_LIB_PATH') or LIB_PATH
 
-CW_ABI_VERSION = 3
+CW_ABI_VERSION = 4
 CW_MT_N = 624
 CW_MAX_TASKS = 16
 CW_MAX_MENUS = 256
@@ -66,9 +61,8 @@ class cw_profile(C.Structure):
 
 
 class cw_tuner_state(C.Structure):
-    _fields_ = [('place', C.c_int32), ('surveys', C.c_int32), ('struck_mask', C.c_int32), ('sleeps_beside', C.c_int32),
-                ('place_tuned', C.c_int32), ('sleeps_tuned', C.c_int32), ('painter', C.c_int32), ('piece_pace', C.c_int32),
-                ('guard_state', C.c_int32), ('guard_trials', C.c_int32)]
+    _fields_ = [('piece_pace', C.c_int32), ('pace_beside', C.c_int32), ('pace_beside_tuned', C.c_int32), ('guard_state', C.c_int32),
+                ('guard_trials', C.c_int32), ('lookahead', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)
@@ -110,12 +104,13 @@ HOST_HELPERS = {
     'cwh_mt_from_numpy': (C.c_int, [_VP, C.c_int]),
     'cwh_mt_to_numpy': (None, [_VP, C.c_int, _VP]),
     'cwh_mt_init_genrand': (None, [_VP, C.c_uint32]),
-    'cwh_choose_place': (C.c_int, [C.POINTER(C.c_float), C.c_uint, C.POINTER(C.c_int)]),
+    'cwh_mt_untwist': (None, [_VP]),
+    'cwh_mt_rewind': (None, [_VP, C.POINTER(C.c_int32), C.c_uint32]),
     'cwh_regime_guard': (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_uint, C.c_int]),
     'cwh_dlpack_make': (_VP, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 
-_libs = {}      # path -> loaded library (a process may hold the product and the experiment build side by side)
+_libs = {}      # path -> loaded library (a process may hold the product and another build side by side)
 _lib = None     # the one loaded (or asked for) last: check() takes its error text
 
 

@@ -16,9 +16,8 @@
 
 extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
-                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *ev);
-int cwk_render_is_linear(const CwParams *P, const CwTuning *T);
-int cwk_render_is_piece_sweep(const CwParams *P, const CwTuning *T);
+                           hipEvent_t *ev);
+hipError_t cwk_launch_refill(const CwParams *P, const CwTuning *T, int all_envs, hipStream_t st);
 hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st);
 hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_seed(const CwParams *P, const uint32_t *seeds_dev, hipStream_t st);
@@ -28,11 +27,7 @@ hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, in
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
-hipError_t cwk_launch_step_render_calib(const CwParams *P, const CwTuning *T, int auto_reset, hipStream_t st);
-hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
-                                   int *waves_per_block);
-int cwk_render_jobs(const CwParams *P, const CwTuning *T);
-int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset);
+hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, int list_aware, hipStream_t st);
 hipError_t cwk_launch_idle(hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
@@ -94,36 +89,26 @@ struct cw_engine {
     hipStream_t last_stream = nullptr; // the stream of the last cw_reset / cw_step / cw_rollout: a resident kernel starts only after that work
     bool last_stream_set = false;
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
-    hipStream_t side = nullptr;        // reset + reset-render run here beside the main render (FULL pixel mode)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // look-ahead (cw_layout.h): the refill kernel is launched every CW_LA_PERIOD steps, ahead of the step, on the step's stream
+    bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
+    unsigned la_steps = 0;
     int prof_cap = 0, prof_n = 0;
-    // online tuner of the render pace (full-frame mode, linear sweep): see adapt_tick
+    // online tuner of the sweep's pace (full-frame mode): see adapt_tick
     struct Adapt {
         bool on = false;
         hipEvent_t ev[CW_ADAPT_RING] = {nullptr};   // ev[w % RING] is recorded on the caller's stream when window w begins (the host may run
                                                // RING windows = 2 048 steps ahead of the GPU before measurements are lost)
         unsigned seq = 0;                      // steps taken in the tuned mode
         unsigned next_window = 0;              // first window whose duration has not been read yet
-        int cur = 2;                           // extra sleeps per pair of jobs while envs are reset beside the sweep, currently held
+        // (1) the extra quarter-sleeps per store on steps on which >= 32 envs finished
+        bool pace_on = false;                  // tuned (off: CW_TUNE_PACE_BESIDE forces the number)
+        int cur = 1;                           // the value currently held
         signed char pace_of_window[CW_ADAPT_RING] = {0};  // what each recent window ran at; negative: a settling window, not counted
-        float stat[16] = {0};                  // per pace: running mean step time of its counted windows (ms; 0: unknown)
+        float stat[16] = {0};                  // per value: running mean step time of its counted windows (ms; 0: unknown)
         unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
-        // ... and of the PLACEMENT of the sweep's batch loop (cw_render_step_kernel<k>, cw_kernels.hip: render_groups)
-        bool pace_on = false;                  // (1) is tuned (off: CW_TUNE_RENDER_PACE_BESIDE forces the number)
-        bool place_on = false;                 // (2) is tuned (off: CW_TUNE_RENDER_PLACE forces one)
-        int place = 3;                         // the placement held outside a survey
-        bool surveying = false;
-        unsigned survey_w0 = 0;                // first window of the running survey
-        signed char place_of_window[CW_ADAPT_RING] = {0}; // placement each recent window ran at
-        signed char round_of_window[CW_ADAPT_RING] = {0}; // 0: not a survey window; r + 1: round r of a survey (round 0 is not counted)
         bool tainted[CW_ADAPT_RING] = {false};            // a step of the window was bracketed by cw_profile_* events (each costs a pipeline bubble): not counted
-        float survey_ms[8][3] = {{0}};         // ms per step of placement k in survey rounds 1..3
-        unsigned survey_seen = 0;              // survey windows read so far
-        float place_ms = 0;                    // what `place` measured when it was chosen
-        int place_bad = 0;                     // consecutive counted windows more than 4 % above that
-        unsigned surveys = 0;
-        unsigned place_struck = 0;             // bit k: placement k was held and fell out of its regime (not held again in this process)
-        bool guard_on = false;                 // (3) the piece sweep runs unpaced and its regime is watched (cwh_regime_guard)
+        // (2) the base pace: unpaced, watched by the regime guard (cwh_regime_guard)
+        bool guard_on = false;
         float guard[41] = {};
         int guard_pace = 0;                    //     what the guard last said: 0 unpaced, 1 paced
         bool guard_test = false;
@@ -132,7 +117,8 @@ struct cw_engine {
         signed char gpace_of_window[CW_ADAPT_RING] = {};   // what the window was launched with: 0 unpaced, 1 paced, -1 the first after a change (not counted)
     } adapt;
 };
-enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_PLACES = 8, CW_SURVEY_ROUNDS = 4, CW_PLACE_BAD_WINDOWS = 24, CW_GUARD_PACE = 2 /* eighths */ };
+enum { CW_LA_PERIOD = 16 };
+enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_GUARD_PACE = 2 /* eighths */ };
 extern "C" int cwh_regime_guard(float *s, float ms, unsigned window, int ran_paced);
 
 // ------------------------------------------------------------------------------ resident stepper (host side)
@@ -172,8 +158,8 @@ int cwh_mt_from_numpy(uint32_t *s, int pos)
 }
 
 // inverse: from engine form (s, idx) recover a numpy key whose stream from position idx is
-// identical.  Words < idx are un-twisted; key[0]'s low 31 bits are unrecoverable and unused
-// by MT19937 (set to 0).
+// identical.  Words < idx are un-twisted; key[0]'s low 31 bits are not part of the MT19937 state and
+// cannot be un-twisted ...
 void cwh_mt_to_numpy(const uint32_t *s, int idx, uint32_t *key)
 {
     for (int j = idx; j < CW_MT_N; j++) key[j] = s[j];
@@ -186,6 +172,45 @@ void cwh_mt_to_numpy(const uint32_t *s, int idx, uint32_t *key)
         const uint32_t y = (t << 1) | odd;     // (G[j] & UPPER) | (G[j+1] & LOWER)
         key[j] |= y & 0x80000000u;
         if (j + 1 < idx) key[j + 1] |= y & 0x7fffffffu;
+    }
+    if (idx > 0) {     // ... but they are what the generation's word 623 was made with: key[623] = key[396] ^ T(previous[623].hi, key[0].lo)
+        uint32_t t = key[CW_MT_N - 1] ^ key[396];
+        const uint32_t odd = t >> 31;
+        if (odd) t ^= 0x9908b0dfu;
+        key[0] |= ((t << 1) | odd) & 0x7fffffffu;      // (exact for every key a twist produced; a rewind to position 0 reads this word again)
+    }
+}
+
+// One generation back: key = all 624 words of a generation as numpy holds them after its twist -> the generation before (whose twist
+// produced it).  The twist is a bijection on the 19 937 state bits (word 0 counts with its top bit only): word k >= 227 of the new
+// generation is new[k-227] ^ T(old[k].hi, old[k+1].lo), word 623 new[396] ^ T(old[623].hi, new[0].lo), word k < 227 old[k+397] ^ T(...);
+// T(y) = (y >> 1) ^ (y odd ? 0x9908b0df : 0) is undone through its top bit.  The low 31 bits of key[0] (not part of the state; the export
+// above restores them from words 623 and 396) are REPAIRED on the way in -- the step for word 227 needs them -- and restored in the result.
+void cwh_mt_untwist(uint32_t *key)
+{
+    uint32_t prev[CW_MT_N];
+    memset(prev, 0, sizeof(prev));
+    for (int k = CW_MT_N - 1; k >= 0; k--) {
+        uint32_t t = key[k] ^ (k == CW_MT_N - 1 ? key[396] : k >= CW_MT_N - 397 ? key[k - (CW_MT_N - 397)] : prev[k + 397]);
+        const uint32_t odd = t >> 31;
+        if (odd) t ^= 0x9908b0dfu;
+        const uint32_t y = (t << 1) | odd;
+        prev[k] |= y & 0x80000000u;
+        if (k == CW_MT_N - 1) key[0] = (key[0] & 0x80000000u) | (y & 0x7fffffffu);
+        else prev[k + 1] |= y & 0x7fffffffu;
+    }
+    uint32_t t = prev[CW_MT_N - 1] ^ prev[396];          // prev[0]'s own low bits, the same way (cwh_mt_to_numpy): a rewind may stop at position 0
+    const uint32_t odd = t >> 31;
+    if (odd) t ^= 0x9908b0dfu;
+    prev[0] |= ((t << 1) | odd) & 0x7fffffffu;
+    memcpy(key, prev, sizeof(prev));
+}
+// numpy state (key, pos) -> the state n raw draws earlier (a look-ahead record's draws, cw_get_mt); pos stays in 0..623 like the export's
+void cwh_mt_rewind(uint32_t *key, int32_t *pos, uint32_t n)
+{
+    while (n > 0) {
+        if ((uint32_t)*pos >= n) { *pos -= (int32_t)n; n = 0; }
+        else { n -= (uint32_t)*pos; cwh_mt_untwist(key); *pos = CW_MT_N; }
     }
 }
 
@@ -221,22 +246,6 @@ void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, c
     m->dl_tensor.byte_offset = 0;
     m->deleter = cw_dl_deleter;
     return m;
-}
-
-// The placement survey's decision (adapt_tick), as a pure function: med[k] = median ms/step of placement k (<= 0: no figure), struck = bit
-// mask of placements not to hold again.  Of the placements within 6 % of the fastest (off the cliff) the MEDIAN one -- the fastest are
-// bistable (profiles/r03_placement.txt C).  -> the placement, or -1 if none has a figure; *n_candidates for the log.
-int cwh_choose_place(const float *med, unsigned struck, int *n_candidates)
-{
-    float fastest = 0.f;
-    for (int k = 0; k < 8; k++)
-        if (med[k] > 0.f && !((struck >> k) & 1u) && (fastest == 0.f || med[k] < fastest)) fastest = med[k];
-    int cand[8], n = 0;
-    for (int k = 0; k < 8; k++)
-        if (med[k] > 0.f && !((struck >> k) & 1u) && med[k] <= 1.06f * fastest) cand[n++] = k;
-    std::sort(cand, cand + n, [&](int x, int y) { return med[x] < med[y] || (med[x] == med[y] && x < y); });
-    if (n_candidates) *n_candidates = n;
-    return n > 0 ? cand[(n - 1) / 2] : -1;
 }
 
 // The piece sweep's REGIME GUARD (adapt_tick), as a pure function fed one counted window at a time: its level (ms per step) and the pace it was LAUNCHED
@@ -350,109 +359,6 @@ static void prof_free(cw_engine *e)
     e->prof_cap = e->prof_n = 0;
 }
 
-// Pace of the linear-sweep render (cw_kernels.hip: render_groups): idle clocks per pair of jobs.  The write path is less
-// efficient saturated than kept just short of saturation.
-//
-// Ray raster: the pace is FIXED at m+0 (one s_sleep inside every job, none between jobs); on top of it come extra sleeps per pair of
-// jobs while at least CW_BESIDE_MIN envs are being reset beside the sweep (cw_kernels.hip: render_groups), and THAT number is what
-// the online tuner (adapt_tick) follows.  Round 2 first measured the pace at cw_create (median launch time per candidate) and let
-// the tuner follow it; then both were compared with forced paces, alternating on one box, several boxes (profiles/history/r02_pace.txt):
-// the launch times cw_create can measure scatter by 4-5 % between processes for the SAME pace (0.2298-0.2455 ms for m+0) -- more
-// than the differences to be resolved -- so the calibration picked m+2 / m+3 in a third of the processes.  Inside a step sequence
-// the order is the same on every box and shape tried: m+0 0.2333, one sleep per pair without the inner one 0.2332-0.2345, unpaced
-// 0.2350, m+1 0.2365, m+2 0.2418 ms (one-launch step, no resets beside; 131 072 envs, 262 144 envs and 32x32 likewise).  With
-// resets beside every launch (episode phases spread out) the best extra is box-dependent -- 0 to 3 more sleeps per pair, and being
-// off by two costs 3-8 % -- hence the tuner there.  CW_TUNE_RENDER_CALIBRATE=1 brings the cw_create measurement back (other
-// hardware), CW_TUNE_RENDER_PACE=n forces the base pace, CW_TUNE_RENDER_PACE_BESIDE=n the extra (tuner off), CW_TUNE_RENDER_ADAPT=0
-// keeps the extra at its start value 2.
-// AltObs raster: measured here as before (0..6 sleeps per 1-KiB store; the optimum is flat and broad there).
-static int calibrate_render_pace(cw_engine *e, bool refine)
-{
-    CwTuning &tn = e->tune;
-    const char *forced = getenv("CW_TUNE_RENDER_PACE");
-    if (forced) {                                         // (256 + n: with the sleep inside each job)
-        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = (atoi(forced) < 0 ? 0 : atoi(forced) & 0x1FF) | (((beside ? atoi(beside) : 2) & 15) << 12);
-        if (e->P.raster == CW_RASTER_ALT) e->P.alt_pace = tn.render_pace & 0xFF;
-        return CW_OK;
-    }
-    const bool alt = e->P.raster == CW_RASTER_ALT;       // the AltObs painter's pace lives in P.alt_pace (every kernel that paints frames reads it)
-    if (alt) e->P.alt_pace = 2;                           // (engines that are not calibrated: mid-range)
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions) return CW_OK;      // (the Ray raster is paced in both of its kernels)
-    if ((long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;          // small batches are launch-bound: nothing to pace
-#ifdef CW_EXPERIMENT
-    const bool measure_base_pace = getenv("CW_TUNE_RENDER_CALIBRATE") && atoi(getenv("CW_TUNE_RENDER_CALIBRATE")) != 0;
-#else
-    const bool measure_base_pace = false;
-#endif
-    if (!alt && !measure_base_pace) {
-        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = 0x100 | (((beside ? atoi(beside) : 2) & 15) << 12);
-        return CW_OK;
-    }
-    // The launches of one candidate are queued back to back and the host waits once, at the end: a host round trip after every
-    // launch lets the card idle for tens of microseconds each time, and what is measured then is a memory system that keeps
-    // leaving and re-entering its busy state (the same kernel on the same buffer reads 0.225 or 0.28 ms that way,
-    // tools/microbench/time_render.py placement) -- not the regime a step sequence runs in.
-    enum { CALIB_LAUNCHES = 9, CALIB_SKIP = 3 };
-    hipEvent_t evs[2 * CALIB_LAUNCHES] = {};
-    for (hipEvent_t &ev : evs)
-        if (hipEventCreate(&ev) != hipSuccess) {
-            for (hipEvent_t &d : evs) if (d) (void)hipEventDestroy(d);
-            return fail(CW_ERR_HIP, "cw_create: event creation failed");
-        }
-    int blocks = 0, wpb = 0, rc = CW_OK;
-    auto median_ms = [&](int pace, double *out) -> int {
-        const int saved = tn.render_pace, saved_alt = e->P.alt_pace;
-        tn.render_pace = pace;
-        if (alt) e->P.alt_pace = pace;
-        bool ok = true;
-        for (int rep = 0; rep < CALIB_LAUNCHES && ok; rep++)             // (a short idle kernel between launches, like the step kernel)
-            ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess &&
-                 cwk_launch_render_calib(&e->P, &tn, nullptr, tn.render_q_all, tn.render_fast_parity, &blocks, &wpb) == hipSuccess &&
-                 hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
-        ok = ok && hipDeviceSynchronize() == hipSuccess;
-        tn.render_pace = saved;
-        e->P.alt_pace = saved_alt;
-        float ms[CALIB_LAUNCHES];
-        for (int rep = 0; rep < CALIB_LAUNCHES && ok; rep++) ok = hipEventElapsedTime(&ms[rep], evs[2 * rep], evs[2 * rep + 1]) == hipSuccess;
-        if (!ok) return fail(CW_ERR_HIP, "cw_create: render pace calibration failed");
-        float *m = ms + CALIB_SKIP;                                             // (the first launches bring the card up to speed)
-        const int n = CALIB_LAUNCHES - CALIB_SKIP;
-        for (int i = 1; i < n; i++) for (int j = i; j > 0 && m[j] < m[j - 1]; j--) { const float t = m[j]; m[j] = m[j - 1]; m[j - 1] = t; }
-        *out = m[n / 2];
-        return CW_OK;
-    };
-    int best = tn.render_pace;
-    double best_ms = 0, t = 0;
-    char log[400] = "";
-    size_t len = 0;
-    if (!refine) for (int i = 0; i < 3 && rc == CW_OK; i++) rc = median_ms(alt ? 2 : 0x100, &t);   // the card up to speed before the first candidate is timed
-    auto try_pace = [&](int pace) {
-        rc = median_ms(pace, &t);
-        if (rc == CW_OK && (best_ms == 0 || t < best_ms)) { best_ms = t; best = pace; }
-        if (len < sizeof(log) - 24) len += (size_t)snprintf(log + len, sizeof(log) - len, " %s%d:%.4f", (pace & 0x100) ? "m+" : "", pace & 0xFF, t);
-    };
-    if (alt) {
-        if (!refine) for (int pp = 0; pp <= 6 && rc == CW_OK; pp++) try_pace(pp);
-        else best = e->P.alt_pace;
-    } else if (!refine) {
-        static const int cand[] = {0x100, 0x101, 0x102, 0x103, 0x104, 0, 1, 2, 3, 4, 6};
-        for (size_t i = 0; i < sizeof(cand) / sizeof(cand[0]) && rc == CW_OK; i++) try_pace(cand[i]);
-    } else {                                                                    // after the shares are known: the neighbours once more
-        const int mid = tn.render_pace & 0x100, p0 = tn.render_pace & 0xFF;      // (bits 12-15, the extra beside resets, play no part here)
-        for (int pp = (p0 > 0 ? p0 - 1 : 0); pp <= p0 + 1 && rc == CW_OK; pp++) try_pace(mid | pp);
-    }
-    for (hipEvent_t &ev : evs) (void)hipEventDestroy(ev);
-    if (rc != CW_OK) return rc;
-    if (alt) e->P.alt_pace = best;
-    else tn.render_pace = (best & 0x1FF) | (2 << 12);       // (+2 while envs are reset beside the launch, see render_groups)
-    if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] render pace%s: ms per launch by sleeps per pair of jobs (m+: and one inside each job)%s -> %s%d\n",
-                refine ? " (with shares)" : "", log, (best & 0x100) ? "m+" : "", best & 0xFF);
-    return CW_OK;
-}
-
 // launch time of the per-step render as currently configured (launches queued back to back, one wait: see calibrate_render_pace): the median and the
 // 90th percentile of 20 launches -- the write path has a slower regime that a configuration may enter launch by launch (profiles/r03_pieces.txt N-P), and
 // a median does not show a configuration that does so one time in three
@@ -463,7 +369,7 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     bool ok = true;
     for (hipEvent_t &ev : evs) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int rep = 0; rep < LAUNCHES && ok; rep++)
-        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_step_render_calib(&e->P, &e->tune, e->auto_reset, nullptr) == hipSuccess &&
+        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_sweep_calib(&e->P, &e->tune, e->auto_reset, nullptr) == hipSuccess &&
              hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     float ms[LAUNCHES];
@@ -477,44 +383,27 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     return CW_OK;
 }
 
-// The per-step render: the painter calibrated so far (the Ray raster's linear sweep of cell rows, or frame per wave) or the sweep of aligned
-// 4-KiB pieces (cw_kernels.hip: render_pieces)?  The latter's pace (eighths of a sleep per 1-KiB store) is checked, then the faster of the two
-// is kept -- the same launches, queued the same way, for both.
-static int calibrate_piece_sweep(cw_engine *e)
+// The sweep's base pace (cw_kernels.hip: render_pieces): eighths of a sleep per 1-KiB store.  The sweep runs fastest unpaced or nearly so -- just
+// short of the write path's slower, saturated regime -- and how much pace it takes to stay clear of that regime depends on details of the build
+// and the shape (round 3's kernel: unpaced 0.2107-0.2121 ms; a build two instructions per batch heavier: unpaced 0.229-0.244, one eighth bimodal
+// 0.210 / 0.239, two eighths a steady 0.2089; profiles/history/r03_pieces.txt F, P).  So the candidates are judged by their 90th-percentile launch, not
+// their median: the smallest pace whose slow launches are within 1.5 % of the best candidate's.  What launches timed here cannot show (the step
+// kernel runs between the sweeps of a step sequence) the regime guard watches for (adapt_tick).
+static int calibrate_pace(cw_engine *e)
 {
     CwTuning &tn = e->tune;
-    if (!tn.piece_sweep || !cwk_render_is_piece_sweep(&e->P, &tn)) return CW_OK;
+    if (const char *beside = getenv("CW_TUNE_PACE_BESIDE")) tn.pace_beside = atoi(beside) & 15;
+    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) tn.period16 = (int)(atof(per) * 1.6 + 0.5);
+    if (const char *forced = getenv("CW_TUNE_PIECE_PACE")) { tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; return CW_OK; }
     tn.piece_pace = e->P.raster == CW_RASTER_ALT ? 4 : 0;
-    // the extra QUARTER sleeps per store while envs are being reset beside the sweep: bits 12-15 of render_pace, the number cw_step's tuner follows
-    // from here (episode phases spread out, 65 536 envs: 0 / 2 / 4 / 6 / 8 / 12 extra = 0.250-0.260 / 0.236-0.257 / 0.238-0.248 / 0.234-0.237 /
-    // 0.241 / 0.241-0.248 ms, profiles/r03_pieces.txt; AltObs: 4)
-    auto set_beside = [&]() {
-        const char *beside = getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        tn.render_pace = (tn.render_pace & ~0xF000) | (((beside ? atoi(beside) : e->P.raster == CW_RASTER_ALT ? 4 : 6) & 15) << 12);
-    };
-#ifdef CW_EXPERIMENT
-    const char *forced = getenv("CW_TUNE_PIECE_PACE");
-#else
-    const char *forced = nullptr;
-#endif
-    if (forced) { tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; set_beside(); return CW_OK; }
-    // (batches down to 4 MB of frames are measured: which painter wins a launch-bound render depends on the shape -- 700 envs of 70x70: frame per wave
-    // 0.028 ms, pieces 0.044)
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (4ll << 20)) { set_beside(); return CW_OK; }
-    double frames_ms = 0, frames_p90 = 0, t = 0, t90 = 0, best_p90 = 0;
-    tn.piece_sweep = 0;
-    int rc = timed_render_stats(e, &frames_ms, &frames_p90);
-    tn.piece_sweep = 1;
-    // Which pace.  The sweep runs fastest unpaced or nearly so -- just short of the write path's slower, saturated regime -- and how much pace it takes to
-    // stay clear of that regime depends on details of the build (the committed one: unpaced 0.2107-0.2121 ms in every process measured; a build two
-    // instructions per batch heavier: unpaced 0.229-0.244, one eighth bimodal 0.210 / 0.239, two eighths a steady 0.2089; profiles/r03_pieces.txt F, P).
-    // So the candidates are judged by their 90th-percentile launch, not their median: the smallest pace whose slow launches are within 1.5 % of the best
-    // candidate's.  (AltObs: 4 eighths first, a sleep after every other store -- 0.1304-0.1322 ms on four boxes, profiles/r03_alt_sweep.txt)
+    // (small batches are launch-bound: nothing to pace; host-mapped frames are PCIe-bound)
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;
     static const int eighths_ray[] = {0, 1, 2, 4, 8}, eighths_alt[] = {4, 0, 2, 8, 12};
     const int *eighths = e->P.raster == CW_RASTER_ALT ? eighths_alt : eighths_ray;
-    double p90s[5] = {0, 0, 0, 0, 0};
+    double p90s[5] = {0, 0, 0, 0, 0}, t = 0, t90 = 0, best_p90 = 0;
     char log[320] = "";
     size_t len = 0;
+    int rc = CW_OK;
     for (size_t i = 0; i < 5 && rc == CW_OK; i++) {
         tn.piece_pace = eighths[i];
         rc = timed_render_stats(e, &t, &t90);
@@ -527,31 +416,21 @@ static int calibrate_piece_sweep(cw_engine *e)
     for (size_t i = 0; i < 5; i++)
         if (p90s[i] <= 1.015 * best_p90) { best = eighths[i]; break; }             // (the first in the list's order of preference)
     tn.piece_pace = best;
-    if (best_p90 >= frames_p90) tn.piece_sweep = 0;
-    if (tn.piece_sweep) set_beside();
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] per-step render: %s %.4f/%.4f ms (median/90th percentile of 20 launches); sweep of aligned pieces by eighths of a sleep per store%s -> %s%s\n",
-                cwk_render_is_linear(&e->P, &tn) ? "sweep of cell rows" : "frame per wave", frames_ms, frames_p90, log, tn.piece_sweep ? "pieces, pace " : "the former",
-                tn.piece_sweep ? std::to_string(tn.piece_pace).c_str() : "");
+        fprintf(stderr, "[craftingworld] sweep pace, ms per launch (median/90th percentile of 20) by eighths of a sleep per store:%s -> %d\n", log, best);
     return CW_OK;
 }
 
-// Online tuner of the one-launch full-frame step: (1) the sweep's extra sleeps beside resets, (2) the placement of its batch loop.
-// Neither can be predicted from launches timed at cw_create (profiles/history/r02_pace.txt, r02_fused_render.txt, r03_placement.txt), so cw_step
-// keeps measuring the thing itself: an event is recorded on the caller's stream every CW_ADAPT_W steps (a "window"), and the time between
-// two consecutive ones, read whenever both have completed -- however far the host runs ahead of the GPU -- is what CW_ADAPT_W whole steps
-// took.  Only performance depends on any of it: every placement and every pace paints the same frames.
-// (1) Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the first window after a change settles and is
-// not counted; a window holding a step on which every env was reset is an outlier and is not counted either); each counted window updates
-// the running figure of its value, and `cur` moves to a neighbour whose figure is 0.7 % better (figures older than three cycles do not
-// count).  With fewer than CW_BESIDE_MIN resets per step the value is never used by the kernel and its drift is harmless.
-// (2) The same instructions run up to 17 % apart depending on where the batch loop lies modulo 32 bytes, and which placement is the good one
-// changes with the loop body, the compiler and the box.  So all eight are built (cw_render_step_kernel<k>) and a SURVEY picks one: four
-// rounds of one window per placement (the first round -- a variant's first launches load its code -- is not counted); of the placements
-// whose median window is within 6 % of the fastest, the MEDIAN one is then held (the fastest are bistable, see below).  A survey runs when
-// the engine starts stepping and again when the held placement has read more than 4 % above its own survey figure for
-// CW_PLACE_BAD_WINDOWS counted windows in a row (the regime has moved: e.g. episode phases that have spread out); that placement is
-// then struck off for the rest of the process.  The pace of (1) is frozen during a survey.  CW_TUNE_RENDER_PLACE=k forces a placement.
+// Online tuner of the full-frame step's sweep.  Two things cannot be predicted from launches timed at cw_create (profiles/history/r02_pace.txt,
+// r03_pieces.txt P; profiles/r04_lookahead.txt), so cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every
+// CW_ADAPT_W steps (a "window"), and the time between two consecutive ones, read whenever both have completed -- however far the host runs
+// ahead of the GPU -- is what CW_ADAPT_W whole steps took.  Only performance depends on any of it: every pace paints the same frames.
+// (1) The extra pace on steps on which envs finish.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the
+// first window after a change settles and is not counted; a window holding a step on which every env finished is an outlier and is not counted
+// either); each counted window updates the running figure of its value, and `cur` moves to a neighbour whose figure is 0.7 % better (figures
+// older than three cycles do not count).  With fewer than CW_BESIDE_MIN finished envs per step the value is never used by the kernel and its
+// drift is harmless.
+// (2) The regime guard of an unpaced sweep (cwh_regime_guard).
 static void adapt_tick(cw_engine *e, hipStream_t st)
 {
     cw_engine::Adapt &a = e->adapt;
@@ -562,25 +441,15 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
     bool moved = false;
     while (a.next_window + 1 <= w) {                 // window next_window lies between ev[next_window] and ev[next_window + 1]
         const unsigned cw = a.next_window;
-        if (w - cw >= CW_ADAPT_RING - 1) {                                                      // (its events have been reused)
-            if (a.round_of_window[cw % CW_ADAPT_RING]) a.survey_seen++;                     //  a survey window lost: its sample stays 0 = unknown
-            a.next_window++;
-            continue;
-        }
+        if (w - cw >= CW_ADAPT_RING - 1) { a.next_window++; continue; }          // (its events have been reused)
         if (cw + 1 == w) break;                                                  // its closing event was recorded just now
         if (hipEventQuery(a.ev[(cw + 1) % CW_ADAPT_RING]) != hipSuccess) break;
         float ms = 0.f;
         const int p = a.pace_of_window[cw % CW_ADAPT_RING];
-        const int round = a.round_of_window[cw % CW_ADAPT_RING], place = a.place_of_window[cw % CW_ADAPT_RING];
         a.next_window++;
         const bool timed = !a.tainted[cw % CW_ADAPT_RING] && hipEventElapsedTime(&ms, a.ev[cw % CW_ADAPT_RING], a.ev[(cw + 1) % CW_ADAPT_RING]) == hipSuccess && ms > 0.f;
         ms /= (float)CW_ADAPT_W;
-        if (round) {                                                             // a survey window
-            if (timed && round >= 2) a.survey_ms[place & 7][round - 2] = ms;
-            a.survey_seen++;
-            continue;
-        }
-        if (a.guard_on && timed) {                                            // (3) the piece sweep's regime: every timed window, whatever the extra pace beside resets
+        if (a.guard_on && timed) {                                            // (2) the sweep's regime: every timed window, whatever the extra pace
             // (guard_test, experiment build: every watched window reads 20 % above the best level, so trials come round by themselves -- for the test
             // that a trial changes no frame)
             const int ran = a.gpace_of_window[cw % CW_ADAPT_RING];
@@ -604,9 +473,6 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             }
         }
         if (p < 0 || !timed) continue;
-        // is the held placement still what it was?  (CONSECUTIVE windows: one holding an all-env reset step is followed by a normal one;
-        // counted before the outlier filter below, which would take a placement that has tipped by 17 % for a reset storm 80 windows long)
-        if (a.place_on && !a.surveying && a.place_ms > 0 && p == a.cur) a.place_bad = ms > 1.04f * a.place_ms ? a.place_bad + 1 : 0;
         const bool known = a.stat[p] > 0 && cw - a.stat_window[p] < 80;
         if (known && ms > 1.06f * a.stat[p]) continue;                           // a reset storm inside the window
         a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
@@ -630,58 +496,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
         a.gpace_last = gp;
         e->tune.piece_pace = gp ? CW_GUARD_PACE : 0;
     }
-    if (a.surveying && a.survey_seen >= (unsigned)(CW_SURVEY_ROUNDS * CW_PLACES) && w >= a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {
-        // Every survey window has been read.  WHICH placement to hold: not the fastest.  Placements come in three kinds (profiles/
-        // r03_placement.txt): on the cliff (+15-25 %), on the plateau (within ~1 % of each other), and one or two 2-3 % FASTER than the
-        // plateau that are bistable -- the same build runs a whole bench at 0.227 ms per launch or at 0.267, and nothing in a short visit
-        // tells which it will be.  So: drop what is more than 6 % above the fastest (the cliff), and of the rest hold the MEDIAN one --
-        // neither on the cliff nor on the edge.  A placement that later reads > 4 % above its survey figure for CW_PLACE_BAD_WINDOWS
-        // windows is struck off (a.place_struck) and the survey repeated.
-        int best = a.place, n_cand = 0;
-        float best_ms = 0.f, med[CW_PLACES];
-        char log[256] = "";
-        size_t len = 0;
-        for (int k = 0; k < CW_PLACES; k++) {
-            float *m = a.survey_ms[k];
-            med[k] = 0.f;
-            if (m[0] <= 0 || m[1] <= 0 || m[2] <= 0) continue;                   // (a lost sample: the placement does not compete)
-            med[k] = std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2]));
-            if (len < sizeof(log) - 16) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f%s", k, med[k], ((a.place_struck >> k) & 1) ? "x" : "");
-        }
-        const int pick = cwh_choose_place(med, a.place_struck, &n_cand);
-        if (pick >= 0) { best = pick; best_ms = med[pick]; }
-        if (verbose) fprintf(stderr, "[craftingworld] placement survey %u (window %u), median ms/step by placement:%s -> %d (median of the %d within 6 %% of the fastest)\n",
-                             a.surveys, w, log, best, n_cand);
-        a.place = best;
-        a.place_ms = best_ms;
-        a.place_bad = 0;
-        a.surveying = false;
-        for (int p = 0; p < 16; p++) a.stat[p] = 0;                              // the pace figures belonged to the old placement
-    }
-    if (a.place_on && !a.surveying && (a.surveys == 0 || a.place_bad >= CW_PLACE_BAD_WINDOWS)) {
-        if (a.surveys) {
-            if (verbose) fprintf(stderr, "[craftingworld] placement %d has read > 4 %% above its %.4f ms/step for %d windows: struck off, new survey\n",
-                                 a.place, a.place_ms, a.place_bad);
-            a.place_struck |= 1u << a.place;
-            if ((a.place_struck & 0xFFu) == 0xFFu) a.place_struck = 0;              // (all struck: the regime has moved as a whole; start over)
-        }
-        a.surveying = true;
-        a.survey_w0 = w;
-        a.survey_seen = 0;
-        a.place_bad = 0;
-        a.surveys++;
-        for (int k = 0; k < CW_PLACES; k++) a.survey_ms[k][0] = a.survey_ms[k][1] = a.survey_ms[k][2] = 0.f;
-    }
-    if (a.surveying && w < a.survey_w0 + CW_SURVEY_ROUNDS * CW_PLACES) {         // a survey window: placement by turns, pace frozen
-        const unsigned j = w - a.survey_w0;
-        a.place_of_window[w % CW_ADAPT_RING] = (signed char)(j % CW_PLACES);
-        a.round_of_window[w % CW_ADAPT_RING] = (signed char)(j / CW_PLACES + 1);
-        a.pace_of_window[w % CW_ADAPT_RING] = (signed char)a.cur;
-        return;
-    }
-    a.place_of_window[w % CW_ADAPT_RING] = (signed char)a.place;                            // (survey windows still being read: the old placement meanwhile)
-    a.round_of_window[w % CW_ADAPT_RING] = 0;
-    if (moved && !a.surveying && a.pace_on) {        // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
+    if (moved && a.pace_on) {                        // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
         const int c = a.cur;
         auto fresh = [&](int p) { return p >= 0 && p <= CW_ADAPT_MAX && a.stat[p] > 0 && a.next_window - a.stat_window[p] < 80; };
         if (fresh(c)) {
@@ -690,7 +505,7 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
             if (fresh(c - 1) && a.stat[c - 1] < a.stat[best] * (best == c ? 0.993f : 1.0f)) best = c - 1;
             if (best != c) {
                 if (verbose)
-                    fprintf(stderr, "[craftingworld] sleeps beside resets (online, window %u): +%d %.4f ms/step | +%d %.4f | +%d %.4f -> +%d\n", w, c,
+                    fprintf(stderr, "[craftingworld] extra pace on steps with finished envs (online, window %u): +%d %.4f ms/step | +%d %.4f | +%d %.4f -> +%d\n", w, c,
                             a.stat[c], c + 1, fresh(c + 1) ? a.stat[c + 1] : 0.0, c - 1, fresh(c - 1) ? a.stat[c - 1] : 0.0, best);
                 a.cur = best;
             }
@@ -699,102 +514,12 @@ static void adapt_tick(cw_engine *e, hipStream_t st)
     // the cycle: 0-19 cur | 20 (settle), 21 cur + 1 | 22 (settle), 23 cur - 1; window 0 of the cycle settles too
     const unsigned pos = w % 24;
     int p = a.cur;
-    const bool settle = (pos == 0 || pos == 20 || pos == 22) || a.surveying;
-    if (!a.surveying && a.pace_on) {
+    const bool settle = (pos == 0 || pos == 20 || pos == 22);
+    if (a.pace_on) {
         if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
         else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
     }
     a.pace_of_window[w % CW_ADAPT_RING] = (signed char)(settle ? -1 - p : p);
-}
-
-// XCD-aware frame shares for the full-frame render kernel.  On MI355X the workgroups of every other XCD write ~15 % slower
-// than their neighbours' (workgroups go round-robin over the 8 XCDs, so it shows as even vs odd workgroup index), and a
-// launch lasts as long as its slowest wave.  Measure it instead of assuming it: a few equal-share launches with the waves'
-// busy time summed per index parity, then the slow class paints q_all frames per wave and the fast class the rest.  Only
-// performance depends on the outcome; which frames are painted does not (cw_kernels.hip: render_jobs).
-static int calibrate_render_shares(cw_engine *e)
-{
-    CwTuning &tn = e->tune;
-    tn.render_q_all = 0;
-    tn.render_fast_parity = -1;
-#ifdef CW_EXPERIMENT
-    const char *off = getenv("CW_TUNE_RENDER_SHARES");
-#else
-    const char *off = nullptr;
-#endif
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (off && atoi(off) == 0)) return CW_OK;   // (host-mapped frames: PCIe-bound anyway)
-    // the paced linear sweep does not profit (m+1: 0.2349 / 0.2349 / 0.2356 ms with shares, 0.2355 / 0.2353 / 0.2349 with equal ones,
-    // alternating on one box, profiles/history/r02_pace.txt): the shares are for the frame-per-wave kernel; CW_TUNE_RENDER_SHARES=1 forces them
-    // (the one-launch step runs the sweep on equal shares whatever is calibrated here: nothing to measure for it)
-    if (cwk_render_is_linear(&e->P, &tn) && (!(off && atoi(off) != 0) || cwk_step_renders_fused(&e->P, &tn, e->auto_reset))) return CW_OK;
-#ifdef CW_EXPERIMENT
-    const char *forced_shares = getenv("CW_TUNE_RENDER_QALL");              // "q_all,parity"
-#else
-    const char *forced_shares = nullptr;
-#endif
-    if (const char *q = forced_shares) {
-        int qa = 0, par = -1;
-        if (sscanf(q, "%d,%d", &qa, &par) == 2 && qa > 0 && (par == 0 || par == 1)) { tn.render_q_all = qa; tn.render_fast_parity = par; }
-        return CW_OK;
-    }
-    unsigned long long *stats = nullptr;
-    int rc = dev_alloc(e, &stats, 2);
-    if (rc != CW_OK) return rc;
-    int blocks = 0, wpb = 0;
-    e->P.render_stats = stats;
-    // busy[c] = summed busy time of the waves of workgroup-index parity c over 3 launches, after 3 warm-up launches, all queued
-    // back to back (see calibrate_render_pace: no host round trip between launches)
-    auto measure = [&](int q_all, int parity, double busy[2]) -> int {
-        unsigned long long h[2] = {0, 0};
-        bool ok = true;
-        for (int rep = 0; rep < 6 && ok; rep++) {
-            if (rep == 3) ok = hipMemsetAsync(stats, 0, sizeof(h), nullptr) == hipSuccess;
-            ok = ok && cwk_launch_render_calib(&e->P, &tn, nullptr, q_all, parity, &blocks, &wpb) == hipSuccess;
-        }
-        if (!ok || hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(CW_ERR_HIP, "cw_create: render calibration failed");
-        busy[0] = (double)h[0];
-        busy[1] = (double)h[1];
-        return CW_OK;
-    };
-    const int jobs = cwk_render_jobs(&e->P, &tn);              // frames, or (frame, row group) pairs of the linear sweep
-    double busy[2], busy0[2];
-    rc = measure(0, -1, busy0);                                  // equal shares
-    int q_all = 0, fast = -1;
-    long long n_half = 0;
-    if (rc == CW_OK && blocks >= 16 && !(blocks & 1) && busy0[0] > 0 && busy0[1] > 0) {
-        n_half = (long long)blocks * wpb / 2;
-        fast = busy0[1] < busy0[0] ? 1 : 0;
-        double rho = busy0[1 - fast] / busy0[fast];              // per-frame cost of the slow class relative to the fast one
-        if (rho >= 1.03) {
-            // the classes share the memory system, so shifting frames changes both costs: refine on what is measured
-            for (int it = 0; it < 3 && rc == CW_OK; it++) {
-                if (rho > 1.6) rho = 1.6;
-                q_all = (int)((double)jobs / ((double)n_half * (1.0 + rho)));
-                if (q_all < 1) { q_all = 0; break; }
-                rc = measure(q_all, fast, busy);
-                if (rc != CW_OK || busy[0] <= 0 || busy[1] <= 0) break;
-                const double q_fast = ((double)jobs - (double)q_all * (double)n_half) / (double)n_half;
-                const double per_frame_slow = busy[1 - fast] / (double)q_all, per_frame_fast = busy[fast] / q_fast;
-                rho = per_frame_slow / per_frame_fast;
-                if (rho < 1.0) rho = 1.0;
-            }
-            if (q_all >= 1) q_all = (int)((double)jobs / ((double)n_half * (1.0 + (rho > 1.6 ? 1.6 : rho))));
-        }
-    }
-    e->P.render_stats = nullptr;
-    if (rc != CW_OK) return rc;
-    if (q_all < 1) return CW_OK;                                 // small batch, or balanced already: equal shares
-    tn.render_q_all = q_all;
-    tn.render_fast_parity = fast;
-    const long long n_waves = 2 * n_half;
-    busy[0] = busy0[0];
-    busy[1] = busy0[1];
-    if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] render shares: waves of even/odd workgroups busy %.1f / %.1f us on equal shares -> %d jobs per slow wave, "
-                "%s workgroups take the rest\n", busy[0] / 3.0 / (double)(n_waves / 2) / 100.0, busy[1] / 3.0 / (double)(n_waves / 2) / 100.0,
-                q_all, fast ? "odd" : "even");
-    return CW_OK;
 }
 
 extern "C" {
@@ -872,43 +597,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
     P.raster = cfg->raster;
     P.frame_bytes = cfg->raster == CW_RASTER_ALT ? 27u * (uint32_t)e->S * (uint32_t)(e->S + 1) : 48u * (uint32_t)e->ncell;
-    P.grp_rows = e->S <= 64 ? 64 / e->S : 0;
-    P.grp_per_frame = P.grp_rows ? (e->S + P.grp_rows - 1) / P.grp_rows : 0;
-    {   // Tuning.  The defaults are the measured best; a product build reads six environment variables -- CW_TUNE_VERBOSE,
-        // CW_TUNE_RENDER_ADAPT, CW_TUNE_RENDER_PLACE, CW_TUNE_RENDER_PACE, CW_TUNE_RENDER_PACE_BESIDE, CW_TUNE_RENDER_CHUNK_ROUNDS -- and a
-        // build with -DCW_EXPERIMENT (libcraftingworld_exp.so: A/B runs and the tests that hold the older launch arrangements to the same
-        // results) the launch-shape knobs below as well.
+    {   // Tuning: the defaults are the measured best
         auto geti = [](const char *k, int d) { const char *v = getenv(k); return v ? atoi(v) : d; };
         CwTuning &tn = e->tune;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
-        tn.list_blocks = tn.n_cu;
-        P.tune_reset_prio = 2;                               // the render waves raise their priority, the reset kernel beside them does not
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
-        tn.render_place = geti("CW_TUNE_RENDER_PLACE", tn.render_place) & 7;
-        tn.piece_sweep = geti("CW_TUNE_PIECE_SWEEP", tn.piece_sweep);
-#ifdef CW_EXPERIMENT
-        P.tune_reset_prio = geti("CW_TUNE_RESET_PRIO", 2);
-        tn.render_blocks_per_cu = geti("CW_TUNE_RENDER_BLOCKS_PER_CU", tn.render_blocks_per_cu);
-        tn.render_blocks_abs = geti("CW_TUNE_RENDER_BLOCKS", tn.render_blocks_abs);
-        const int rt = geti("CW_TUNE_RENDER_THREADS", tn.render_threads);
-        if (rt == 64 || rt == 128 || rt == 256) tn.render_threads = rt;
-        tn.list_blocks = geti("CW_TUNE_LIST_BLOCKS", tn.list_blocks);
-        tn.overlap = geti("CW_TUNE_OVERLAP", tn.overlap);
-        tn.fused_step = geti("CW_TUNE_FUSED_STEP", tn.fused_step);
-        tn.profile_side = geti("CW_PROFILE_SIDE_STREAM", tn.profile_side);
-        tn.render_linear = geti("CW_TUNE_RENDER_LINEAR", tn.render_linear);
-        tn.render_pace_fine = geti("CW_TUNE_RENDER_FINE", tn.render_pace_fine);
-        tn.fused_render = geti("CW_TUNE_FUSED_RENDER", tn.fused_render);
-        tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS_PER_CU", tn.reset_blocks_per_cu);
-        tn.fused_reset_blocks_per_cu = geti("CW_TUNE_FUSED_RESET_BLOCKS_PER_CU", tn.fused_reset_blocks_per_cu);
-#endif
-        if (tn.reset_blocks_per_cu < 1) tn.reset_blocks_per_cu = 1;
-        if (tn.reset_blocks_per_cu > 8) tn.reset_blocks_per_cu = 8;
-        if (tn.fused_reset_blocks_per_cu < 1) tn.fused_reset_blocks_per_cu = 1;
-        if (tn.fused_reset_blocks_per_cu > 8) tn.fused_reset_blocks_per_cu = 8;
-        if (tn.render_blocks_per_cu < 1) tn.render_blocks_per_cu = 1;
-        if (tn.list_blocks < 1) tn.list_blocks = 1;
     }
 
     int rc = CW_OK;
@@ -935,7 +629,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(desired_out, N);
     ALLOC_OUT(episode_length, N);
     ALLOC(done_list, N);
-    ALLOC(done_count, 2);
+    ALLOC(done_count, 4);
     ALLOC(counters, 4);
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
@@ -944,6 +638,18 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (cfg->keep_terminal_obs && cfg->auto_reset) ALLOC_OUT(terminal_img, N * P.frame_bytes);
     }
     if (cfg->host_outputs && rc == CW_OK) rc = host_alloc(e, &e->host_actions, N);
+    if (P.terminal_img) {                            // the finished episode's last state, saved by the step kernel for its terminal frame
+        ALLOC(term_pos, N);
+        ALLOC(term_hx, N);
+    }
+    // look-ahead records: every engine that resets by itself and lives in device memory (CW_TUNE_LOOKAHEAD=0: the slow path only, for A/B runs
+    // and the test that both give the same results)
+    P.lookahead = (cfg->auto_reset && !cfg->host_outputs && !(getenv("CW_TUNE_LOOKAHEAD") && atoi(getenv("CW_TUNE_LOOKAHEAD")) == 0)) ? 1 : 0;
+    ALLOC(nx_init_pos, P.lookahead ? N : 1);
+    ALLOC(nx_goal_pos, P.lookahead ? N : 1);
+    ALLOC(nx_misc, P.lookahead ? N : 1);
+    ALLOC(refill_list, P.lookahead ? N : 1);
+    ALLOC(refill_count, 2);
 #undef ALLOC_OUT
 #undef ALLOC
     CwMenuDev *dmenus = nullptr;
@@ -961,16 +667,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (hipMemcpy(P.hdr, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(CW_ERR_HIP, "cw_create: header upload failed");
     }
-    if (rc == CW_OK && (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess))
-        rc = fail(CW_ERR_HIP, "cw_create: side stream / event creation failed");
     if (rc != CW_OK) {
         for (void *p : e->allocs) (void)hipFree(p);
         for (void *p : e->host_allocs) (void)hipHostFree(p);
-        if (e->side) (void)hipStreamDestroy(e->side);
-        if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-        if (e->ev_join) (void)hipEventDestroy(e->ev_join);
         delete e;
         return rc;
     }
@@ -992,31 +691,19 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
-    const int want_piece_sweep = e->tune.piece_sweep;
-    e->tune.piece_sweep = 0;                                       // (the frame-per-wave painter first: its pace and shares also serve the frames of resets)
-    if (rc == CW_OK) rc = calibrate_render_pace(e, false);
-    if (rc == CW_OK) rc = calibrate_render_shares(e);
-    if (rc == CW_OK && e->tune.render_fast_parity >= 0) rc = calibrate_render_pace(e, true);
-    e->tune.piece_sweep = want_piece_sweep;
-    if (rc == CW_OK) rc = calibrate_piece_sweep(e);
-    if (rc == CW_OK) e->tune.render_pace |= (e->tune.render_pace_fine & 0xFF) << 16;
+    if (rc == CW_OK) rc = calibrate_pace(e);
     if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
-        (cwk_render_is_linear(&e->P, &e->tune) || cwk_render_is_piece_sweep(&e->P, &e->tune)) && !(getenv("CW_TUNE_RENDER_ADAPT") && atoi(getenv("CW_TUNE_RENDER_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
+        !(getenv("CW_TUNE_ADAPT") && atoi(getenv("CW_TUNE_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
         cw_engine::Adapt &a = e->adapt;
-        a.cur = (e->tune.render_pace >> 12) & 15;
+        a.cur = e->tune.pace_beside;
         if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
-        a.pace_on = !getenv("CW_TUNE_RENDER_PACE_BESIDE");
-        a.place = e->tune.render_place;
-        a.place_on = !getenv("CW_TUNE_RENDER_PLACE") && cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset) && cwk_render_is_linear(&e->P, &e->tune) &&
-                     !cwk_render_is_piece_sweep(&e->P, &e->tune);          // (the placements are render_groups': nothing to survey for the sweep of pieces)
-        // (3) only the Ray raster's unpaced piece sweep (AltObs runs paced already), and only if nobody forced a pace
-        a.guard_on = cwk_render_is_piece_sweep(&e->P, &e->tune) && e->P.raster != CW_RASTER_ALT && e->tune.piece_pace == 0 && !getenv("CW_TUNE_PIECE_PACE") &&
+        a.pace_on = !getenv("CW_TUNE_PACE_BESIDE");
+        // (2) only the Ray raster's unpaced sweep (AltObs runs paced already), and only if nobody forced a pace
+        a.guard_on = e->P.raster != CW_RASTER_ALT && e->tune.piece_pace == 0 && !getenv("CW_TUNE_PIECE_PACE") &&
                      !(getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 0);
-#ifdef CW_EXPERIMENT
         a.guard_test = a.guard_on && getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 2;
-#endif
         if (a.guard_on && !a.guard_test) a.guard[2] = 3.f;                    // (the opening survey)
-        if (a.pace_on || a.place_on || a.guard_on) {
+        if (a.pace_on || a.guard_on) {
             for (hipEvent_t &ev : a.ev)
                 if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
             a.on = rc == CW_OK;
@@ -1039,14 +726,21 @@ int cw_destroy(cw_engine *e)
     (void)hipDeviceSynchronize();
     prof_free(e);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
-    if (e->side) (void)hipStreamDestroy(e->side);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (hipEvent_t ev : e->adapt.ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
     return CW_OK;
+}
+
+// A new stream makes the records computed from the old one void: drop them all; the next refill covers every env.
+static hipError_t lookahead_drop(cw_engine *e)
+{
+    if (!e->P.lookahead) return hipSuccess;
+    hipError_t rc = hipMemsetAsync(e->P.nx_misc, 0, (size_t)e->n * sizeof(uint4), nullptr);
+    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.refill_count, 0, 2 * sizeof(int32_t), nullptr);
+    e->la_refill_all = true;
+    return rc;
 }
 
 // Both seeders run on the device (cw_seed_kernel, one lane per env): the host only copies what the caller handed over.
@@ -1064,6 +758,7 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
     HIP_TRY(hipMemcpy(e->P.mt, keys, N * CW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->P.mt_idx, pos, N * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, nullptr, nullptr));
+    HIP_TRY(lookahead_drop(e));
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }
@@ -1077,6 +772,7 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, nullptr));
+    HIP_TRY(lookahead_drop(e));
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }
@@ -1093,6 +789,12 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     HIP_TRY(hipMemcpy(words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < N; i++) cwh_mt_to_numpy(&words[i * CW_MT_N], pos[i], keys + i * CW_MT_N);
+    if (e->P.lookahead) {                            // the engine's streams are one reset ahead where a record waits: report the position BEFORE it
+        std::vector<uint32_t> misc(N * 4);
+        HIP_TRY(hipMemcpy(misc.data(), e->P.nx_misc, N * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++)
+            if (misc[i * 4 + 2] >> 31) cwh_mt_rewind(keys + i * CW_MT_N, &pos[i], misc[i * 4 + 3]);
+    }
     return CW_OK;
 }
 
@@ -1103,6 +805,13 @@ int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    if (e->P.lookahead && e->has_reset) {            // records wait, computed from the stream the pool is about to draw from: rewind and drop them
+        std::vector<uint32_t> keys((size_t)e->n * CW_MT_N);
+        std::vector<int32_t> pos((size_t)e->n);
+        int rc = cw_get_mt(e, keys.data(), pos.data());
+        if (rc == CW_OK) rc = cw_seed_mt(e, keys.data(), pos.data());
+        if (rc != CW_OK) return rc;
+    }
     HIP_TRY(cwk_launch_pool(&e->P, &e->tune, (hipStream_t)stream));
     // one-time, off the hot path: the pool and the advanced RNG streams are complete before any other stream can reset from them
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1116,6 +825,11 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
+    if (e->P.lookahead) {                            // every env's NEXT episode, ahead of time (cw_refill_kernel)
+        HIP_TRY(cwk_launch_refill(&e->P, &e->tune, 1, (hipStream_t)stream));
+        e->la_refill_all = false;
+        e->la_steps = 0;
+    }
     e->has_reset = true;
     e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     return CW_OK;
@@ -1131,22 +845,24 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     PARK(e);
     e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    if (e->adapt.on) {                               // full-frame mode: the sweep's extra sleeps beside resets follow what the steps measure (adapt_tick)
+    if (e->adapt.on) {                               // full-frame mode: the sweep's pace follows what the steps measure (adapt_tick)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
             if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
             const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING];
-            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | ((pw < 0 ? -1 - pw : pw) << 12);
-            if (e->adapt.place_on) e->tune.render_place = e->adapt.place_of_window[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING];
+            e->tune.pace_beside = pw < 0 ? -1 - pw : pw;
             if (ev) e->adapt.tainted[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING] = true;
             e->adapt.seq++;
         } else {
-            e->tune.render_pace = (e->tune.render_pace & 0xFF01FF) | (e->adapt.cur << 12);     // a captured graph keeps the values it was captured with
-            if (e->adapt.place_on) e->tune.render_place = e->adapt.place;
+            e->tune.pace_beside = e->adapt.cur;      // a captured graph keeps the values it was captured with
         }
     }
-    HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, e->side,
-                            e->ev_fork, e->ev_join, ev));
+    if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
+        HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
+        e->la_refill_all = false;
+        e->la_steps = 0;
+    }
+    HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, ev));
     if (ev) e->prof_n++;
     return CW_OK;
 }
@@ -1219,6 +935,11 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
+    if (e->P.lookahead) {
+        HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
+        e->la_refill_all = false;
+        e->la_steps = 0;
+    }
     HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
@@ -1299,7 +1020,7 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
     memset(out, 0, sizeof(*out));
     const int n = e->prof_n;
     if (n > 0) {
-        const bool side_recorded = e->tune.profile_side || !(e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && e->tune.overlap);
+        const bool side_recorded = e->obs_mode != CW_OBS_PIXELS_FULL;      // (full-frame mode: only the sweep is bracketed)
         for (int k = 0; k < 6; k++)
             if (side_recorded || k >= 4) HIP_TRY(hipEventSynchronize(e->prof_ev[(size_t)(n - 1) * 6 + k]));
         double acc[3] = {0, 0, 0};
@@ -1330,27 +1051,20 @@ int cw_profile_end(cw_engine *e, cw_profile *out)
 const char *cw_render_kernel_name(const cw_engine *e)
 {
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
-    if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset && e->tune.fused_step ? "cw_step_fused_kernel" : "cw_step_kernel";
-    const bool one_launch = cwk_step_renders_fused(&e->P, &e->tune, e->auto_reset);
-    if (cwk_render_is_piece_sweep(&e->P, &e->tune)) return one_launch ? "cw_render_pieces_step_kernel" : "cw_render_pieces_kernel";
-    if (!cwk_render_is_linear(&e->P, &e->tune)) return one_launch ? "cw_render_frames_step_kernel" : "cw_render_frames_kernel";
-    return one_launch ? "cw_render_step_kernel" : "cw_render_kernel";
+    if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset ? "cw_step_fused_kernel" : "cw_step_kernel";
+    return e->auto_reset ? "cw_render_pieces_step_kernel" : "cw_render_pieces_kernel";
 }
 
 int cw_tuner(const cw_engine *e, cw_tuner_state *out)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_tuner: null argument");
     const cw_engine::Adapt &a = e->adapt;
-    out->place = a.place_on ? a.place : e->tune.render_place;
-    out->surveys = (int32_t)a.surveys;
-    out->struck_mask = (int32_t)a.place_struck;
-    out->sleeps_beside = a.on && a.pace_on ? a.cur : (e->tune.render_pace >> 12) & 15;
-    out->place_tuned = a.on && a.place_on ? 1 : 0;
-    out->sleeps_tuned = a.on && a.pace_on ? 1 : 0;
-    out->painter = cwk_render_is_piece_sweep(&e->P, &e->tune) ? 2 : cwk_render_is_linear(&e->P, &e->tune) ? 1 : 0;
     out->piece_pace = e->tune.piece_pace;
+    out->pace_beside = a.on && a.pace_on ? a.cur : e->tune.pace_beside;
+    out->pace_beside_tuned = a.on && a.pace_on ? 1 : 0;
     out->guard_state = a.on && a.guard_on ? (int32_t)a.guard[2] : -1;
     out->guard_trials = a.guard_trials;
+    out->lookahead = e->P.lookahead;
     return CW_OK;
 }
 
@@ -1564,7 +1278,7 @@ struct CwCkptHeader {
     char magic[8];
     uint32_t version, header_bytes;
     int32_t n_envs, size, max_steps, pool_k;
-    uint32_t task_mask, n_menus;
+    uint32_t task_mask, n_menus, lookahead, reserved;
     uint64_t menus_hash, total_bytes;
 };
 static const char CW_CKPT_MAGIC[8] = {'C', 'W', 'C', 'K', 'P', 'T', 0, 1};
@@ -1577,7 +1291,10 @@ static std::vector<CkptSection> ckpt_sections(cw_engine *e)
     return {{P.hdr, N * 16}, {P.pos, N * 16}, {P.init_pos, N * 16}, {P.goal_pos, N * 16}, {P.goal_codes, N * 4},
             {P.init_agent, N * 2}, {P.goal_agent, N * 2}, {P.ep_no, N * 4}, {P.mt, N * CW_MT_N * 4}, {P.mt_idx, N * 4},
             {P.pool, N * (size_t)e->K * 9 * 2}, {P.reward, N * 4}, {P.done, N}, {P.achieved_out, N * 2}, {P.desired_out, N * 2},
-            {P.episode_length, N * 4}, {P.counters, 4 * 8}};
+            {P.episode_length, N * 4}, {P.counters, 4 * 8},
+            // the look-ahead records, verbatim (the RNG streams above are one reset ahead wherever one waits)
+            {P.nx_init_pos, P.lookahead ? N * 16 : 0}, {P.nx_goal_pos, P.lookahead ? N * 16 : 0}, {P.nx_misc, P.lookahead ? N * 16 : 0},
+            {P.refill_list, P.lookahead ? N * 4 : 0}, {P.refill_count, P.lookahead ? (size_t)8 : 0}};
 }
 static uint64_t menus_hash(const cw_engine *e)
 {
@@ -1590,10 +1307,11 @@ static CwCkptHeader ckpt_header(cw_engine *e)
 {
     CwCkptHeader h{};
     memcpy(h.magic, CW_CKPT_MAGIC, 8);
-    h.version = 1;
+    h.version = 2;                                   // 2: look-ahead records
     h.header_bytes = (uint32_t)sizeof(CwCkptHeader);
     h.n_envs = e->n; h.size = e->S; h.max_steps = e->P.max_steps; h.pool_k = e->K;
     h.task_mask = e->P.task_mask; h.n_menus = (uint32_t)e->menus.size();
+    h.lookahead = (uint32_t)e->P.lookahead;
     h.menus_hash = menus_hash(e);
     h.total_bytes = sizeof(CwCkptHeader);
     for (const CkptSection &sec : ckpt_sections(e)) h.total_bytes += sec.bytes;
@@ -1634,7 +1352,7 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (length < sizeof(h)) return fail(CW_ERR_INVALID, "cw_checkpoint_load: %zu bytes is not a checkpoint", length);
     memcpy(&h, buf, sizeof(h));
     const CwCkptHeader mine = ckpt_header(e);
-    if (memcmp(h.magic, CW_CKPT_MAGIC, 8) != 0 || h.version != 1 || h.header_bytes != sizeof(CwCkptHeader))
+    if (memcmp(h.magic, CW_CKPT_MAGIC, 8) != 0 || h.version != 2 || h.header_bytes != sizeof(CwCkptHeader))
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: not a CraftingWorld checkpoint (or another version)");
     if (h.n_envs != mine.n_envs || h.size != mine.size || h.max_steps != mine.max_steps || h.pool_k != mine.pool_k ||
         h.task_mask != mine.task_mask)
@@ -1644,6 +1362,9 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (h.n_menus != mine.n_menus || h.menus_hash != mine.menus_hash)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: the checkpoint was written with different task menus (selected_tasks / "
                     "number_of_tasks / stacking / reward_style)");
+    if (h.lookahead != mine.lookahead)
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: the checkpoint was written %s look-ahead records, this engine runs %s them (auto_reset / CW_TUNE_LOOKAHEAD)",
+                    h.lookahead ? "with" : "without", mine.lookahead ? "with" : "without");
     if (h.total_bytes != mine.total_bytes || length < h.total_bytes)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
     HIP_TRY(hipDeviceSynchronize());
@@ -1653,6 +1374,7 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
         p += sec.bytes;
     }
     e->has_reset = true;
+    e->la_refill_all = e->P.lookahead != 0;          // (harmless: envs that hold a record are skipped)
     if (e->obs_mode != CW_OBS_STATE) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));   // frames follow the records
     HIP_TRY(hipDeviceSynchronize());
     return CW_OK;

@@ -1,24 +1,23 @@
 // cw_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the CraftingWorld engine.
 //
-//   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward,
-//                     done, wave-ballot compaction of the done list; in DIRTY pixel mode also
-//                     render_edit() (ray.py:522-557) of the <=2 changed cells.  (Full-frame mode and
-//                     engines without auto-reset.)
-//   cw_step_fused_kernel  state-only / dirty-cell modes: the whole auto-reset step in ONE launch -- a wave
-//                     steps its 8..64 envs and resets the finished ones inline.
-//   cw_reset_kernel   one WAVEFRONT per finished env: reset() of ray.py:156-218 = task draw, legacy
-//                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS,
-//                     lane-parallel rejection sampling), imagine_obs(); in the pixel modes the same
-//                     wave then paints the env's three frames (obs, init_obs, desired_goal).
-//   cw_render_kernel  one wavefront per frame: render() of ray.py:442-520; a lane paints one cell's
-//                     4 pixel rows with 4 x 12-byte stores; the records of a wave's 64 frames are fetched
-//                     one per lane up front; frame shares per workgroup parity are XCD-aware.
-//   cw_render_reset_kernel  the three frames of every env after cw_reset; terminal frames of the done list.
+//   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward, done; a finished env takes over the
+//                     record of its next episode (LOOK-AHEAD, cw_layout.h) in the same lane; wave-ballot compaction of the done list.
+//                     (Full-frame mode and engines without auto-reset; in DIRTY pixel mode also render_edit(), ray.py:522-557.)
+//   cw_step_fused_kernel  state-only / dirty-cell modes: the whole auto-reset step in ONE launch -- a wave steps its 8..64 envs,
+//                     finished ones take their records, whatever is left is reset inline.
+//   cw_refill_kernel  one WAVEFRONT per env: the NEXT reset() of ray.py:156-218, ahead of time and in bulk = task draw, legacy
+//                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS, lane-parallel rejection sampling),
+//                     imagine_obs().  cw_reset_kernel: the same for every env at once (explicit reset()).
+//   cw_render_pieces_kernel  render() of ray.py:442-520 (and the AltObs raster) for a whole frame ARRAY as a sweep of aligned 4-KiB
+//                     pieces: a zero fill plus the few lit bytes of the frames a piece overlaps.  The roofline kernel.
+//   cw_list_kernel    after the sweep: INIT_OBS / desired_goal frames of the envs that finished on this step, terminal frames, and the
+//                     reset of any env that found no record.
 //   cw_rollout_kernel persistent: T steps of every env in one launch (state-only mode).
+//   cw_resident_kernel  the single-env loop without a launch per step (doorbell in pinned host memory).
 //   cw_export_*       dense grid / one-hot views of the slot state.
 //
 // All integer; no MFMA (nothing here is a contraction: the reference's tensordot with a one-hot
-// operand is a table lookup).  Bounding resource: HBM write bandwidth for cw_render_kernel,
+// operand is a table lookup).  Bounding resource: HBM write bandwidth for cw_render_pieces_kernel,
 // issue/latency for the others.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,11 +26,8 @@
 #include "cw_mt.h"
 
 #define CW_WAVE 64
-// per-class busy time of the render waves (100 MHz wall clock), summed into P.render_stats[class] when the engine is
-// calibrating (cw_create) -- a null pointer otherwise, and then this is two scalar clock reads per wave
-#define CW_WAVE_CLOCK(var) const unsigned long long var = wall_clock64()
-#define CW_WAVE_BUSY(P, t0, cls) do { if ((P).render_stats && lane == 0) atomicAdd((P).render_stats + (cls), wall_clock64() - (t0)); } while (0)
 #define CW_BALLOT(p) __builtin_amdgcn_ballot_w64(p)   // the compare's own SGPR pair (__ballot goes through a select + compare)
+#define CW_ALT_FRAME_PACE 2    // render_frame_alt: s_sleep(1) after each 1-KiB store of a single frame's zero fill (back to back 3.0 TB/s, with 64-192 idle clocks 5.2-5.4)
 
 // -DCW_TRACE (make trace -> libcraftingworld_trace.so, tools/microbench only): 100 MHz wall-clock stamps of the reset's phases
 #ifdef CW_TRACE
@@ -39,12 +35,8 @@ __device__ unsigned long long cw_trace_buf[1024 * 8];
 #define CW_STAMP(env, k) do { if (lane == 0) { cw_trace_buf[((env) & 1023) * 8 + (k)] = wall_clock64(); \
                                                if ((k) == 0 || (k) == 5) cw_trace_buf[((env) & 1023) * 8 + 6 + ((k) ? 1 : 0)] = clock64(); } } while (0)
 extern "C" hipError_t cwk_trace_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cw_trace_buf), sizeof(cw_trace_buf)); }
-__device__ unsigned long long cw_trace_render[1024 * 2];      // per render wave: start, end (100 MHz wall clock)
-extern "C" hipError_t cwk_trace_render_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cw_trace_render), sizeof(cw_trace_render)); }
-#define CW_WAVE_STAMP(wave, k) do { if (lane == 0) cw_trace_render[((wave) & 1023) * 2 + (k)] = wall_clock64(); } while (0)
 #else
 #define CW_STAMP(env, k) do { } while (0)
-#define CW_WAVE_STAMP(wave, k) do { } while (0)
 #endif
 
 enum { EMPTY = 0, STICKS = 1, AXE = 2, HAMMER = 3, ROCK = 4, TREE = 5, BREAD = 6, HOUSE = 7, WHEAT = 8 };
@@ -239,6 +231,86 @@ __device__ __forceinline__ void render_frame_alt(uint8_t *__restrict__ dst0, uin
     }
 }
 
+// ------------------------------------------------------------------------------------ single frames
+// One wavefront paints one frame, 64 cells per iteration: lane = one cell (row-major), whose colour
+// is an 8-compare chain against the wave-uniform slot positions (SGPRs), computed ONCE and stored
+// to the cell's 4 pixel rows as 4 x 12 B (global_store_dwordx3).  This is the painter of single frames
+// -- the frames of the done list (cw_list_kernel), of resets inlined in the dirty-cell step, of cw_render
+// into an array the sweep's 16-byte stores cannot take; every whole ARRAY is swept (render_pieces below).
+// Plain stores: nontemporal ones measured 25 % slower in this shape (tools/microbench).
+__device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
+                                             int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
+                                             const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
+                                             int lane)
+{
+    const uint32_t row_bytes = 12u * S;
+    for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
+        const uint32_t r = __umulhi(cell, div_magic);
+        const uint32_t c = cell - r * S;
+        uint32_t col = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? rgb[k] : col;
+        const u32x3 d = cell_row_dwords(col);
+        const bool ag = (cell == agent_cell);
+        const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
+        const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
+        const size_t off = (size_t)(4u * r) * row_bytes + 12u * c;
+        uint8_t *q = dst0 + off;
+        *(u32x3_a4 *)(q) = d;
+        *(u32x3_a4 *)(q + row_bytes) = d1;
+        *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
+        *(u32x3_a4 *)(q + 3 * row_bytes) = d;
+        if (dst1) {
+            uint8_t *q1 = dst1 + off;
+            *(u32x3_a4 *)(q1) = d;
+            *(u32x3_a4 *)(q1 + row_bytes) = d1;
+            *(u32x3_a4 *)(q1 + 2 * row_bytes) = d2;
+            *(u32x3_a4 *)(q1 + 3 * row_bytes) = d;
+        }
+    }
+}
+// one frame of either raster from wave-uniform values: slot positions / codes, agent cell, hold
+__device__ __forceinline__ void paint_state_frame(const CwParams &P, uint8_t *dst, const uint32_t sp[8], uint32_t codes, uint32_t agent_cell,
+                                                  uint32_t hold, int lane)
+{
+    if (P.raster == 1) {
+        render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, sp, codes, agent_cell, hold, lane, CW_ALT_FRAME_PACE);
+    } else {
+        uint32_t rgb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
+        render_frame(dst, nullptr, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
+    }
+}
+// which of an env's three states a frame shows: its current one (observation), the one at reset (INIT_OBS), imagine_obs' final one (desired_goal)
+enum { CW_SRC_CURRENT = 0, CW_SRC_INIT = 1, CW_SRC_GOAL = 2 };
+// ... as wave-uniform values (every lane loads the same record)
+__device__ __forceinline__ void load_state_uniform(const CwParams &P, int env, int src, uint32_t sp[8], uint32_t &codes, uint32_t &agent_cell, uint32_t &hold)
+{
+    uint4 v_p;
+    uint32_t v_c, v_a, v_h = 0;
+    if (src == CW_SRC_CURRENT) {
+        const uint4 h = P.hdr[env];
+        v_p = P.pos[env];
+        v_c = h.w;
+        v_a = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+        v_h = (h.x >> 16) & 0xFFu;
+    } else if (src == CW_SRC_INIT) {
+        v_p = P.init_pos[env];
+        v_c = CW_CODES_INITIAL;
+        v_a = P.init_agent[env];
+    } else {
+        v_p = P.goal_pos[env];
+        v_c = P.goal_codes[env];
+        v_a = P.goal_agent[env];
+    }
+    unpack_pos(make_uint4(__builtin_amdgcn_readfirstlane(v_p.x), __builtin_amdgcn_readfirstlane(v_p.y), __builtin_amdgcn_readfirstlane(v_p.z),
+                          __builtin_amdgcn_readfirstlane(v_p.w)), sp);
+    codes = __builtin_amdgcn_readfirstlane(v_c);
+    agent_cell = __builtin_amdgcn_readfirstlane(v_a);
+    hold = __builtin_amdgcn_readfirstlane(v_h);
+}
+
 // ------------------------------------------------------------------------------------ step
 // One env's step() on registers (ray.py:301-378).  Shared by cw_step_kernel (one launch per step)
 // and cw_rollout_kernel (T steps in one persistent launch).
@@ -368,6 +440,33 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
     return o;
 }
 
+// LOOK-AHEAD (cw_layout.h): the finished env `env` takes over the record of its next episode, if the refill kernel has left one -- the whole
+// of reset() (ray.py:156-218) as three 16-byte loads and the stores of the episode records, by the lane that stepped the env.  h / sp become
+// the new episode's header and slots (reset_header's values).  -> false: no record (the env finished twice between two refills, or the
+// engine keeps none); the caller hands the env to the slow path, which resets it from the same position of its stream.
+__device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint4 &h, uint32_t sp[8], bool count_episode)
+{
+    const uint4 m = P.nx_misc[env];
+    if (!(m.z >> 31)) return false;
+    const uint4 ipos = P.nx_init_pos[env];
+    P.init_pos[env] = ipos;
+    P.goal_pos[env] = P.nx_goal_pos[env];
+    P.goal_codes[env] = m.y;
+    P.init_agent[env] = (uint16_t)(m.x & 0xFFFFu);
+    P.goal_agent[env] = (uint16_t)(m.x >> 16);
+    if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
+    ((uint32_t *)(P.nx_misc + env))[2] = m.z & 0x7FFFFFFFu;       // taken
+    const uint32_t ia = m.x & 0xFFFFu;
+    const uint32_t ar = __umulhi(ia, P.div_magic), ac = ia - ar * P.size;
+    h.x = ar | (ac << 8) | (h.x & 0xFF000000u);                   // (the menu id stays)
+    h.y = (m.z & 0xFFFFu) << 16;
+    h.z = (CW_FLAG_RESET | (((m.z >> 16) & 1u) ? CW_FLAG_SUBSET : 0u)) << 16;
+    h.w = CW_CODES_INITIAL;
+    unpack_pos(ipos, sp);
+    return true;
+}
+#define CW_LIST_POPPED 0x80000000u    // done-list entry: the env took its look-ahead record (its state is the new episode's already)
+
 __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype,
                                                       int compact, int paint_dirty)
 {
@@ -376,7 +475,7 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
     }
     const bool live = i < P.n_envs;
-    bool done = false, success = false, invalid = false;
+    bool done = false, success = false, invalid = false, popped = false;
     if (live) {
         int a;
         if (act_dtype == 0) a = ((const int32_t *)actions)[i];
@@ -389,15 +488,7 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         const CwStepOut o = step_env(P, h, sp, a, [&]() { return P.init_pos[i]; });
         done = o.done; success = o.success; invalid = o.invalid;
 
-        P.hdr[i] = h;
-        P.pos[i] = pack_pos(sp);
-        P.reward[i] = o.reward;
-        P.done[i] = done ? 1 : 0;
-        P.achieved_out[i] = (uint16_t)o.achieved;
-        P.desired_out[i] = (uint16_t)o.desired;
-        if (done) P.episode_length[i] = (int32_t)o.step_num;
-
-        if (paint_dirty && o.changed) {                                    // render_edit, :358
+        if (paint_dirty && o.changed) {                                    // render_edit, :358 (engines without auto-reset)
             uint8_t *frame = P.obs + (size_t)i * P.frame_bytes;
             const uint32_t hold = (h.x >> 16) & 0xFFu;
             const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
@@ -415,42 +506,58 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
                     paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
             }
         }
+        if (done && compact) {                                             // auto-reset
+            if (P.term_pos) {                                              // keep_terminal_obs: the episode's last state, for its terminal frame
+                P.term_pos[i] = pack_pos(sp);
+                P.term_hx[i] = make_uint2(h.x, h.w);
+            }
+            if (P.lookahead) popped = pop_next_episode(P, i, h, sp, true);
+        }
+        P.hdr[i] = h;
+        P.pos[i] = pack_pos(sp);
+        P.reward[i] = o.reward;
+        P.done[i] = done ? 1 : 0;
+        P.achieved_out[i] = (uint16_t)o.achieved;
+        P.desired_out[i] = (uint16_t)o.desired;
+        if (done) P.episode_length[i] = (int32_t)o.step_num;
     }
 
     // done-mask compaction with wavefront ballots (64-bit on CDNA)
     const unsigned long long m_done = CW_BALLOT(done);
     const unsigned long long m_succ = CW_BALLOT(success);
     const unsigned long long m_inv = CW_BALLOT(invalid);
+    const unsigned long long m_pop = CW_BALLOT(popped);
     if (m_done | m_inv) {
         const int lane = threadIdx.x & (CW_WAVE - 1);
-        int base = 0;
+        int base = 0, rbase = 0;
         if (lane == 0) {
             if (m_done) {
                 if (compact) base = atomicAdd(&P.done_count[0], __popcll(m_done));
                 atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
             }
+            if (m_pop) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
             if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
             if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
         }
         base = __shfl(base, 0);
-        if (done && compact) {
-            const unsigned long long below = m_done & ((1ull << lane) - 1ull);
-            P.done_list[base + __popcll(below)] = i;
-        }
+        rbase = __shfl(rbase, 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (done && compact) P.done_list[base + __popcll(m_done & below)] = (int32_t)((uint32_t)i | (popped ? CW_LIST_POPPED : 0u));
+        if (popped) P.refill_list[rbase + __popcll(m_pop & below)] = i;      // the refill kernel computes the env's next record
     }
 }
 
 // The done counter is zeroed for the next step by the LAST workgroup of the last kernel that reads
 // it (a ticket in done_count[1]) -- no host-side parity and no memset node, so one cw_step is a
 // fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is.
-__device__ __forceinline__ void release_done_list(const CwParams &P, int n_blocks)
+__device__ __forceinline__ void release_list(int32_t *count, int n_blocks)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = atomicAdd(&P.done_count[1], 1);
+        const int t = atomicAdd(&count[1], 1);
         if (t == n_blocks - 1) {
-            P.done_count[0] = 0;
-            P.done_count[1] = 0;
+            count[0] = 0;
+            count[1] = 0;
         }
     }
 }
@@ -585,8 +692,6 @@ __device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint3
 // 65 536 envs succeed on almost every step, and 1-5 resetting waves do not disturb the sweep -- reacting to them cost 15 us on most
 // launches of the synchronized benchmark (the "two launch modes" of profiles/history/r02_pace.txt H)
 #define CW_BESIDE_MIN 32
-#define CW_PLACE_DEFAULT 3   // placement of render_groups' batch loop where no tuner picks it (cw_render, the two-kernel step)
-#define CW_N_PLACES 8
 
 // One env's reset() (ray.py:156-218) by one wavefront; every value in the result is wave-uniform.
 struct CwResetOut {
@@ -595,6 +700,7 @@ struct CwResetOut {
     uint4 goal_pos;          // imagine_obs final state
     uint32_t goal_codes, goal_agent;
     uint32_t desired, subset;
+    uint32_t draws;          // raw 32-bit draws taken from the env's stream
 };
 
 // menu_fn() yields the env's task-menu id; it is called after the MT state's loads are in flight, so a caller that
@@ -700,6 +806,7 @@ __device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env,
     }
 
     CW_STAMP(env, 4);
+    const uint32_t draws = mt.draws();
     mt.store(P.mt + (size_t)env * CW_MT_WORDS, P.mt_idx + env, lane);   // coalesced write-back
     CW_STAMP(env, 5);
     CwResetOut r;
@@ -713,6 +820,7 @@ __device__ __forceinline__ CwResetOut reset_env_wave(const CwParams &P, int env,
     r.goal_agent = agent;
     r.desired = desired;
     r.subset = M.reward_subset ? 1u : 0u;
+    r.draws = draws;
     return r;
 }
 
@@ -739,12 +847,7 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
     if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
 }
 
-__device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1, int S, int ncell,
-                                             uint32_t div_magic, const uint32_t sp[8], const uint32_t rgb[8],
-                                             uint32_t agent_cell, uint32_t hold_rgb, int lane, int pace = 0);
-
-// the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the
-// wave that just reset it: no second kernel has to wait for the reset and re-read its records
+// the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the wave that just reset it
 __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, const CwResetOut &r, int lane)
 {
     const size_t off = (size_t)env * P.frame_bytes;
@@ -757,56 +860,150 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
         grgb[k] = rgb_of_code((r.goal_codes >> (4 * k)) & 15u);
     }
     if (P.raster == 1) {
-        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, P.alt_pace);
-        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, P.alt_pace);
+        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, CW_ALT_FRAME_PACE);
+        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, CW_ALT_FRAME_PACE);
     } else {
         render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
         render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
     }
 }
-
-// (bid of n_blocks: the workgroup's index among the resetting workgroups -- the whole grid for cw_reset_kernel, the grid's tail
-// for cw_render_step_kernel)
-__device__ __forceinline__ void reset_list_block(const CwParams &P, uint32_t (*s_mt)[CW_MT_WORDS], int bid, int n_blocks,
-                                                 int last_reader, int all_envs, int paint)
+// the last frame of the episode that just ended (keep_terminal_obs), from the state the step kernel saved before the env was reset in place
+__device__ __forceinline__ void paint_terminal_frame(const CwParams &P, int env, int lane)
 {
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = bid * CW_RESET_WAVES + wave_in_block;
-    const int n_waves = n_blocks * CW_RESET_WAVES;
-    // few, latency-critical waves sharing CUs with the render kernel's store-bound waves: win arbitration
-    if (P.tune_reset_prio == 1) __builtin_amdgcn_s_setprio(3);
-    // the wave's first list entry is fetched together with the count (entries past the count are stale but in bounds)
-    const int first = (!all_envs && wave < P.n_envs) ? P.done_list[wave] : 0;
-    const int count = all_envs ? P.n_envs : P.done_count[0];
-    // nothing finished on this step (most steps): nothing to reset and nothing to release, no ticket either.  Every workgroup reads
-    // the same count: the counter only changes when the last of n_blocks tickets has been drawn, i.e. after all of them have read it.
-    if (!all_envs && count == 0) return;
-    for (int job = wave; job < count; job += n_waves) {
-        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : (job == wave ? first : P.done_list[job]));
-        const uint32_t v_hx = P.hdr[env].x, v_hz = P.hdr[env].z;     // in flight beside the MT state
-        uint32_t menu_id = 0;
-        const CwResetOut r = reset_env_wave(P, env, [&]() { menu_id = __builtin_amdgcn_readfirstlane(v_hx) >> 24; return menu_id; },
-                                            s_mt[wave_in_block], lane);
-        const uint32_t h_old_z = __builtin_amdgcn_readfirstlane(v_hz);
-        if (lane == 0) {
-            store_episode_records(P, env, r, (h_old_z & 0xFFFFu) != 0);
-            P.pos[env] = r.init_pos;
-            P.hdr[env] = reset_header(P, r, menu_id);
-            if (all_envs) {                          // explicit reset(): the mask outputs describe the new episode
-                P.achieved_out[env] = 0;             // (an auto-reset leaves them at the finished step's values)
-                P.desired_out[env] = (uint16_t)r.desired;
-            }
-        }
-        if (paint) paint_reset_frames(P, env, r, lane);
-    }
-    if (!all_envs && last_reader) release_done_list(P, n_blocks);
+    const uint2 hx = P.term_hx[env];
+    uint32_t tp[8], stp[8];
+    unpack_pos(P.term_pos[env], tp);
+#pragma unroll
+    for (int k = 0; k < 8; k++) stp[k] = __builtin_amdgcn_readfirstlane(tp[k]);
+    const uint32_t h_x = __builtin_amdgcn_readfirstlane(hx.x), codes = __builtin_amdgcn_readfirstlane(hx.y);
+    paint_state_frame(P, P.terminal_img + (size_t)env * P.frame_bytes, stp, codes, (h_x & 0xFFu) * P.size + ((h_x >> 8) & 0xFFu), (h_x >> 16) & 0xFFu, lane);
+}
+// the record of an episode as the look-ahead arrays hold it (refill) / as the episode arrays hold it after a pop
+__device__ __forceinline__ void store_next_record(const CwParams &P, int env, const CwResetOut &r)
+{
+    P.nx_init_pos[env] = r.init_pos;
+    P.nx_goal_pos[env] = r.goal_pos;
+    P.nx_misc[env] = make_uint4(r.init_agent | (r.goal_agent << 16), r.goal_codes, r.desired | (r.subset << 16) | 0x80000000u, r.draws);
+}
+__device__ __forceinline__ CwResetOut load_episode_record(const CwParams &P, int env)
+{
+    CwResetOut r;
+    const uint4 ip = P.init_pos[env], gp = P.goal_pos[env];
+    r.init_pos = make_uint4(__builtin_amdgcn_readfirstlane(ip.x), __builtin_amdgcn_readfirstlane(ip.y), __builtin_amdgcn_readfirstlane(ip.z), __builtin_amdgcn_readfirstlane(ip.w));
+    r.goal_pos = make_uint4(__builtin_amdgcn_readfirstlane(gp.x), __builtin_amdgcn_readfirstlane(gp.y), __builtin_amdgcn_readfirstlane(gp.z), __builtin_amdgcn_readfirstlane(gp.w));
+    r.init_agent = __builtin_amdgcn_readfirstlane((uint32_t)P.init_agent[env]);
+    r.goal_agent = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[env]);
+    r.goal_codes = __builtin_amdgcn_readfirstlane(P.goal_codes[env]);
+    r.desired = r.subset = r.draws = 0;
+    return r;
 }
 
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P, int last_reader, int all_envs, int paint)
+// reset() of EVERY env (cw_reset, ray.py:156-218), one wavefront per env: a waiting look-ahead record is taken over, any other env is
+// reset here from its stream.  (cw_reset then sweeps the three frame arrays and refills the records.)
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    reset_list_block(P, s_mt, (int)blockIdx.x, (int)gridDim.x, last_reader, all_envs, paint);
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int n_waves = (int)gridDim.x * CW_RESET_WAVES;
+    for (int env = (int)blockIdx.x * CW_RESET_WAVES + wave_in_block; env < P.n_envs; env += n_waves) {
+        const uint4 v_h = P.hdr[env];                                 // in flight beside the MT state
+        const uint32_t menu_id = __builtin_amdgcn_readfirstlane(v_h.x) >> 24;
+        const bool count_episode = (__builtin_amdgcn_readfirstlane(v_h.z) & 0xFFFFu) != 0;   // ray.py:200-201
+        if (P.lookahead && (__builtin_amdgcn_readfirstlane(P.nx_misc[env].z) >> 31)) {        // the next episode is waiting
+            if (lane == 0) {
+                uint4 h = v_h;
+                uint32_t sp[8];
+                pop_next_episode(P, env, h, sp, count_episode);
+                P.pos[env] = pack_pos(sp);
+                P.hdr[env] = h;
+                P.achieved_out[env] = 0;                              // the mask outputs describe the new episode
+                P.desired_out[env] = (uint16_t)(h.y >> 16);           // (an auto-reset leaves them at the finished step's values)
+            }
+            continue;
+        }
+        const CwResetOut r = reset_env_wave(P, env, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
+        if (lane == 0) {
+            store_episode_records(P, env, r, count_episode);
+            P.pos[env] = r.init_pos;
+            P.hdr[env] = reset_header(P, r, menu_id);
+            P.achieved_out[env] = 0;
+            P.desired_out[env] = (uint16_t)r.desired;
+        }
+    }
+}
+
+// The done list of a full-frame step, AFTER the sweep, by the tail workgroups of the sweep's launch (most steps: nothing finished, they leave at once).
+// An env that took its look-ahead record in the step kernel is in its new episode already and its observation was an ordinary frame of the
+// sweep: INIT_OBS and desired_goal are left to paint, one frame per wave.  An env that found no record (it finished twice between two refills)
+// is reset here, the slow way, and all three of its frames painted -- the sweep showed its finished state, this comes after it in stream
+// order.  keep_terminal_obs: the last frame of the episode that ended, from the state the step kernel saved.
+// WHY NOT BESIDE THE SWEEP (rounds 1-3 reset and painted in the render launch's tail workgroups): anything that runs beside the sweep takes its
+// waves out of step and costs the launch far more than its own work -- ~220 resets per step 26 us, their frames alone (the resets gone, thanks to
+// the look-ahead records) still 26 us, the same frames painted by the sweep's own waves at their end 12-15 us; after the sweep, in this kernel,
+// the sweep runs as if nothing had finished; in a kernel of its own after the sweep the same, but an empty launch costs every step 8 us
+// (profiles/r04_lookahead.txt).
+__device__ __forceinline__ void list_block(const CwParams &P, uint32_t (*s_mt)[CW_MT_WORDS], int bid, int n_blocks, int sweep_blocks)
+{
+    const int count = __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count == 0) return;                              // (every workgroup reads the same value: it changes only after all of them have drawn a ticket)
+    if (threadIdx.x == 0)                                // asleep until the sweep is through (its workgroups were dispatched first: they are resident or done)
+        while (__hip_atomic_load(P.done_count + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sweep_blocks) __builtin_amdgcn_s_sleep(127);
+    __syncthreads();
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int n_waves = n_blocks * CW_RESET_WAVES;
+    for (int j = bid * CW_RESET_WAVES + wave_in_block; j < 2 * count; j += n_waves) {        // two jobs per entry
+        const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane(P.done_list[j >> 1]);
+        const int env = (int)(entry & ~CW_LIST_POPPED);
+        const bool second = j & 1;
+        const size_t off = (size_t)env * P.frame_bytes;
+        if (!second && P.terminal_img) paint_terminal_frame(P, env, lane);
+        if (entry & CW_LIST_POPPED) {
+            uint32_t sp[8], codes, agent_cell, hold;
+            load_state_uniform(P, env, second ? CW_SRC_GOAL : CW_SRC_INIT, sp, codes, agent_cell, hold);
+            paint_state_frame(P, (second ? P.desired_img : P.init_img) + off, sp, codes, agent_cell, hold, lane);
+        } else if (!second) {
+            const uint4 v_h = P.hdr[env];
+            const uint32_t menu_id = __builtin_amdgcn_readfirstlane(v_h.x) >> 24;
+            const CwResetOut r = reset_env_wave(P, env, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
+            if (lane == 0) {
+                store_episode_records(P, env, r, true);               // (step_num >= 1 here)
+                P.pos[env] = r.init_pos;
+                P.hdr[env] = reset_header(P, r, menu_id);
+            }
+            paint_reset_frames(P, env, r, lane);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&P.done_count[1], 1) == n_blocks - 1) {      // the last workgroup out zeroes the list for the next step
+        P.done_count[0] = 0;
+        P.done_count[1] = 0;
+        P.done_count[2] = 0;
+    }
+}
+
+// LOOK-AHEAD refill: the next reset() of every env of the refill list (all_envs: of every env without a record), run ahead of time from
+// the env's stream and parked in the nx_* arrays; the stream is left AFTER that reset (nx_misc.w says by how many draws).  Launched by the
+// host every few steps, between steps: thousands of resets side by side at one wave each cost ~5 ns per reset where ~200 of them beside every
+// sweep cost the step 25 us.  Same device function as the slow path, same stream order: results cannot differ.
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_refill_kernel(CwParams P, int all_envs)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
+    const int n_waves = gridDim.x * CW_RESET_WAVES;
+    const int count = all_envs ? P.n_envs : P.refill_count[0];
+    if (count == 0) return;                              // (every workgroup reads the same count: see reset_list_block)
+    for (int job = wave; job < count; job += n_waves) {
+        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.refill_list[job]);
+        const uint32_t v_hx = P.hdr[env].x;
+        if (all_envs && (__builtin_amdgcn_readfirstlane(P.nx_misc[env].z) >> 31)) continue;
+        const CwResetOut r = reset_env_wave(P, env, [&]() { return __builtin_amdgcn_readfirstlane(v_hx) >> 24; }, s_mt[wave_in_block], lane);
+        if (lane == 0) store_next_record(P, env, r);
+    }
+    release_list(P.refill_count, (int)gridDim.x);        // (all_envs too: whatever the list held has a record now)
 }
 
 // T consecutive steps of every env in ONE persistent launch (state-only observation mode): each
@@ -844,12 +1041,25 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
             if (rewards) rewards[(size_t)t * P.n_envs + env] = o.reward;
             if (dones) dones[(size_t)t * P.n_envs + env] = o.done ? 1 : 0;
         }
-        unsigned long long m = CW_BALLOT(live && o.done);
-        n_done += __popcll(m);
+        const unsigned long long m_all = CW_BALLOT(live && o.done);
+        n_done += __popcll(m_all);
         n_succ += __popcll(CW_BALLOT(live && o.success));
         n_inv += __popcll(CW_BALLOT(live && o.invalid));
-        if (m && t + 1 == T && live && o.done) P.episode_length[env] = (int32_t)o.step_num;
-        while (m) {                                  // auto-reset, one finished env at a time, whole wave
+        if (m_all && t + 1 == T && live && o.done) P.episode_length[env] = (int32_t)o.step_num;
+        bool popped = false;                         // auto-reset: the look-ahead record if there is one ...
+        if (live && o.done && P.lookahead) {
+            popped = pop_next_episode(P, env, h, sp, true);
+            if (popped) ip = pack_pos(sp);
+        }
+        const unsigned long long m_pop = CW_BALLOT(popped);
+        if (m_pop) {
+            int rbase = 0;
+            if (lane == 0) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
+            rbase = __shfl(rbase, 0);
+            if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
+        }
+        unsigned long long m = m_all & ~m_pop;
+        while (m) {                                  // ... else the slow way, one finished env at a time, whole wave
             const int l = __builtin_ctzll(m);
             m &= m - 1;
             const int env_l = env0 + l;
@@ -1021,38 +1231,47 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
             }
         }
     }
-    unsigned long long m = CW_BALLOT(done);
+    // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
+    const uint4 h_last = h;                          // (the finished episode's last state: keep_terminal_obs paints it below)
+    uint32_t sp_last[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
+    bool popped = false;
+    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true);
+    const unsigned long long m_all = CW_BALLOT(done), m_pop = CW_BALLOT(popped);
     const unsigned long long m_succ = CW_BALLOT(live && o.success);
     const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
+    int rbase = 0;
     if (lane == 0) {                                 // (one same-address atomic per wave would serialise the grid in L2)
         if (wave == 0) atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
-        if (m) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m));
+        if (m_all) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_all));
         if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
         if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
+        if (m_pop) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
     }
-    if (m && P.tune_reset_prio) __builtin_amdgcn_s_setprio(3);
+    if (m_pop) {
+        rbase = __shfl(rbase, 0);
+        if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
+    }
+    unsigned long long m = paint ? m_all : (m_all & ~m_pop);     // what is left for the whole wave: the slow resets, and in the pixel mode every finished env's frames
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const int env_l = env0 + l;
-        const uint32_t hx = __builtin_amdgcn_readlane(h.x, l);
+        const bool took = (m_pop >> l) & 1ull;
         if (paint && P.terminal_img) {               // keep_terminal_obs: the finished episode's last frame
-            uint32_t tp[8], rgb[8];
+            uint32_t tp[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) tp[k] = __builtin_amdgcn_readlane(sp[k], l);
-            const uint32_t codes = __builtin_amdgcn_readlane(h.w, l);
-            const uint32_t acell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
-            const uint32_t hold = (hx >> 16) & 0xFFu;
-            uint8_t *dst = P.terminal_img + (size_t)env_l * P.frame_bytes;
-            if (P.raster == 1) {
-                render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, tp, codes, acell, hold, lane, P.alt_pace);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
-                render_frame(dst, nullptr, P.size, P.ncell, P.div_magic, tp, rgb, acell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
-            }
+            for (int k = 0; k < 8; k++) tp[k] = __builtin_amdgcn_readlane(sp_last[k], l);
+            const uint32_t hx = __builtin_amdgcn_readlane(h_last.x, l), codes = __builtin_amdgcn_readlane(h_last.w, l);
+            paint_state_frame(P, P.terminal_img + (size_t)env_l * P.frame_bytes, tp, codes, (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu), (hx >> 16) & 0xFFu, lane);
         }
-        const uint32_t menu_id = hx >> 24;
+        if (took) {                                  // (the records lane l stored a moment ago, read back by the whole wave)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            paint_reset_frames(P, env_l, load_episode_record(P, env_l), lane);
+            continue;
+        }
+        const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
         const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
         if (lane == 0) store_episode_records(P, env_l, r, true);           // step_num >= 1 here
         if (lane == l) {
@@ -1086,371 +1305,59 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_pool_kernel(CwPara
     }
 }
 
-// ------------------------------------------------------------------------------------ render
-// One wavefront paints one frame, 64 cells per iteration: lane = one cell (row-major), whose colour
-// is an 8-compare chain against the wave-uniform slot positions (SGPRs), computed ONCE and stored
-// to the cell's 4 pixel rows as 4 x 12 B (global_store_dwordx3).  Lanes of one grid row are
-// contiguous in memory on every pixel row, so each store instruction writes ceil(64/S)+1 contiguous
-// runs; the 4 stores of an iteration complete each other's partial cache lines back to back.
-// Plain stores: nontemporal ones measured 25 % slower in this shape (tools/microbench).
-__device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
-                                             int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
-                                             const uint32_t rgb[8], uint32_t agent_cell, uint32_t hold_rgb,
-                                             int lane, int pace)
-{
-    const uint32_t row_bytes = 12u * S;
-    for (uint32_t cell = lane; cell < (uint32_t)ncell; cell += CW_WAVE) {
-        const uint32_t r = __umulhi(cell, div_magic);
-        const uint32_t c = cell - r * S;
-        uint32_t col = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) col = (cell == sp[k]) ? rgb[k] : col;
-        const u32x3 d = cell_row_dwords(col);
-        const bool ag = (cell == agent_cell);
-        const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
-        const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
-        const size_t off = (size_t)(4u * r) * row_bytes + 12u * c;
-        uint8_t *q = dst0 + off;
-        *(u32x3_a4 *)(q) = d;
-        *(u32x3_a4 *)(q + row_bytes) = d1;
-        if (pace & 0x100) __builtin_amdgcn_s_sleep(1);                        // (PACING, see render_groups)
-        *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
-        *(u32x3_a4 *)(q + 3 * row_bytes) = d;
-        if ((cell >> 6) & 1u) for (int z = 0; z < (pace & 0xFF); z++) __builtin_amdgcn_s_sleep(1);   // per pair of 64-cell groups
-        if (dst1) {
-            uint8_t *q1 = dst1 + off;
-            *(u32x3_a4 *)(q1) = d;
-            *(u32x3_a4 *)(q1 + row_bytes) = d1;
-            *(u32x3_a4 *)(q1 + 2 * row_bytes) = d2;
-            *(u32x3_a4 *)(q1 + 3 * row_bytes) = d;
-        }
-    }
-}
-
-// Per-env records are wave-uniform and must not be loaded inside the frame loop: loads and stores retire through
-// one in-order counter (vmcnt), so waiting for a vector load there drains the wave's 28 outstanding frame stores
-// once per frame (measured 0.320 ms vs 0.274 ms per launch).  First fix: scalar loads (constant cache, lgkmcnt
-// domain) one frame ahead.  Current form (render_jobs): the records of a wave's next 64 frames are fetched one per
-// lane BEFORE the wave has a store in flight and handed out with v_readlane -- 2 % faster again on the same box
-// (the scalar loads missed to HBM under the render's own write storm, where a round trip takes ~25 us).
-typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-
-template <typename T>
-__device__ __forceinline__ T cload(const T *p)
-{
-    return *(const __attribute__((address_space(4))) T *)(p);
-}
-
-struct CwEnvRec {
-    u32x4s h, pp;
-    uint32_t done_word;
-    int env;
-};
-__device__ __forceinline__ void unpack_pos_s(const u32x4s &v, uint32_t sp[8])
-{
-    sp[0] = v.x & 0xFFFFu; sp[1] = v.x >> 16;
-    sp[2] = v.y & 0xFFFFu; sp[3] = v.y >> 16;
-    sp[4] = v.z & 0xFFFFu; sp[5] = v.z >> 16;
-    sp[6] = v.w & 0xFFFFu; sp[7] = v.w >> 16;
-}
-
-template <int MODE>
-__device__ __forceinline__ void render_one(const CwParams &P, const CwEnvRec &cur, bool want_done, uint8_t *ext_out, int lane, int pace)
-{
-    if (cur.env < 0) return;
-    const int cur_env = cur.env;
-    if (want_done && ((cur.done_word >> (8 * (cur_env & 3))) & 0xFFu)) return;
-    uint32_t sp[8], rgb[8];
-    unpack_pos_s(cur.pp, sp);
-#pragma unroll
-    for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((cur.h.w >> (4 * k)) & 15u);   // SALU select chains
-    const uint32_t hx = cur.h.x;
-    const uint32_t agent_cell = (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu);
-    const uint32_t hold = (hx >> 16) & 0xFFu;
-    const uint32_t hold_rgb = hold ? rgb_of_code(hold) : 0x00FFFFFFu;
-    constexpr bool three = (MODE == 0);
-    constexpr bool goal_too = (MODE == 0) || (MODE == 5);
-    const size_t off = (size_t)cur_env * P.frame_bytes;
-    uint8_t *d0 = (MODE == 2) ? ext_out + off : (MODE == 4) ? P.terminal_img + off : P.obs + off;
-    uint8_t *d1 = three ? P.init_img + off : nullptr;
-    if (P.raster == 1) render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, cur.h.w, agent_cell, hold, lane, P.alt_pace);
-    else render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold_rgb, lane, pace);
-    if (MODE == 5) {                                         // restored checkpoint: INIT_OBS from the reset-time state
-        uint32_t ip[8], irgb[8];
-        const u32x4s ipp = cload((const u32x4s *)(P.init_pos + cur_env));
-        unpack_pos_s(ipp, ip);
-        const uint32_t iaw = cload((const uint32_t *)((const uint8_t *)P.init_agent + ((2 * cur_env) & ~3)));
-        const uint32_t ia = (iaw >> (16 * (cur_env & 1))) & 0xFFFFu;
-#pragma unroll
-        for (int k = 0; k < 8; k++) irgb[k] = rgb_of_code((uint32_t)k + 1u);
-        if (P.raster == 1) render_frame_alt(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, CW_CODES_INITIAL, ia, 0u, lane, P.alt_pace);
-        else render_frame(P.init_img + off, nullptr, P.size, P.ncell, P.div_magic, ip, irgb, ia, 0x00FFFFFFu, lane);
-    }
-    if (goal_too) {                                          // desired_goal = render(final_state), ray.py:299
-        uint32_t gp[8], grgb[8];
-        const u32x4s gpp = cload((const u32x4s *)(P.goal_pos + cur_env));
-        unpack_pos_s(gpp, gp);
-        const uint32_t gc = cload(P.goal_codes + cur_env);
-        const uint32_t gaw = cload((const uint32_t *)((const uint8_t *)P.goal_agent + ((2 * cur_env) & ~3)));
-        const uint32_t ga = (gaw >> (16 * (cur_env & 1))) & 0xFFFFu;
-#pragma unroll
-        for (int k = 0; k < 8; k++) grgb[k] = rgb_of_code((gc >> (4 * k)) & 15u);
-        if (P.raster == 1) render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, gc, ga, 0u, lane, P.alt_pace);
-        else render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, ga, 0x00FFFFFFu, lane);
-    }
-}
-
-// mode 0: every env -> obs, init_img (same pixels) and desired_img (goal state)   (cw_reset)
-// mode 2: every env -> ext_out only                                               (cw_render)
-// mode 3: every env -> obs only; with skip_done, envs whose done flag is set are left to the
-//         resetting wave (cw_reset_kernel, paint=1) on the side stream             (FULL pixel step)
-// mode 4: envs in the done list, BEFORE their reset -> terminal_img only            (keep_terminal_obs)
-// Records in lanes: lane l fetches the records of the wave's l-th next frame, so the records of 64 frames are
-// requested at once, BEFORE the wave has a store in flight, and the frame loop itself has no load at all (frame k's
-// wave-uniform record is 9 v_readlane).  With 1024 waves and 65 536 envs that is the whole launch; larger batches
-// reload every 64 frames (the only point where the wave waits for its stores).
-//
-// Which frames a wave paints.  Rounds 0..q_all-1: every wave paints one frame per round (frame i*n_waves + wave), so all
-// waves sweep through memory together.  XCD-aware part: the workgroups of every other XCD write ~15 % slower
-// (tools/microbench/render_waves.py: with equal shares the waves of even-numbered workgroups finish at ~255 us, the
-// odd ones at ~222 us, whatever frames they paint), and a launch lasts as long as its slowest wave.  So the frames
-// past round q_all go to the fast class only, one per fast wave per round; q_all and the fast parity come from a
-// calibration at cw_create (cw_engine.cpp).  fast_parity < 0: no classes, q_all covers everything.  The partition
-// depends on workgroup indices only, never on where a workgroup actually runs: coverage is exact either way.
-template <int MODE>
-__device__ __forceinline__ void render_jobs(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                            int bid, int n_blocks)
+// ------------------------------------------------------------------------------------ whole arrays
+// cw_render into a caller's array of ANY alignment (an array the sweep's 16-byte stores can take is swept): one wave per frame
+__global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, uint8_t *out)
 {
     const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wpb = blockDim.x / CW_WAVE;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = bid * wpb + wave_in_block;
-    const int n_waves = n_blocks * wpb;
-    const int n_jobs = (MODE == 4) ? cload(P.done_count) : P.n_envs;
-    if (wave >= n_jobs) return;   // (wave-uniform)
-    const bool want_done = (MODE == 3) && skip_done;
-    if (want_done && cload(P.done_count) >= CW_BESIDE_MIN) pace += (pace >> 12) & 15;     // envs being reset beside this launch: see render_groups
-    const bool classes = (MODE == 2 || MODE == 3) && fast_parity >= 0;
-    if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
-    const int n_fast = (n_blocks / 2) * wpb;                               // (classes only: the grid is even)
-    const bool fast = classes && (bid & 1) == fast_parity;
-    const int fast_rank = (bid >> 1) * wpb + wave_in_block;
-    const int tail0 = q_all * n_waves;                                     // first frame of the fast class's extra rounds
-    const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
-    CW_WAVE_CLOCK(t_start);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
-    for (int base = 0; base < q_mine; base += CW_WAVE) {
-        const int i = base + lane;                                         // this lane holds the wave's i-th frame
-        const int f = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
-        int v_env = -1;
-        uint4 v_h = make_uint4(0, 0, 0, 0), v_p = make_uint4(0, 0, 0, 0);
-        uint32_t v_done = 0;
-        if (i < q_mine && f < n_jobs) {
-            v_env = (MODE == 4) ? P.done_list[f] : f;
-            v_h = P.hdr[v_env];
-            v_p = P.pos[v_env];
-            if (want_done) v_done = P.done[v_env];
-        }
-        const int in_batch = min(q_mine - base, CW_WAVE);
-        for (int k = 0; k < in_batch; k++) {
-            CwEnvRec cur;
-            cur.env = __builtin_amdgcn_readlane(v_env, k);
-            cur.h.x = __builtin_amdgcn_readlane(v_h.x, k);
-            cur.h.y = 0u;
-            cur.h.z = 0u;
-            cur.h.w = __builtin_amdgcn_readlane(v_h.w, k);
-            cur.pp.x = __builtin_amdgcn_readlane(v_p.x, k);
-            cur.pp.y = __builtin_amdgcn_readlane(v_p.y, k);
-            cur.pp.z = __builtin_amdgcn_readlane(v_p.z, k);
-            cur.pp.w = __builtin_amdgcn_readlane(v_p.w, k);
-            cur.done_word = __builtin_amdgcn_readlane(v_done, k) << (8 * (cur.env & 3));
-            render_one<MODE>(P, cur, want_done, ext_out, lane, pace);      // (env < 0: nothing to paint)
-        }
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CW_WAVE;
+    const int n_waves = gridDim.x * blockDim.x / CW_WAVE;
+    for (int env = wave; env < P.n_envs; env += n_waves) {
+        uint32_t sp[8], codes, agent_cell, hold;
+        load_state_uniform(P, env, CW_SRC_CURRENT, sp, codes, agent_cell, hold);
+        paint_state_frame(P, out + (size_t)env * P.frame_bytes, sp, codes, agent_cell, hold, lane);
     }
-    CW_WAVE_BUSY(P, t_start, bid & 1);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
 }
 
-// ---- the same frames as ONE LINEAR SWEEP of the frame array (the default for the per-step render) ------------------
-// In the [N][4S][4S][3] layout a GRID row is 4 pixel rows = 48*S contiguous bytes, so a run of whole grid rows is a
-// contiguous byte range.  Job = (frame, group): the frame's next grp_rows = floor(64/S) grid rows (<= 64 cells, lane =
-// cell; 21x21: 3 rows = 63 cells = 3024 B, 7 groups per frame).  Job ids are laid out in ADDRESS order and handed out
-// round-robin -- wave w paints jobs w, w + n_waves, ... -- so at any moment the launch's ~1024 waves write ONE
-// contiguous ~3-MB window that slides through the frame array, the shape of a plain fill, instead of 1024 separate
-// 21-KB-stride streams.  A wave needs a new env record per JOB (7x the record fetches of frame-per-wave; still ~1 % of
-// the traffic): the records of a wave's next 64 jobs are fetched one per lane, a BATCH AHEAD (the loads queue behind
-// stores already in flight and have 64 jobs' time to return, so a batch boundary waits for the wave's last few
-// stores, not for a load round trip under the write storm), and handed out with v_readlane.
-//
-// PACING.  The kernel is bound by the memory system's write path, and that path is LESS efficient when saturated than
-// when kept just short of it: with every wave pushing stores as fast as it can the launch takes 0.254 ms, with 128 idle
-// clocks per pair of jobs 0.241 ms, with 256 it is slower again (profiles/history/r02_render_linear.txt; the same holds for every
-// store shape tried, 16-B-per-lane stores staged through LDS included, each with its own optimum).  WHERE the idle clocks
-// sit matters too: 64 clocks between a job's second and third store beat the same clocks between jobs by 2.5 %
-// (0.2407 vs 0.2471 ms) -- the smoother the stream of stores, the better.  So a wave sleeps 64 clocks in the middle of
-// a job's stores (`pace` bit 8) and `pace & 0xFF` x 64 clocks per pair of jobs; cw_create finds both on the box it runs on,
-// as it does the XCD shares.
-template <int MODE, int PLACE = CW_PLACE_DEFAULT>
-__device__ __forceinline__ void render_groups(const CwParams &P, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                              int bid, int n_blocks, int env_lo, int env_n)
-{
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wpb = blockDim.x / CW_WAVE;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = bid * wpb + wave_in_block;
-    const int n_waves = n_blocks * wpb;
-    const int S = P.size, gr = P.grp_rows, G = P.grp_per_frame;
-    const int n_jobs = env_n * G;                                            // this launch sweeps envs [env_lo, env_lo + env_n): a CHUNK of the batch (cw_sweep_chunks)
-    if (wave >= n_jobs) return;
-    const bool want_done = (MODE == 3) && skip_done;
-    const bool classes = fast_parity >= 0;
-    if (!classes) q_all = (n_jobs + n_waves - 1) / n_waves;
-    const int n_fast = (n_blocks / 2) * wpb;
-    const bool fast = classes && (bid & 1) == fast_parity;
-    const int fast_rank = (bid >> 1) * wpb + wave_in_block;
-    const int tail0 = q_all * n_waves;
-    const int q_mine = fast ? q_all + (max(n_jobs - tail0, 0) + n_fast - 1) / n_fast : q_all;
-    // lane -> cell of the group, once
-    const uint32_t row_bytes = 12u * S;
-    const uint32_t r_local = __umulhi((uint32_t)lane, P.div_magic);
-    const uint32_t c_local = (uint32_t)lane - r_local * S;
-    const bool lane_in_group = lane < gr * S;
-    const uint32_t v_off = 4u * r_local * row_bytes + 12u * c_local;
-    const uint32_t v_table = rgb_of_code((uint32_t)lane);                    // lane k <= 8: COLORS_N[k]; others 0
-    uint8_t *const dst_base = (MODE == 2) ? ext_out : P.obs;
-    // a render wave shares its SIMD with at most a few resetting waves (side stream): it wins the issue slot, they have the whole
-    // launch to finish (with the reset waves raised instead, as in round 1, the spread-out-phases step is 3-8 % slower)
-    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    // sleeps of 64 clocks per pair of jobs (pace bits 0-7), and `pace` bits 12-15 more while at least CW_BESIDE_MIN envs are being
-    // reset beside this sweep (the launch's resetting workgroups, or the reset kernel on the side stream): their unpaced bursts push a
-    // write path that sits just short of saturation over the edge -- phases spread out, 0 / 2 / 3 / 4 extra: 0.263 / 0.245 / 0.248 /
-    // 0.252 ms on one box, 3 best and 1 at 0.267 on another (profiles/history/r02_pace.txt, r02_fused_render.txt; cw_step tunes the number
-    // online).  (done_count is zeroed by the last resetting workgroup: a wave that starts after that paces like a launch with nothing
-    // beside it, which is what it then is.)
-    const int pace_base = pace & 0xFF, pace_beside = want_done ? ((pace >> 12) & 15) : 0;
-    const bool pace_mid = (pace & 0x100) != 0;                               // one more in the middle of every job's four stores
-    const int pace_fine = (pace >> 16) & 0xFF;                               // iterations of a one-s_nop loop before every job
-    CW_WAVE_CLOCK(t_start);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 0);
-    struct Rec { int env, g, cnt; uint32_t hx, hw, done; uint4 p; };
-    auto fetch = [&](int base) {
-        Rec r;
-        // the done counter rides with every batch's records (a coherent load: the last resetting workgroup zeroes it when the list is
-        // done): the extra sleeps apply only to batches fetched while envs were still being reset beside the sweep -- the resets are over
-        // after the first 20-40 us of a launch, and slowing the sweep for the rest of it bought nothing
-        r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int i = base + lane;
-        const int id = i < q_all ? i * n_waves + wave : tail0 + (i - q_all) * n_fast + fast_rank;
-        r.env = -1; r.g = 0; r.hx = 0; r.hw = 0; r.done = 0;
-        r.p = make_uint4(0, 0, 0, 0);
-        if (i < q_mine && id < n_jobs) {
-            const int e_local = id / G;
-            r.env = env_lo + e_local;
-            r.g = id - e_local * G;
-            const uint32_t *h = (const uint32_t *)(P.hdr + r.env);
-            r.hx = h[0];
-            r.hw = h[3];
-            r.p = P.pos[r.env];
-            if (want_done) r.done = P.done[r.env];     // (envs that finished are left to the resetting wave on the side stream)
-        }
-        return r;
-    };
-    // PLACEMENT.  This loop's launch time depends on where it lies in the code object, with a period of 32 bytes: the same instructions have
-    // read 0.2325 ms at one placement, 0.2276 four bytes later and 0.27 (or either, from run to run) at five of the eight others -- a few
-    // clocks per job at the loop's branch targets (profiles/history/r02_pace.txt N-P) -- and which placement is the good one moves with every edit
-    // of the loop body, with the box, and would move with the compiler (profiles/r03_placement.txt).  So the placement is a TUNED parameter,
-    // not a pinned one: the one-launch step is built at all eight placements modulo 32 bytes (PLACE x s_nop after a 32-byte boundary,
-    // executed once per wave; cw_render_step_kernel<0..7>) and cw_step measures which one this process should run (cw_engine.cpp: adapt_tick).
-    // (one asm block: nothing can be scheduled between the boundary, the s_nops and the symbol tools/isa_report.py reads the address from)
-    asm volatile(".p2align 5\n\t.rept %0\n\ts_nop 0\n\t.endr\ncw_sweep_head_%=:" ::"i"(PLACE));
-    Rec nxt = fetch(0);
-    for (int base = 0; base < q_mine; base += CW_WAVE) {
-        const Rec cur = nxt;
-        if (base + CW_WAVE < q_mine) nxt = fetch(base + CW_WAVE);
-        const int in_batch = min(q_mine - base, CW_WAVE);
-        const int pace_pair = pace_base + (__builtin_amdgcn_readfirstlane(cur.cnt) >= CW_BESIDE_MIN ? pace_beside : 0);
-        for (int k = 0; k < in_batch; k++) {
-            if (k & 1) for (int z = 0; z < pace_pair; z++) __builtin_amdgcn_s_sleep(1);
-            for (int z = 0; z < pace_fine; z++) asm volatile("s_nop 0");
-            const int env = __builtin_amdgcn_readlane(cur.env, k);
-            if (env < 0) continue;
-            if (want_done && __builtin_amdgcn_readlane(cur.done, k)) continue;
-            const uint32_t g = __builtin_amdgcn_readlane(cur.g, k);
-            const uint32_t hx = __builtin_amdgcn_readlane(cur.hx, k), codes = __builtin_amdgcn_readlane(cur.hw, k);
-            u32x4s pp;
-            pp.x = __builtin_amdgcn_readlane(cur.p.x, k);
-            pp.y = __builtin_amdgcn_readlane(cur.p.y, k);
-            pp.z = __builtin_amdgcn_readlane(cur.p.z, k);
-            pp.w = __builtin_amdgcn_readlane(cur.p.w, k);
-            uint32_t sp[8];
-            unpack_pos_s(pp, sp);
-            const uint32_t row0 = g * gr;
-            const uint32_t cell = row0 * S + (uint32_t)lane;
-            uint32_t code = 0;                                               // the lane's cell: slot code by 8 compares ...
-#pragma unroll
-            for (int q = 0; q < 8; q++) code = (cell == sp[q]) ? ((codes >> (4 * q)) & 15u) : code;
-            const uint32_t col = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_table);   // ... colour from the table register
-            const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
-            const uint32_t hold = (hx >> 16) & 0xFFu;
-            const uint32_t hold_rgb = hold ? (uint32_t)__builtin_amdgcn_readlane(v_table, hold & 15u) : 0x00FFFFFFu;
-            const u32x3 d = cell_row_dwords(col);
-            const bool ag = (cell == agent_cell);
-            const u32x3 d1 = ag ? overlay_dwords(d, 0x00FFFFFFu) : d;     // ray.py:483
-            const u32x3 d2 = ag ? overlay_dwords(d, hold_rgb) : d;        // ray.py:484-486
-            if (lane_in_group && row0 + r_local < (uint32_t)S) {
-                uint8_t *q = dst_base + (size_t)env * P.frame_bytes + (size_t)(4u * row0) * row_bytes + v_off;
-                *(u32x3_a4 *)(q) = d;
-                *(u32x3_a4 *)(q + row_bytes) = d1;
-                if (pace_mid) __builtin_amdgcn_s_sleep(1);                // (see PACING above)
-                *(u32x3_a4 *)(q + 2 * row_bytes) = d2;
-                *(u32x3_a4 *)(q + 3 * row_bytes) = d;
-            }
-        }
-    }
-    CW_WAVE_BUSY(P, t_start, bid & 1);
-    if (MODE == 3) CW_WAVE_STAMP(wave, 1);
-}
-
-// ---- the frame array as a sweep of ALIGNED 4-KiB PIECES ---------------------------------------------------------------
+// ---- a frame array as a sweep of ALIGNED 4-KiB PIECES: the one painter of whole arrays ---------------------------------
 // Both rasters' frames are almost all zeros.  An AltObs frame is a zero fill plus <= 19 lit pixels (render_frame_alt); a Ray frame is
 // black (COLORS_N[0], ray.py:28) except the 4x4-pixel cells of its <= 8 objects and the agent's 2x2 mark (ray.py:476-486).  So the
 // sweep's jobs need not follow the frames, the pixel rows or the cells at all: job j is the j-th aligned 4-KiB piece of the frame array --
 // four 1-KiB stores of zeros, every lane one 16-byte chunk, the shape of a plain fill whatever the frame size -- followed by those bytes
-// of the lit items of the one or two frames the piece overlaps that fall inside it (lanes 0-31 hold the items of the first frame, 32-63
-// of the second; a wave's stores to one address are performed in program order, so the items land on the zeros):
+// of the lit items of the frames the piece overlaps that fall inside it, two frames at a time (lanes 0-31 hold the items of one frame,
+// 32-63 of the next; a wave's stores to one address are performed in program order, so the items land on the zeros):
 //   AltObs: lane = pixel (8 objects, agent, held item, 9 flag pixels of the strip), three byte stores;
 //   Ray   : lane = (object slot, pixel row of its cell): the 12 bytes of that row as three dwords, then (lanes of slot 0, rows 1 and 2)
 //           the agent's mark over whatever is there: bytes 3..8 of its cell's rows 1 and 2 = a byte, a dword, a byte.
-// Jobs go to the waves in address order, four consecutive ones per workgroup, like render_groups' jobs (a CU writes 16 KiB contiguous;
-// profiles/r03_wave_order.txt).  A frame whose env finished is left to its resetting wave: the piece's fill is clipped to the other
-// frame (rare path).  Records (agent, codes, positions, done flag of both frames of a job) are fetched a batch of 32 jobs ahead, one
-// (job, frame) per lane, and handed to the lanes that paint with ds_bpermute -- asked for before the fill's stores, used after them; no other
-// LDS or memory round trip and no branch in a job but the pace loops and the stores' own predicates.
+// A piece overlaps at most floor(4095 / frame_bytes) + 2 frames: two for frames of 4 KiB and more (grids from 10x10 / AltObs 12x12), up to
+// nine for the smallest (4x4 AltObs: 540 bytes).  FPJ = that number rounded up to a power of two is a template parameter: records are
+// fetched for FPJ frames per job, and a job paints FPJ / 2 pairs (the loop ends with the piece's last frame) -- one pair and no loop at all
+// for the frames of the BASELINE configs.
+// Jobs go to the waves in address order, four consecutive ones per workgroup (a CU writes 16 KiB contiguous; profiles/history/r03_wave_order.txt).
+// Records (agent, hold, codes, positions of the frames of a job) are fetched a batch of 64 / FPJ jobs ahead, one (job, frame) per lane, and
+// handed to the lanes that paint with ds_bpermute -- asked for before the fill's stores, used after them; no other LDS or memory round trip
+// and no branch in a job but the pace loops and the stores' own predicates.  `src` says which of an env's three states the array shows.
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
-#define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/r03_pieces.txt G)
+#define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/history/r03_pieces.txt G)
 #define CW_PIECE_STORES 4          // 1-KiB stores per piece
-// the rare piece: one of its two frames belongs to a resetting wave, or it is the array's last, partial one -- zeros for the bytes of [a0, a1)
-// whose frame is not done (frame A before `bnd`, frame B from there on), 16-byte chunks where a whole chunk qualifies, single bytes otherwise
-__device__ __attribute__((noinline)) void piece_fill_clipped(uint8_t *dst_base, uint32_t a0, uint32_t a1, uint32_t bnd, uint32_t done_a, uint32_t done_b, int lane)
+// the array's last, partial piece: zeros for [a0, a1), 16-byte chunks where a whole chunk fits, single bytes after it
+__device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, uint32_t a0, uint32_t a1, int lane)
 {
     for (int s = 0; s < CW_PIECE_STORES; s++) {
         const uint32_t c = a0 + 1024u * s + 16u * lane;
-        const bool in_a = c + 16u <= bnd, in_b = c >= bnd;
-        const bool whole = c + 16u <= a1 && (in_a ? !done_a : in_b ? !done_b : false);
-        if (whole) *(uint4 *)(dst_base + c) = make_uint4(0, 0, 0, 0);
-        else if (c < a1 && !(in_a && done_a) && !(in_b && done_b))               // (the chunk that straddles the frames, or the array's end)
-            for (uint32_t b = c; b < min(c + 16u, a1); b++)
-                if (!(b < bnd ? done_a : done_b)) dst_base[b] = 0;
+        if (c + 16u <= a1) *(uint4 *)(dst_base + c) = make_uint4(0, 0, 0, 0);
+        else for (uint32_t b = c; b < a1; b++) dst_base[b] = 0;
     }
 }
-template <int RASTER>
-__device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, uint8_t *frames, int pace, int bid, int n_blocks, int env_lo, int env_n)
+template <int RASTER, int FPJ>
+__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int list_aware, int pace, int period16, int env_lo, int env_n, int n_blocks)
 {
+    constexpr int JPB = CW_WAVE / FPJ;                                      // jobs per batch of records
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int n_waves = n_blocks * wpb;
-    const int wave = bid * wpb + wave_in_block;                             // (four consecutive pieces per workgroup)
+    const int wave = (int)blockIdx.x * wpb + wave_in_block;                 // (four consecutive pieces per workgroup)
     const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = (RASTER == 1 ? 9u : 12u) * S;
     uint8_t *const dst_base = frames + (size_t)env_lo * FB;
     const uint32_t total = (uint32_t)env_n * FB;                             // (cw_piece_chunks: < 2^32)
@@ -1469,180 +1376,190 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, int skip_done, 
     const uint32_t fj = pl >= 10u ? pl - 10u : 0u, fjr = (fj >= 6u) ? 2u : (fj >= 3u) ? 1u : 0u;
     const uint32_t off_flag = (3u * S + fjr) * row_bytes + 9u + 3u * (fj - 3u * fjr);      // AltObs lanes pl 10..18: the strip's nine flag pixels
     const bool marks = slot == 0u && (dy == 1u || dy == 2u);                 // Ray: the lanes that paint the agent's mark
-    if (P.tune_reset_prio == 2) __builtin_amdgcn_s_setprio(3);
-    // `pace`: EIGHTHS of a sleep per 1-KiB store (bits 0-7: 4 = an s_sleep(1) after every other store), and bits 12-15 QUARTERS more while
-    // envs are being reset beside the sweep (as in render_groups)
-    const int pace_base = pace & 0xFF, pace_beside = skip_done ? 2 * ((pace >> 12) & 15) : 0;
+    __builtin_amdgcn_s_setprio(3);
+    // PACING.  The write path is LESS efficient saturated than kept just short of saturation (profiles/history/r02_render_linear.txt), and where the
+    // edge lies moves with what else the memory system is doing.  `pace`: EIGHTHS of a sleep per 1-KiB store (bits 0-7: 4 = an s_sleep(1) after every
+    // other store), and bits 12-15 QUARTERS more in every launch of a step on which at least CW_BESIDE_MIN envs finished (the list kernel wrote their
+    // frames a moment ago and will again: such a sweep wants a higher pace to its end -- profiles/r04_lookahead.txt; cw_step tunes the number online)
+    const int pace_base = pace & 0xFF, pace_beside = list_aware ? 2 * ((pace >> 12) & 15) : 0;
     int owed = 0;
-    struct Rec { int env, cnt; uint32_t hx, hw, done, o2; uint4 p; };       // (o2, Ray: the colour of row 2 of the agent's mark -- what it holds, else white)
+    struct Rec { int f, cnt; uint32_t hx, hw, o2; uint4 p; };               // (hx: agent row | col << 8 | hold << 16; o2, Ray: the colour of row 2 of the agent's mark)
+    // fetch() only ISSUES the loads of a batch's records (nothing in it depends on a loaded value, so the wave does not wait here, with its
+    // stores in flight: loads and stores retire through one in-order counter); finish() derives what the jobs need a batch later, when the
+    // loads have long returned
     auto fetch = [&](int base) {
         Rec r;
         r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int i = base + (lane >> 1);
+        const int i = base + lane / FPJ;
         const int id = i * n_waves + wave;
-        r.env = -1; r.hx = 0; r.hw = 0; r.done = 0; r.o2 = 0;
+        r.f = -1; r.hx = 0; r.hw = 0; r.o2 = 0;
         r.p = make_uint4(0, 0, 0, 0);
         if (i < q_mine && id < n_jobs) {
-            const int f = (int)(((uint32_t)id * CW_PIECE) / FB) + (lane & 1);       // (frame index inside the chunk)
+            const int f = (int)(((uint32_t)id * CW_PIECE) / FB) + (lane % FPJ);     // (frame index inside the chunk)
             if (f < env_n) {
-                r.env = f;
-                const uint32_t *h = (const uint32_t *)(P.hdr + env_lo + f);
-                r.hx = h[0];
-                r.hw = h[3];
-                r.p = P.pos[env_lo + f];
-                if (skip_done) r.done = P.done[env_lo + f];
-                if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
+                r.f = f;
+                const int e = env_lo + f;
+                if (src == CW_SRC_CURRENT) {
+                    const uint32_t *h = (const uint32_t *)(P.hdr + e);
+                    r.hx = h[0];
+                    r.hw = h[3];
+                    r.p = P.pos[e];
+                } else {                                                      // (INIT_OBS / desired_goal arrays; hx: the agent's CELL for now)
+                    r.hx = src == CW_SRC_INIT ? (uint32_t)P.init_agent[e] : (uint32_t)P.goal_agent[e];
+                    r.hw = src == CW_SRC_INIT ? CW_CODES_INITIAL : P.goal_codes[e];
+                    r.p = src == CW_SRC_INIT ? P.init_pos[e] : P.goal_pos[e];
+                }
             }
         }
+#ifdef CW_EXP_OLD_FETCH
+        if (src == CW_SRC_CURRENT) r.hx &= 0x00FFFFFFu;
+        else { const uint32_t ar = __umulhi(r.hx, P.div_magic); r.hx = ar | ((r.hx - ar * S) << 8); }
+        if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
+#endif
         return r;
     };
+    auto finish = [&](Rec &r) {
+#ifdef CW_EXP_OLD_FETCH
+        return;
+#endif
+        if (src == CW_SRC_CURRENT) r.hx &= 0x00FFFFFFu;                       // (the menu id)
+        else { const uint32_t ar = __umulhi(r.hx, P.div_magic); r.hx = ar | ((r.hx - ar * S) << 8); }      // nothing is held in those states
+        if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
+    };
     Rec nxt = fetch(0);
-    for (int base = 0; base < q_mine; base += CW_WAVE / 2) {
-        const Rec cur = nxt;
-        if (base + CW_WAVE / 2 < q_mine) nxt = fetch(base + CW_WAVE / 2);
-        const int in_batch = min(q_mine - base, CW_WAVE / 2);
+    // THE CLOCK.  period16 != 0: job k of a wave starts no earlier than t0 + k x period (period16 = the period in 1/16 of a 10-ns tick of the
+    // constant 100-MHz clock, s_memrealtime), the waves' t0 spread evenly over one period: the launch's stores leave as ONE smooth stream at a
+    // set rate -- bytes per second = waves x 4 KiB / period -- instead of at whatever rate the waves' instruction streams happen to produce.
+    long long t_next16 = ((long long)__builtin_amdgcn_s_memrealtime() << 4) + ((long long)wave * period16) / n_waves;
+    for (int base = 0; base < q_mine; base += JPB) {
+        Rec cur = nxt;
+        if (base + JPB < q_mine) nxt = fetch(base + JPB);
+        finish(cur);
+        const int in_batch = min(q_mine - base, JPB);
         const int pace_now = pace_base + (__builtin_amdgcn_readfirstlane(cur.cnt) >= CW_BESIDE_MIN ? pace_beside : 0);
         for (int k = 0; k < in_batch; k++) {
-            const int env_a = __builtin_amdgcn_readlane(cur.env, 2 * k);
-            if (env_a < 0) continue;                                         // (past the last job)
-            const int env_b = __builtin_amdgcn_readlane(cur.env, 2 * k + 1);
+            const int f0 = __builtin_amdgcn_readlane(cur.f, FPJ * k);         // the piece's first frame
+            if (f0 < 0) continue;                                             // (past the last job)
             const uint32_t a0 = (uint32_t)((base + k) * n_waves + wave) * CW_PIECE;
             const uint32_t a1 = min(a0 + CW_PIECE, total);
-            const uint32_t bnd = (uint32_t)(env_a + 1) * FB;                 // first byte of the second frame
-            const bool two = bnd < a1 && env_b >= 0;
-            const uint32_t done_a = __builtin_amdgcn_readlane(cur.done, 2 * k);
-            const uint32_t done_b = two ? (uint32_t)__builtin_amdgcn_readlane(cur.done, 2 * k + 1) : done_a;
-            if (done_a && done_b) continue;
-            // ---- the records of the job's two frames, from the lanes that fetched them to the lanes that paint (asked for before the fill's stores
-            //      and sleeps, used after them: the LDS round trip is off the job's critical path)
+            const uint32_t win = a1 - a0;                                    // (x - a0 < win: x inside the piece)
+            // ---- the records of a pair of the job's frames, from the lanes that fetched them to the lanes that paint (the first pair is asked for
+            //      before the fill's stores and sleeps and used after them: the LDS round trip is off the job's critical path)
             //      (Ray raster.  The AltObs sweep keeps them after the fill, where they were when its pace was found: with them hoisted its launches
-            //      turn bimodal, 0.133 or 0.15 ms against a steady 0.131 -- profiles/r03_alt_sweep.txt C; the job's own delays are part of the pace)
-            const int src = (int)((2u * (uint32_t)k + half) << 2);
+            //      turn bimodal, 0.133 or 0.15 ms against a steady 0.131 -- profiles/history/r03_alt_sweep.txt C; the job's own delays are part of the pace)
             uint32_t hx = 0, hw = 0, o2 = 0, pd = 0;
-            auto gather = [&]() {
-                hx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hx);
-                hw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.hw);
-                o2 = RASTER != 1 ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.o2) : 0u;
-                pd = ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.x) & m_p0) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.y) & m_p1) |
-                     ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.p.w) & m_p3);
+            auto gather = [&](int pair) {
+                const int from = (int)(((uint32_t)(FPJ * k + 2 * pair) + half) << 2);
+                hx = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.hx);
+                hw = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.hw);
+                o2 = RASTER != 1 ? (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.o2) : 0u;
+                pd = ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.x) & m_p0) | ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.y) & m_p1) |
+                     ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.w) & m_p3);
             };
-            if (RASTER != 1) gather();
+            if (RASTER != 1) gather(0);
+            if (period16) {                                                   // ---- the job's slot (THE CLOCK above)
+                const long long now16 = (long long)__builtin_amdgcn_s_memrealtime() << 4, wait16 = t_next16 - now16;
+                if (wait16 > 0) {
+                    for (int z = (int)((wait16 * 5) >> 8); z > 0; z--) __builtin_amdgcn_s_sleep(1);       // (64 clocks each: a little short of the slot ...)
+                    while (((long long)__builtin_amdgcn_s_memrealtime() << 4) < t_next16) { }              // (... the rest on the clock)
+                } else if (wait16 < -(long long)period16) t_next16 = now16 - period16;                     // fell behind by more than a job: the debt is forgiven
+                t_next16 += period16;
+            }
             // ---- the fill
             uint8_t *const job = dst_base + a0;
-            if (!(done_a | done_b) && a1 - a0 == CW_PIECE) {
+            if (win == CW_PIECE) {
 #pragma unroll
                 for (int s = 0; s < CW_PIECE_STORES; s++) {
                     *(uint4 *)(job + 1024 * s + 16 * lane) = make_uint4(0, 0, 0, 0);
                     for (owed += pace_now; owed >= 8; owed -= 8) __builtin_amdgcn_s_sleep(1);  // (PACING above)
                 }
-            } else piece_fill_clipped(dst_base, a0, a1, bnd, done_a, done_b, lane);
-            // ---- the lit items of both frames (branch-free: colours from select chains / the table register)
-            if (RASTER == 1) gather();
-            const bool frame_on = half ? (two && !done_b) : !done_a;
-            const uint32_t f_base = half ? bnd : bnd - FB;
-            const uint32_t win = a1 - a0;                                    // (x - a0 < win: x inside the piece)
-            const uint32_t hold = (hx >> 16) & 0xFFu;
-            if (RASTER == 1) {
-                const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
-                // pl 0..7: object slots; 8: the agent, pixel 8 (altobs.py:536); 9: the held item, on its own object pixel at the agent's cell
-                const uint32_t pos = (((pd >> sh_pos) & 0xFFFFu) & m_slot) | (agent_cell & ~m_slot);
-                const uint32_t item = (((hw >> sh_item) & 15u) & m_slot) | (9u & m_agent) | (hold & m_held);
-                const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
-                const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
-                const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
-                const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_cpv);      // (a select chain here compiles to branches)
-                const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
-                const bool is_flag = (m_flag & hold) != 0;                            // the strip's flag (altobs.py:557-559)
-                uint32_t p_off = is_obj ? off_obj : is_flag ? off_flag : 0xFFFFFFFFu;
-                uint32_t p_val = is_obj ? col_obj : 0x00FFFFFFu;
-                // the held item's pixel on top of an object's: one store of the sum, byte-wise modulo 256 (render_frame_alt)
-                const uint32_t held_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & 32u) + 9u) << 2), (int)p_off);
-                const bool twice = pl < 8u && p_off != 0xFFFFFFFFu && p_off == held_off;
-                p_val = twice ? (((2u * (p_val & 0xFFu)) & 0xFFu) | ((2u * (p_val & 0xFF00u)) & 0xFF00u) | ((2u * (p_val & 0xFF0000u)) & 0xFF0000u)) : p_val;
-                const unsigned long long m_twice = CW_BALLOT(twice);
-                p_off = (pl == 9u && ((m_twice >> (32u * half)) & 0xFFFFFFFFull)) ? 0xFFFFFFFFu : p_off;
-                if (frame_on && p_off != 0xFFFFFFFFu) {
-                    const uint32_t at = f_base + p_off;
-                    if (at - a0 < win) dst_base[at] = (uint8_t)p_val;
-                    if (at + 1u - a0 < win) dst_base[at + 1u] = (uint8_t)(p_val >> 8);
-                    if (at + 2u - a0 < win) dst_base[at + 2u] = (uint8_t)(p_val >> 16);
+            } else piece_fill_partial(dst_base, a0, a1, lane);
+            // ---- the lit items of the piece's frames, a pair at a time (branch-free: colours from select chains / the table register)
+#pragma unroll
+            for (int pair = 0; pair < FPJ / 2; pair++) {
+                if (FPJ > 2 && pair > 0 && ((uint32_t)f0 + 2u * pair >= (uint32_t)env_n || ((uint32_t)f0 + 2u * pair) * FB >= a1)) break;   // (wave-uniform)
+                if (RASTER == 1 || pair > 0) gather(pair);
+                const uint32_t fi = (uint32_t)f0 + 2u * (uint32_t)pair + half;      // this half's frame
+                const uint32_t f_base = fi * FB;
+                const bool frame_on = fi < (uint32_t)env_n && f_base < a1;
+                const uint32_t hold = (hx >> 16) & 0xFFu;
+                if (RASTER == 1) {
+                    const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+                    // pl 0..7: object slots; 8: the agent, pixel 8 (altobs.py:536); 9: the held item, on its own object pixel at the agent's cell
+                    const uint32_t pos = (((pd >> sh_pos) & 0xFFFFu) & m_slot) | (agent_cell & ~m_slot);
+                    const uint32_t item = (((hw >> sh_item) & 15u) & m_slot) | (9u & m_agent) | (hold & m_held);
+                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
+                    const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
+                    const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
+                    const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_cpv);      // (a select chain here compiles to branches)
+                    const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
+                    const bool is_flag = (m_flag & hold) != 0;                            // the strip's flag (altobs.py:557-559)
+                    uint32_t p_off = is_obj ? off_obj : is_flag ? off_flag : 0xFFFFFFFFu;
+                    uint32_t p_val = is_obj ? col_obj : 0x00FFFFFFu;
+                    // the held item's pixel on top of an object's: one store of the sum, byte-wise modulo 256 (render_frame_alt)
+                    const uint32_t held_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & 32u) + 9u) << 2), (int)p_off);
+                    const bool twice = pl < 8u && p_off != 0xFFFFFFFFu && p_off == held_off;
+                    p_val = twice ? (((2u * (p_val & 0xFFu)) & 0xFFu) | ((2u * (p_val & 0xFF00u)) & 0xFF00u) | ((2u * (p_val & 0xFF0000u)) & 0xFF0000u)) : p_val;
+                    const unsigned long long m_twice = CW_BALLOT(twice);
+                    p_off = (pl == 9u && ((m_twice >> (32u * half)) & 0xFFFFFFFFull)) ? 0xFFFFFFFFu : p_off;
+                    if (frame_on && p_off != 0xFFFFFFFFu) {
+                        const uint32_t at = f_base + p_off;
+                        if (at - a0 < win) dst_base[at] = (uint8_t)p_val;
+                        if (at + 1u - a0 < win) dst_base[at + 1u] = (uint8_t)(p_val >> 8);
+                        if (at + 2u - a0 < win) dst_base[at + 2u] = (uint8_t)(p_val >> 16);
+                    }
+                } else {
+                    // the object of this lane's slot: pixel row dy of its cell, 12 bytes R G B R | G B R G | B R G B (ray.py:476-481)
+                    const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
+                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
+                    const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
+                    const u32x3 d = cell_row_dwords(rgb_of_code(code));
+                    const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
+                    if (is_obj && seg - a0 < win) *(uint32_t *)(dst_base + seg) = d.x;
+                    if (is_obj && seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
+                    if (is_obj && seg + 8u - a0 < win) *(uint32_t *)(dst_base + seg + 8u) = d.z;
+                    // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
+                    // the colour of what it holds (ray.py:483-486)
+                    const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
+                    const uint32_t o = dy == 2u ? o2 : 0x00FFFFFFu;
+                    const bool is_mark = frame_on && marks;
+                    if (is_mark && aseg - a0 < win) dst_base[aseg + 3u] = (uint8_t)o;
+                    if (is_mark && aseg + 4u - a0 < win) *(uint32_t *)(dst_base + aseg + 4u) = (o >> 8) | (o << 16);
+                    if (is_mark && aseg + 8u - a0 < win) dst_base[aseg + 8u] = (uint8_t)(o >> 16);
                 }
-            } else {
-                // the object of this lane's slot: pixel row dy of its cell, 12 bytes R G B R | G B R G | B R G B (ray.py:476-481)
-                const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
-                const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
-                const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
-                const u32x3 d = cell_row_dwords(rgb_of_code(code));
-                const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
-                if (is_obj && seg - a0 < win) *(uint32_t *)(dst_base + seg) = d.x;
-                if (is_obj && seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
-                if (is_obj && seg + 8u - a0 < win) *(uint32_t *)(dst_base + seg + 8u) = d.z;
-                // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
-                // the colour of what it holds (ray.py:483-486)
-                const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
-                const uint32_t o = dy == 2u ? o2 : 0x00FFFFFFu;
-                const bool is_mark = frame_on && marks;
-                if (is_mark && aseg - a0 < win) dst_base[aseg + 3u] = (uint8_t)o;
-                if (is_mark && aseg + 4u - a0 < win) *(uint32_t *)(dst_base + aseg + 4u) = (o >> 8) | (o << 16);
-                if (is_mark && aseg + 8u - a0 < win) dst_base[aseg + 8u] = (uint8_t)(o >> 16);
             }
         }
     }
 }
-
-// the per-step full-frame render (mode 3) and cw_render (mode 2) -- the roofline kernel: linear sweep
-__global__ __launch_bounds__(256) void cw_render_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace,
-                                                        int env_lo, int env_n)
+template <int RASTER, int FPJ>
+__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int list_aware, int pace, int period16, int env_lo, int env_n)
 {
-    if (mode == 3) render_groups<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
-    else render_groups<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
+    render_pieces<RASTER, FPJ>(P, frames, src, list_aware, pace, period16, env_lo, env_n, (int)gridDim.x);
 }
-
-// The FULL pixel step's render AND its auto-resets in one launch: the first render_blocks workgroups are the linear sweep over
-// the envs that go on (mode 3, skip_done), the rest are resetting workgroups over the done list (one wave per finished env, its
-// three frames painted by that wave) -- the pair that cwk_launch_step otherwise runs as two kernels on two streams with an event
-// fork / join around them.  Same work, same waves side by side on the CUs; what goes away is the second hardware queue and its
-// barrier packets: the render's part runs 3-6 % shorter without them (profiles/history/r02_fused_render.txt).
-template <int PLACE>
-__global__ __launch_bounds__(256) void cw_render_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
+#ifdef CW_EXP_LIST_KERNEL
+__global__ __launch_bounds__(256) void cw_list_kernel(CwParams P)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_groups<3, PLACE>(P, 1, nullptr, 0, -1, pace, (int)blockIdx.x, render_blocks, env_lo, env_n);
-    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
+    list_block(P, s_mt, (int)blockIdx.x, (int)gridDim.x, 0);
 }
-// the same with the frame-per-wave painter (grids wider than 64 cells, large batches, the AltObs raster) and its XCD shares
-__global__ __launch_bounds__(256) void cw_render_frames_step_kernel(CwParams P, int render_blocks, int q_all, int fast_parity, int pace)
+#endif
+// The full-frame step's launch: the sweep of the observation array (its last chunk) in the grid's first render_blocks workgroups, the done
+// list's work in the rest (list_block) -- which leave at once when nothing finished on the step and otherwise WAIT, asleep, until every sweeping
+// workgroup has signalled that it is through (done_count[2]): the list's frames must not be painted beside the sweep (see list_block).
+template <int RASTER, int FPJ>
+__global__ __launch_bounds__(256) void cw_render_pieces_step_kernel(CwParams P, int render_blocks, int pace, int period16, int env_lo, int env_n)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_jobs<3>(P, 1, nullptr, q_all, fast_parity, pace, (int)blockIdx.x, render_blocks);
-    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
-}
-// the sweep of aligned pieces (render_pieces), alone (cw_render / two-stream step / calibration) and with the step's resetting workgroups beside it
-template <int RASTER>
-__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int pace, int env_lo, int env_n)
-{
-    render_pieces<RASTER>(P, skip_done, mode == 2 ? ext_out : P.obs, pace, (int)blockIdx.x, (int)gridDim.x, env_lo, env_n);
-}
-template <int RASTER>
-__global__ __launch_bounds__(256) void cw_render_pieces_step_kernel(CwParams P, int render_blocks, int pace, int env_lo, int env_n)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) render_pieces<RASTER>(P, 1, P.obs, pace, (int)blockIdx.x, render_blocks, env_lo, env_n);
-    else reset_list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, 1, 0, 1);
-}
-// the same two modes frame-per-wave: grids wider than 64 cells, the AltObs raster, CW_TUNE_RENDER_LINEAR=0
-__global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, int mode, int skip_done, uint8_t *ext_out, int q_all, int fast_parity, int pace)
-{
-    if (mode == 3) render_jobs<3>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
-    else render_jobs<2>(P, skip_done, ext_out, q_all, fast_parity, pace, (int)blockIdx.x, (int)gridDim.x);
-}
-// off the per-step path: the three frames of every env after cw_reset (mode 0), or the last frames of the
-// done list's envs before their reset (mode 4, keep_terminal_obs)
-__global__ __launch_bounds__(256) void cw_render_reset_kernel(CwParams P, int mode)
-{
-    if (mode == 0) render_jobs<0>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);
-    else if (mode == 5) render_jobs<5>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);    // cw_set_state: all three frames of every env from its restored state
-    else render_jobs<4>(P, 0, nullptr, 0, -1, 0, (int)blockIdx.x, (int)gridDim.x);
+    if ((int)blockIdx.x < render_blocks) {
+        render_pieces<RASTER, FPJ>(P, P.obs, CW_SRC_CURRENT, 1, pace, period16, env_lo, env_n, render_blocks);
+        if (__hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // somebody is waiting for the sweep
+            __threadfence();                                     // this workgroup's frames first (an env reset the slow way is repainted by the list's wave)
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(P.done_count + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, render_blocks);
+    }
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1814,89 +1731,74 @@ __global__ __launch_bounds__(256) void cw_seed_kernel(CwParams P, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// linear sweep where the geometry allows it: Ray raster, S <= 64.  Its waves are in step only at the start of a launch; over thousands
-// of rounds they drift apart (the write window smears, the slower XCDs' waves trail): 0.76-0.77 of the HBM peak up to ~1 800 rounds per
-// wave (262 144 envs at 21x21), 0.62-0.74 at 2^20 envs in one launch (profiles/history/r02_other_configs.txt, r02_pace.txt R-S, r03_other_configs.txt).  So a large
-// batch is swept in CHUNKS of at most tn.render_chunk_rounds rounds per wave, back-to-back launches over consecutive env ranges on
-// one stream (a launch gap of ~2 us against ~1 ms per chunk; every launch starts with its waves in step again).
-static inline int cw_render_linear(const CwParams &P, const CwTuning &tn)
+// frames of a job of the sweep (render_pieces): the most frames an aligned 4-KiB piece can overlap, as a power of two
+static inline int cw_frames_per_job(uint32_t frame_bytes)
 {
-    if (!tn.render_linear || P.raster != 0 || P.grp_rows <= 0) return 0;
-    return (long long)P.n_envs * P.grp_per_frame < (1ll << 30);
+    const int most = (int)((CW_PIECE - 1u) / frame_bytes) + 2;
+    int fpj = 2;
+    while (fpj < most) fpj <<= 1;
+    return fpj;                                  // <= 16: the smallest frame is 540 bytes (AltObs 4x4)
 }
-// the sweep of aligned pieces (render_pieces): frames of at least one piece, so that a piece overlaps at most two of them.  AltObs frames are
-// not multiples of 16 bytes, so only a sweep from env 0 is aligned: one launch, 32-bit offsets
-static inline int cw_piece_sweep(const CwParams &P, const CwTuning &tn)
-{
-    if (!tn.piece_sweep || P.frame_bytes < CW_PIECE) return 0;
-    return P.raster == 1 ? (long long)P.n_envs * P.frame_bytes < (1ll << 31) : (long long)P.n_envs * P.frame_bytes / CW_PIECE < (1ll << 30);
-}
-// ... in chunks of consecutive envs (Ray frames are multiples of 16 bytes: every chunk starts aligned) of about as many bytes as the linear
-// sweep's chunks, cw_sweep_chunks below: render_chunk_rounds jobs of 3 KB per wave, 2.8 GB -- 32-bit offsets inside a chunk
+// The sweep's waves are in step only at the start of a launch; over thousands of rounds they drift apart (0.62-0.74 of the HBM peak at 2^20
+// envs in one launch against 0.86 in eight, profiles/history/r03_other_configs.txt).  So a large batch is swept in CHUNKS of consecutive envs, back-to-back
+// launches on one stream of at most render_chunk_rounds rounds of 3 KB per wave (~2.8 GB; 32-bit offsets inside a chunk).  Chunks are whole
+// multiples of 4 096 envs: every chunk then starts on a 4-KiB boundary of the array (frames are multiples of 16 bytes for the Ray raster, of
+// 2 for AltObs) and every wave of a chunk paints the same number of pieces.  -> number of chunks; *per = envs per chunk (the last one may be shorter)
 static inline int cw_piece_chunks(const CwParams &P, const CwTuning &tn, int *per)
 {
-    *per = P.n_envs;
-    if (P.raster == 1) return 1;
-    const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
+    const long long waves = (long long)tn.n_cu * (256 / CW_WAVE);
     const long long cap = (long long)(tn.render_chunk_rounds > 0 ? tn.render_chunk_rounds : 1 << 20) * waves * 3072;
     const long long bytes = (long long)P.n_envs * P.frame_bytes;
     int n = (int)((bytes + cap - 1) / cap);
     if (n < 1) n = 1;
     *per = (P.n_envs + n - 1) / n;
-    if (n > 1) *per = (int)(((long long)*per + waves - 1) / waves * waves);
-    while ((long long)*per * P.frame_bytes >= (1ll << 32)) *per = (*per + 1) / 2;      // (tiny chunk_rounds settings aside, never taken)
+    if (n > 1 || bytes >= (1ll << 32)) {
+        *per = (int)(((long long)*per + 4095) / 4096 * 4096);
+        while ((long long)*per * P.frame_bytes >= (1ll << 32) && *per > 4096) *per = (*per / 2 + 4095) / 4096 * 4096;
+    }
     return (P.n_envs + *per - 1) / *per;
 }
-// -> number of chunks; *per = envs per chunk (the last one may be shorter)
-static inline int cw_sweep_chunks(const CwParams &P, const CwTuning &tn, int *per)
-{
-    const long long jobs = (long long)P.n_envs * P.grp_per_frame;
-    const long long waves = (long long)tn.n_cu * tn.render_blocks_per_cu * (tn.render_threads / CW_WAVE);
-    const long long cap = (long long)(tn.render_chunk_rounds > 0 ? tn.render_chunk_rounds : 1 << 30) * waves;
-    int n = (int)((jobs + cap - 1) / cap);
-    if (n < 1) n = 1;
-    *per = (P.n_envs + n - 1) / n;
-    // whole multiples of the wave count: every wave of a chunk then paints the same number of jobs, and chunks start at multiples of
-    // 1024 frames (2^20 envs in 7 chunks of 149 797: 0.60 of the HBM peak at EVERY placement; in 8 of 131 072: 0.775, r03_other_configs.txt)
-    if (n > 1) *per = (int)(((long long)*per + waves - 1) / waves * waves);
-    return (P.n_envs + *per - 1) / *per;
-}
-static inline int cw_render_grid(const CwTuning &tn, int jobs);
-static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
-                                    int fast_parity, hipStream_t st);
-static inline int cw_render_grid(const CwTuning &tn, int jobs)
+static inline int cw_render_grid(const CwTuning &tn, long long jobs)
 {
     // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
     // write path saturates with few store streams and gets slower with more of them in flight
-    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt); it also
-    // leaves the wave slots for the reset kernel running beside it
-    const int wpb = tn.render_threads / CW_WAVE;
-    int blocks = (jobs + wpb - 1) / wpb;
-    if (blocks > tn.n_cu * tn.render_blocks_per_cu) blocks = tn.n_cu * tn.render_blocks_per_cu;
-    if (tn.render_blocks_abs > 0 && blocks > tn.render_blocks_abs) blocks = tn.render_blocks_abs;
+    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt)
+    long long blocks = (jobs + 3) / 4;
+    if (blocks > tn.n_cu) blocks = tn.n_cu;
     if (blocks < 1) blocks = 1;
-    return blocks;
+    return (int)blocks;
 }
-
-static inline void cw_launch_render(const CwParams &P, const CwTuning &tn, int mode, int skip_done, uint8_t *ext_out, int q_all,
-                                    int fast_parity, hipStream_t st)
+typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int);
+typedef void (*CwStepSweepKernel)(CwParams, int, int, int, int, int);
+static CwStepSweepKernel cw_step_sweep_kernel(int raster, int fpj)
 {
-    const dim3 grid(cw_render_grid(tn, P.n_envs)), block(tn.render_threads);
-    if (cw_piece_sweep(P, tn) && (mode == 2 || mode == 3)) {
-        int per = 0;
-        const int n_chunks = cw_piece_chunks(P, tn, &per);
-        const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
-        for (int c = 0; c < n_chunks; c++)
-            if (P.raster == 1) hipLaunchKernelGGL(cw_render_pieces_kernel<1>, grid, block, 0, st, P, mode, skip_done, ext_out, pace, c * per, min(per, P.n_envs - c * per));
-            else hipLaunchKernelGGL(cw_render_pieces_kernel<0>, grid, block, 0, st, P, mode, skip_done, ext_out, pace, c * per, min(per, P.n_envs - c * per));
-    } else if (cw_render_linear(P, tn)) {
-        int per = 0;
-        const int n_chunks = cw_sweep_chunks(P, tn, &per);
-        for (int c = 0; c < n_chunks; c++)
-            hipLaunchKernelGGL(cw_render_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, tn.render_pace, c * per,
-                               min(per, P.n_envs - c * per));
+    if (raster == 1) return fpj <= 2 ? cw_render_pieces_step_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_step_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_step_kernel<1, 8> : cw_render_pieces_step_kernel<1, 16>;
+    return fpj <= 2 ? cw_render_pieces_step_kernel<0, 2> : fpj <= 4 ? cw_render_pieces_step_kernel<0, 4> : fpj <= 8 ? cw_render_pieces_step_kernel<0, 8> : cw_render_pieces_step_kernel<0, 16>;
+}
+static CwSweepKernel cw_sweep_kernel(int raster, int fpj)
+{
+    if (raster == 1) return fpj <= 2 ? cw_render_pieces_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_kernel<1, 8> : cw_render_pieces_kernel<1, 16>;
+    return fpj <= 2 ? cw_render_pieces_kernel<0, 2> : fpj <= 4 ? cw_render_pieces_kernel<0, 4> : fpj <= 8 ? cw_render_pieces_kernel<0, 8> : cw_render_pieces_kernel<0, 16>;
+}
+// one frame array [N][frame_bytes] (16-byte aligned) painted from the envs' current / reset-time / goal states.  list_aware 1: the sweep of a
+// step (its pace follows the done list's length); 2: ... and the done list's work rides on the last chunk's launch (cw_render_pieces_step_kernel)
+static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *frames, int src, int list_aware, hipStream_t st)
+{
+    int per = 0;
+    const int n_chunks = cw_piece_chunks(P, tn, &per);
+    const int pace = tn.piece_pace | (list_aware ? (tn.pace_beside & 15) << 12 : 0);
+    const int fpj = cw_frames_per_job(P.frame_bytes);
+    for (int c = 0; c < n_chunks; c++) {
+        const int env_n = min(per, P.n_envs - c * per);
+        const long long pieces = ((long long)env_n * P.frame_bytes + CW_PIECE - 1) / CW_PIECE;
+        const int blocks = cw_render_grid(tn, pieces);
+#ifndef CW_EXP_LIST_KERNEL
+        if (list_aware == 2 && c == n_chunks - 1)
+            hipLaunchKernelGGL(cw_step_sweep_kernel(P.raster, fpj), dim3(blocks + tn.n_cu), dim3(256), 0, st, P, blocks, pace, tn.period16, c * per, env_n);
+        else
+#endif
+            hipLaunchKernelGGL(cw_sweep_kernel(P.raster, fpj), dim3(blocks), dim3(256), 0, st, P, frames, src, list_aware ? 1 : 0, pace, tn.period16, c * per, env_n);
     }
-    else hipLaunchKernelGGL(cw_render_frames_kernel, grid, block, 0, st, P, mode, skip_done, ext_out, q_all, fast_parity, P.raster == 0 ? tn.render_pace : 0);
 }
 
 static inline int cw_reset_grid(const CwTuning &tn, int jobs)
@@ -1917,106 +1819,42 @@ static int cw_envs_per_wave(int n)
     return epw;
 }
 
-// the one-launch render + resets of the full-frame step (cwk_launch_step; cw_create's calibrations time exactly this launch)
-static void cw_launch_fused_render(const CwParams &Pr, const CwTuning &tn, hipStream_t st)
-{
-    const CwParams *P = &Pr;
-    const int n = P->n_envs;
-    const dim3 reset_grid(cw_reset_grid(tn, n));
-    const int render_blocks = cw_render_grid(tn, n);
-    // resetting workgroups: one per CU.  Each costs the launch ~12 ns whether or not anything finished (+1.2 % per 256 of them on
-    // every step), and a step on which every env finishes at once is rare: 1 / 2 / 4 per CU = 2.62 / 2.60 / 2.55 x 10^8 env-steps/s
-    // with the phases in step (the two all-env steps of 600 included), 2.56 / 2.52 / 2.46 spread out (profiles/history/r02_fused_render.txt H)
-    int reset_blocks = (int)reset_grid.x;
-    if (reset_blocks > tn.n_cu * tn.fused_reset_blocks_per_cu) reset_blocks = tn.n_cu * tn.fused_reset_blocks_per_cu;
-    if (cw_piece_sweep(*P, tn)) {
-        int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
-        const int n_chunks = cw_piece_chunks(*P, tn, &per);
-        const int pace = tn.piece_pace | (tn.render_pace & 0xF000);
-        for (int c = 0; c < n_chunks; c++)
-            if (P->raster == 1)
-                hipLaunchKernelGGL(cw_render_pieces_step_kernel<1>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
-                                   c * per, min(per, n - c * per));
-            else
-                hipLaunchKernelGGL(cw_render_pieces_step_kernel<0>, dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P, render_blocks, pace,
-                                   c * per, min(per, n - c * per));
-    } else if (cw_render_linear(*P, tn)) {
-        typedef void (*StepRenderFn)(CwParams, int, int, int, int);
-        static const StepRenderFn at_place[CW_N_PLACES] = {cw_render_step_kernel<0>, cw_render_step_kernel<1>, cw_render_step_kernel<2>,
-                                                           cw_render_step_kernel<3>, cw_render_step_kernel<4>, cw_render_step_kernel<5>,
-                                                           cw_render_step_kernel<6>, cw_render_step_kernel<7>};
-        int per = 0;                             // (the resetting workgroups ride on the first chunk's launch: they have the whole step to finish)
-        const int n_chunks = cw_sweep_chunks(*P, tn, &per);
-        for (int c = 0; c < n_chunks; c++)
-            hipLaunchKernelGGL(at_place[tn.render_place & (CW_N_PLACES - 1)], dim3(render_blocks + (c == 0 ? reset_blocks : 0)), dim3(256), 0, st, *P,
-                               render_blocks, tn.render_pace, c * per, min(per, n - c * per));
-    }
-    else
-        hipLaunchKernelGGL(cw_render_frames_step_kernel, dim3(render_blocks + reset_blocks), dim3(256), 0, st, *P, render_blocks,
-                           tn.render_q_all, tn.render_fast_parity, P->raster == 0 ? tn.render_pace : 0);
-}
-
 extern "C" {
 
-// FULL pixel step: render + auto-resets as one launch (cw_render_step_kernel)?
-int cwk_step_renders_fused(const CwParams *P, const CwTuning *T, int auto_reset)
-{
-    return auto_reset && T->overlap && T->fused_render && !P->terminal_img && T->render_threads == 256;
-}
-
-// One engine step.  FULL pixel mode forks: the caller's stream renders every env that is not done
-// while the side stream resets the done envs, the resetting waves painting their three frames; both join back into
-// the caller's stream, so the caller sees ordinary stream order.
+// One engine step, everything in stream order on `st`.  FULL pixel mode: the step kernel (finished envs take their look-ahead records), the
+// sweep of the observation array, and -- engines that reset by themselves -- the done list's kernel (cw_list_kernel; most steps it finds
+// nothing).  State-only / dirty-cell modes with auto-reset: ONE kernel that steps, takes the records and resets whatever is left inline.
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode,
-                           int auto_reset, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
-                           hipEvent_t *ev /* 6 or null */)
+                           int auto_reset, hipStream_t st, hipEvent_t *ev /* 6 or null */)
 {
     const CwTuning &tn = *T;
     const int n = P->n_envs;
-    const dim3 reset_grid(cw_reset_grid(tn, n)), reset_block(CW_RESET_WAVES * CW_WAVE);
-    const bool pixels = obs_mode != 0;
-    const bool overlapped = (obs_mode == 1 && auto_reset && tn.overlap);
-    const bool ev_all = ev && (tn.profile_side || !overlapped);
+    const bool ev_all = ev && obs_mode != 1;                   // (full-frame mode: only the dominant kernel is bracketed -- every event record costs a pipeline bubble)
     if (ev_all) (void)hipEventRecord(ev[0], st);
-    if (auto_reset && obs_mode != 1 && tn.fused_step) {        // state-only / dirty-cell: the whole step is one launch
+    if (auto_reset && obs_mode != 1) {
         const int epw = cw_envs_per_wave(n);
         const int waves = (n + epw - 1) / epw;
         hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
-                           *P, actions, act_dtype, pixels ? 1 : 0, epw);
+                           *P, actions, act_dtype, obs_mode == 2 ? 1 : 0, epw);
         if (ev) for (int k = 1; k < 6; k++) (void)hipEventRecord(ev[k], st);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
                        auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev_all) (void)hipEventRecord(ev[1], st);
-    if (obs_mode == 1 && cwk_step_renders_fused(P, T, auto_reset)) {
-        if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
-        cw_launch_fused_render(*P, tn, st);
-        if (ev) (void)hipEventRecord(ev[5], st);
-        return hipGetLastError();
-    }
-    if (obs_mode == 1 && auto_reset && tn.overlap) {
-        (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
-        if (ev && tn.profile_side) (void)hipEventRecord(ev[2], side);
-        if (P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, side, *P, 4);
-        hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, side, *P, 1, 0, 1);   // reset + its three frames
-        if (ev && tn.profile_side) (void)hipEventRecord(ev[3], side);
-        (void)hipEventRecord(ev_join, side);
-        if (ev) (void)hipEventRecord(ev[4], st);
-        cw_launch_render(*P, tn, 3, 1, nullptr, tn.render_q_all, tn.render_fast_parity, st);
-        if (ev) (void)hipEventRecord(ev[5], st);
-        (void)hipStreamWaitEvent(st, ev_join, 0);
-        return hipGetLastError();
-    }
-    if (ev) (void)hipEventRecord(ev[2], st);
-    if (auto_reset && P->terminal_img) hipLaunchKernelGGL(cw_render_reset_kernel, dim3(tn.list_blocks), dim3(256), 0, st, *P, 4);
-    // pixel modes: the resetting wave paints the env's three frames itself and is the done list's last reader
-    if (auto_reset) hipLaunchKernelGGL(cw_reset_kernel, reset_grid, reset_block, 0, st, *P, 1, 0, pixels ? 1 : 0);
-    if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
-    if (obs_mode == 1)   // no overlap: the reset is complete; finished envs are painted twice (rare path, tuning only)
-        cw_launch_render(*P, tn, 3, 0, nullptr, tn.render_q_all, tn.render_fast_parity, st);
+    if (ev) for (int k = 2; k < 5; k++) (void)hipEventRecord(ev[k], st);
+    if (obs_mode == 1) cw_launch_sweep(*P, tn, P->obs, CW_SRC_CURRENT, auto_reset ? 2 : 0, st);
     if (ev) (void)hipEventRecord(ev[5], st);
+#ifdef CW_EXP_LIST_KERNEL
+    if (obs_mode == 1 && auto_reset) hipLaunchKernelGGL(cw_list_kernel, dim3(tn.n_cu), dim3(256), 0, st, *P);
+#endif
+    return hipGetLastError();
+}
+
+// look-ahead refill (cw_refill_kernel): the refill list, or every env without a record
+hipError_t cwk_launch_refill(const CwParams *P, const CwTuning *T, int all_envs, hipStream_t st)
+{
+    hipLaunchKernelGGL(cw_refill_kernel, dim3(cw_reset_grid(*T, P->n_envs)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, all_envs);
     return hipGetLastError();
 }
 
@@ -2029,20 +1867,20 @@ hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, 
     return hipGetLastError();
 }
 
-hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st)
+// every env's observation, INIT_OBS and desired_goal arrays from its current, reset-time and goal states: three sweeps
+// (after cw_reset the first two show the same pixels; a restored checkpoint's do not)
+hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st)
 {
-    const CwTuning &tn = *T;
-    const int n = P->n_envs;
-    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(tn, n)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, 0, 1, 0);
-    if (obs_mode != 0)
-        hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(tn, n)), dim3(256), 0, st, *P, 0);
+    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, 0, st);
+    cw_launch_sweep(*P, *T, P->init_img, CW_SRC_INIT, 0, st);
+    cw_launch_sweep(*P, *T, P->desired_img, CW_SRC_GOAL, 0, st);
     return hipGetLastError();
 }
 
-// every env's observation, desired_goal and init_observation frames from its (restored) current, goal and reset-time states
-hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st)
+hipError_t cwk_launch_reset_all(const CwParams *P, const CwTuning *T, int obs_mode, hipStream_t st)
 {
-    hipLaunchKernelGGL(cw_render_reset_kernel, dim3(cw_render_grid(*T, P->n_envs)), dim3(256), 0, st, *P, 5);
+    hipLaunchKernelGGL(cw_reset_kernel, dim3(cw_reset_grid(*T, P->n_envs)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P);
+    if (obs_mode != 0) return cwk_launch_render_restore(P, T, st);
     return hipGetLastError();
 }
 
@@ -2076,27 +1914,14 @@ hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st)
     return hipGetLastError();
 }
 
-// one launch of the step's render kernel (all frames -> obs) with the given shares and P->render_stats set: cw_create's calibration
-hipError_t cwk_launch_render_calib(const CwParams *P, const CwTuning *T, hipStream_t st, int q_all, int fast_parity, int *blocks,
-                                   int *waves_per_block)
+// the sweep of the observation array exactly as cw_step issues it (cw_create's choice of the pace times this launch)
+hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, int list_aware, hipStream_t st)
 {
-    const CwTuning &tn = *T;
-    *blocks = cw_render_grid(tn, P->n_envs);
-    *waves_per_block = tn.render_threads / CW_WAVE;
-    cw_launch_render(*P, tn, 3, 0, nullptr, q_all, fast_parity, st);
-    return hipGetLastError();
-}
-// the render launch of cw_step itself, as cw_step would issue it (the one-launch kernel with its resetting workgroups, which find nothing to do):
-// where the unpaced sweep sits relative to the write path's slower regime depends on the very kernel (profiles/r03_pieces.txt N-P), so the
-// painter and the pace are chosen on this launch, not on the sweep alone
-hipError_t cwk_launch_step_render_calib(const CwParams *P, const CwTuning *T, int auto_reset, hipStream_t st)
-{
-    if (cwk_step_renders_fused(P, T, auto_reset)) cw_launch_fused_render(*P, *T, st);
-    else cw_launch_render(*P, *T, 3, auto_reset ? 1 : 0, nullptr, T->render_q_all, T->render_fast_parity, st);
+    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, list_aware ? 2 : 0, st);
     return hipGetLastError();
 }
 
-// ~10 us of one idle wave: stands in for the step kernel between two render launches in cw_create's calibration
+// ~10 us of one idle wave: stands in for the step kernel between two sweeps in cw_create's calibration
 __global__ void cw_idle_kernel(int n)
 {
     for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
@@ -2107,19 +1932,11 @@ hipError_t cwk_launch_idle(hipStream_t st)
     return hipGetLastError();
 }
 
-int cwk_render_is_linear(const CwParams *P, const CwTuning *T) { return cw_render_linear(*P, *T); }
-int cwk_render_is_piece_sweep(const CwParams *P, const CwTuning *T) { return cw_piece_sweep(*P, *T); }
-int cwk_render_jobs(const CwParams *P, const CwTuning *T)
-{
-    if (cw_piece_sweep(*P, *T)) return (int)(((long long)P->n_envs * P->frame_bytes + CW_PIECE - 1) / CW_PIECE);
-    return cw_render_linear(*P, *T) ? P->n_envs * P->grp_per_frame : P->n_envs;
-}
-
+// cw_render / cw_set_state: the envs' current frames into any array
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
-    CwTuning tn = *T;
-    if ((uintptr_t)out & 15u) tn.piece_sweep = 0;      // (the pieces' 16-byte stores want an aligned array: any other pointer takes the older painters)
-    cw_launch_render(*P, tn, 2, 0, out, tn.render_q_all, tn.render_fast_parity, st);
+    if (((uintptr_t)out & 15u) == 0) cw_launch_sweep(*P, *T, out, CW_SRC_CURRENT, 0, st);
+    else hipLaunchKernelGGL(cw_render_frames_kernel, dim3(cw_render_grid(*T, P->n_envs)), dim3(256), 0, st, *P, out);   // (the sweep's 16-byte stores want an aligned array)
     return hipGetLastError();
 }
 

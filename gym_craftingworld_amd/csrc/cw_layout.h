@@ -8,7 +8,7 @@
 // 64 x 16 B = 1 KiB contiguous per load (env i handled by lane i): fully coalesced, and the
 // step kernel never makes a data-dependent (gather) access to HBM.  "What is in cell p" is 8
 // register compares.  Dense views (grid codes, one-hot, pixels) are materialised by the
-// render/export kernels through an LDS-free compare chain against the slots.
+// render/export kernels from the slots.
 #pragma once
 #include <stdint.h>
 
@@ -38,31 +38,16 @@ struct CwMenuDev {
     int32_t reward_subset;
 };
 
-// Host-side launch tuning of one engine (defaults = the measured best; the CW_TUNE_* /
-// CW_PROFILE_* environment variables read in cw_create override them for experiments).
+// Host-side launch tuning of one engine (defaults = the measured best; the CW_TUNE_* environment variables read in
+// cw_create override them for experiments).
 struct CwTuning {
     int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
-    int render_blocks_per_cu = 1;   // render workgroups per CU (persistent, grid-stride over frames)
-    int render_blocks_abs = 0;      // >0: absolute cap on render workgroups
-    int render_threads = 256;       // threads per render workgroup (64, 128, 256)
-    int list_blocks = 0;            // workgroups of the done-list (terminal-frame) render (0: one per CU)
-    int overlap = 1;                // full-pixel step: reset (+ its frames) on the side stream beside the main render
-    int render_q_all = 0;           // XCD-aware frame shares (cw_create calibrates): rounds painted by every wave ...
-    int render_fast_parity = -1;    //   ... the rest by workgroups of this index parity only (-1: equal shares)
-    int fused_step = 1;             // state / dirty-cell modes with auto-reset: step + reset (+ paint) in one launch
-    int profile_side = 0;           // profiling brackets every kernel, not just the dominant render kernel
-    int piece_sweep = 1;            // the per-step render as a sweep of aligned 4-KiB pieces (render_pieces); cw_create keeps it if it measures faster than the other painter
-    int piece_pace = 0;             // ... eighths of an s_sleep(1) per 1-KiB store (Ray raster: unpaced, AltObs: 4, unless cw_create measures another pace 3 % faster)
-    int render_linear = 1;          // full-frame render as a linear sweep (job = a run of whole grid rows); 0: frame per wave
-    int render_chunk_rounds = 896;  // ... in launches of at most this many rounds per wave over consecutive env ranges: 131 072 envs at 21x21 (0: one launch whatever the batch)
-    int render_place = 3;           // one-launch full-frame step: which of the eight placements of the sweep's batch loop to launch (cw_render_step_kernel<k>;
-                                    // tuned online by cw_step, CW_TUNE_RENDER_PLACE=k forces one)
-    int render_pace_fine = 0;       // ... bits 16-23 of render_pace: iterations of a one-s_nop loop before every job (a pace finer than s_sleep's 64 clocks)
-    int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset kernels
-    int fused_reset_blocks_per_cu = 1;   // ... and the resetting tail of the one-launch full-frame step (cwk_launch_step)
-    int fused_render = 1;           // FULL pixel step: render + auto-resets in ONE launch (cw_render_step_kernel) instead of two kernels on two streams
-    int render_pace = 0;            // linear sweep: bits 0-7 idle s_sleep(1) (64 clocks) per pair of jobs, bit 8 one more inside every job,
-                                    // bits 12-15 more per pair while envs are being reset beside the sweep (cw_create sets 0x2100; cw_step tunes bits 12-15)
+    int piece_pace = 2;             // the sweep's pace: eighths of an s_sleep(1) per 1-KiB store (cw_create checks the neighbours on the engine's batch)
+    int period16 = 0;               // the sweep's CLOCK: a wave's jobs start one period apart; in 1/16 of a 10-ns tick (0: unclocked)
+    int pace_beside = 1;            // ... and QUARTERS more on steps on which >= 32 envs finished (cw_step tunes the number online)
+    int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
+                                    // 131 072 envs at 21x21 (0: one launch whatever the batch)
+    int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
 };
 
 // Control block of the RESIDENT stepper (cw_step_resident: the single-env loop, a step without a kernel launch): pinned, coherent host memory
@@ -102,10 +87,22 @@ struct CwParams {
     uint8_t *desired_img;
     uint8_t *init_img;
     uint8_t *terminal_img;   // or null
+    uint4 *term_pos;         // [N] keep_terminal_obs only (else null): slot positions / (hdr.x, hdr.w) of the episode's LAST state, saved by the
+    uint2 *term_hx;          //     step kernel before the env is reset in place; the terminal frame is painted from them
+    // LOOK-AHEAD: the outcome of every env's NEXT reset(), computed ahead of time.  Only reset() draws from an env's RNG stream, so the next
+    // episode's placement, goal state and task set are known as soon as the previous reset has been taken: the refill kernel runs them ahead in
+    // bulk, off the per-step path, and a finished env just takes the record over inside the step kernel (a POP: three 16-byte loads).  An env
+    // that finishes again before the next refill finds no record and is reset the slow way, on the spot, from the same stream position.
+    uint4 *nx_init_pos;      // [N] sample_state placement of the next episode
+    uint4 *nx_goal_pos;      // [N] its imagine_obs final state
+    uint4 *nx_misc;          // [N] x = init_agent | goal_agent << 16, y = goal_codes, z = desired | subset << 16 | VALID << 31,
+                             //     w = raw 32-bit draws the record consumed (cw_get_mt rewinds the exported stream by them)
+    int32_t *refill_list;    // [N] envs whose record was taken since the last refill (each at most once)
+    int32_t *refill_count;   // [2] entries, release ticket
+    int32_t lookahead;       // 0: no records are kept (engines without auto-reset, host-mapped engines, CW_TUNE_LOOKAHEAD=0)
     // done-list compaction: done_count[0] = entries, [1] = release ticket (cw_kernels.hip)
     int32_t *done_list;      // [N]
-    int32_t *done_count;     // [2]
-    unsigned long long *render_stats;   // [2] calibration only (else null): busy time of even / odd render workgroups' waves
+    int32_t *done_count;     // [4]: + [2] = sweeping workgroups of the step's launch that are through (the list's workgroups wait for them)
     unsigned long long *counters; // [4]
     const CwMenuDev *menus;
     // constants
@@ -118,9 +115,5 @@ struct CwParams {
     uint32_t div_magic;      // floor(2^32 / S) + 1 : x / S == mulhi(x, magic) for x < 2^18
     uint32_t frame_bytes;    // 48 * S * S, or 27 * S * (S+1) for the AltObs rasteriser
     int32_t raster;          // CW_RASTER_*
-    int32_t tune_reset_prio; // s_setprio 3 for: 2 the render waves and the resets inlined in the fused / rollout kernels (default), 1 every resetting wave, 0 nobody
     uint8_t *res_onehot;     // resident stepper only (else null): host-mapped [S][S][12] one-hot state, rewritten after every resident step
-    int32_t alt_pace;        // AltObs frame painter: s_sleep(1) (64 clocks) after each 1-KiB store of the zero fill (cw_create calibrates)
-    int32_t grp_rows;        // linear render: grid rows per 64-lane group = floor(64 / S) (0: S > 64, frame-per-wave render only)
-    int32_t grp_per_frame;   // linear render: groups per frame = ceil(S / grp_rows)
 };

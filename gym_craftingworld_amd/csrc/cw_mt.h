@@ -27,6 +27,7 @@ struct CwMtWave {
     uint32_t *s;        // LDS copy of this env's 624 words (owned by this wave)
     int idx;            // wave-uniform: index of the first word not yet turned into a chunk
     int used;           // wave-uniform: outputs consumed from the current chunk (64 = none left)
+    int gens;           // wave-uniform: chunks generated since load (raw draws consumed so far = 64 * gens - (64 - used))
     int lane;
     uint32_t v_out;     // lane l: tempered output of word (chunk_start + l)
     uint32_t v_old;     // lane l: that word's value before replacement
@@ -58,6 +59,7 @@ struct CwMtWave {
         }
         idx = __builtin_amdgcn_readfirstlane(q.gidx);
         used = 64;
+        gens = 0;
         v_out = 0;
         v_old = 0;
     }
@@ -80,7 +82,10 @@ struct CwMtWave {
         s[p] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         idx = wrap(idx + 64);
         used = 0;
+        gens++;
     }
+    // raw 32-bit draws consumed since load (what cw_get_mt rewinds a look-ahead record by)
+    __device__ __forceinline__ uint32_t draws() const { return (uint32_t)(64 * gens - (64 - used)); }
     // genrand_uint32 (wave-uniform result)
     __device__ __forceinline__ uint32_t next()
     {

@@ -487,10 +487,10 @@ class CraftingWorldVecEnv:
         return {k: getattr(p, k) for k, _ in p._fields_}
 
     def tuner_state(self):
-        """What the engine's online tuner holds right now (full-frame mode; performance only): dict with `place` (the placement k of the
-        sweep loop it launches -- a kernel trace lists it as cw_render_step_kernel<k>), `surveys`, `struck_mask`, `sleeps_beside`,
-        `place_tuned`, `sleeps_tuned`, `painter` (0 frame per wave, 1 sweep of cell rows, 2 sweep of aligned pieces: what cw_create kept),
-        `piece_pace`, `guard_state` (-1 off, 0 watching, 1 trial, 2 the paced sweep was kept), `guard_trials`."""
+        """What the engine's tuning holds right now (full-frame mode; performance only): dict with `piece_pace` (the sweep's pace in eighths of
+        a sleep per 1-KiB store), `pace_beside` (quarter-sleeps more on steps on which >= 32 envs finished) and `pace_beside_tuned` (1: cw_step
+        tunes it online), `guard_state` (-1 off, 0 watching, 1 trial, 2 the paced sweep was kept, 3 opening survey), `guard_trials`, `lookahead`
+        (1: the outcome of every env's next reset() is computed ahead of time)."""
         t = L.cw_tuner_state()
         L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner')
         return {k: int(getattr(t, k)) for k, _ in t._fields_}

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 3   /* 2: cw_profile grew ms_render_kernel_median; cw_lookahead_join removed with the look-ahead prototype.  3: cw_tuner_state grew painter .. guard_trials */
+#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {piece_pace, pace_beside, pace_beside_tuned, guard_state, guard_trials, lookahead}; one painter, look-ahead records */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -251,16 +251,13 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
  * (the render alone), the step kernel's name in CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
-/* What cw_step's online tuner currently holds (full-frame mode, one-launch step): the placement k of the sweep's batch loop
- * it launches (the kernel a trace lists as cw_render_step_kernel<k>), how many placement surveys it has run, the placements it struck
- * off (bit k), the extra sleeps per pair of jobs beside resets, and whether each of the two is tuned (1) or forced / off (0).
- * Only performance depends on any of it. */
+/* What the engine's tuning holds right now (full-frame mode): the sweep's pace in eighths of a sleep per 1-KiB store, the
+ * extra quarter-sleeps on steps on which >= 32 envs finished and whether cw_step tunes that number online (1) or it is fixed (0), the regime
+ * guard of an unpaced sweep (-1 off, 0 watching, 1 trial of the paced sweep under way, 2 the paced sweep was kept, 3 opening survey) and the
+ * trials it has run, and whether the engine keeps look-ahead records (cw_config.auto_reset, device-resident outputs).  Only performance
+ * depends on any of it. */
 typedef struct cw_tuner_state {
-    int32_t place, surveys, struck_mask, sleeps_beside, place_tuned, sleeps_tuned;
-    /* which painter the full-frame step runs (cw_create timed them: 0 frame per wave, 1 sweep of cell rows, 2 sweep of aligned pieces), the
-     * piece sweep's pace in eighths of a sleep per 1-KiB store, and its regime guard: -1 off, 0 watching, 1 trial of the paced sweep under
-     * way, 2 the paced sweep was kept; how many trials it has run */
-    int32_t painter, piece_pace, guard_state, guard_trials;
+    int32_t piece_pace, pace_beside, pace_beside_tuned, guard_state, guard_trials, lookahead;
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 

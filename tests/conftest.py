@@ -15,11 +15,3 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
-
-
-@pytest.fixture
-def experiment_build(monkeypatch):
-    """Engines created inside the test load libcraftingworld_exp.so (same sources, -DCW_EXPERIMENT): the launch-shape knobs
-    (CW_TUNE_FUSED_RENDER, CW_TUNE_OVERLAP, CW_TUNE_FUSED_STEP, CW_TUNE_RENDER_LINEAR, CW_TUNE_RENDER_QALL, ...) are compiled out of
-    the product library."""
-    monkeypatch.setenv('CW_EXPERIMENT_BUILD', '1')

@@ -641,8 +641,8 @@ def test_config4_shard_shape_mixed_menus_131072():
 def test_altobs_raster_vs_oracle(obs_mode, S, N):
     """the AltObs rasteriser (3x3-px CPV tiles + holding strip) in both pixel modes
     vs the oracle: all three frames, cw_render, terminal frames; includes sticks held over sticks (2 x colour).
-    (6x6 frames are painted frame per wave; frames of >= 4 KiB -- 13x13, 21x21 -- by the sweep of aligned 4-KiB pieces, whose pieces
-    here overlap two frames, one of them often being reset, and end in a partial piece.)"""
+    (All sizes go through the sweep of aligned 4-KiB pieces: a piece of the 6x6 array overlaps up to five 1 134-byte frames, of the 13x13 and
+    21x21 arrays two; the arrays end in a partial piece.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from oracle import OracleBatch
     T, kw = 90, dict(size=(S, S), max_steps=30)
@@ -653,7 +653,7 @@ def test_altobs_raster_vs_oracle(obs_mode, S, N):
     obs = env.reset()
     ora.reset()
     assert tuple(obs['observation'].shape) == (N, 3 * S + 3, 3 * S, 3)
-    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_pieces_kernel' if S >= 13 else 'cw_render_frames_kernel')      # (keep_terminal_obs: render and resets on two streams)
+    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_pieces_kernel')
     acts = np.random.RandomState(2).randint(0, 6, size=(T, N)).astype(np.int32)
     dacts = torch.as_tensor(acts, device=env.device)
     for t in range(T):
@@ -900,20 +900,20 @@ def test_systematic_transition_table():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('obs_mode,raster,N', [('state', 'ray', 1003), ('state', 'ray', 70001), ('pixels_dirty', 'ray', 5000),
-                                               ('pixels_dirty', 'alt', 777)])
-def test_single_launch_step_equals_separate_kernels(obs_mode, raster, N, monkeypatch, experiment_build):
-    """State-only and dirty-cell modes run a whole auto-reset step as ONE launch (cw_step_fused_kernel: a wave
-    steps its envs and resets the finished ones inline); CW_TUNE_FUSED_STEP=0 selects the separate step / reset
-    kernels the full-frame mode uses.  Same seeds and actions: every buffer, counter and RNG stream must agree,
-    with batch sizes that leave the last wavefront partly filled."""
+                                               ('pixels_dirty', 'alt', 777), ('pixels', 'ray', 5000), ('pixels', 'alt', 777)])
+def test_lookahead_records_equal_the_slow_path(obs_mode, raster, N, monkeypatch):
+    """Engines that reset by themselves keep the outcome of every env's NEXT reset() ready (cw_refill_kernel, every 16 steps) and a finished
+    env takes it over inside the step kernel; an env that finishes again before the next refill is reset the slow way, on the spot.
+    CW_TUNE_LOOKAHEAD=0 keeps no records at all.  Same seeds and actions, episodes of at most 17 steps ending on every step (so both ways are
+    taken all the time): every buffer, counter and RNG stream must agree, with batch sizes that leave the last wavefront partly filled."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     kw = dict(size=(9, 9), max_steps=17, obs_mode=obs_mode, raster=raster, seed=77)
     if obs_mode != 'state':
         kw['keep_terminal_obs'] = True
     one = CraftingWorldVecEnv(N, **kw)
-    monkeypatch.setenv('CW_TUNE_FUSED_STEP', '0')
+    monkeypatch.setenv('CW_TUNE_LOOKAHEAD', '0')
     two = CraftingWorldVecEnv(N, **kw)
-    monkeypatch.delenv('CW_TUNE_FUSED_STEP')
+    monkeypatch.delenv('CW_TUNE_LOOKAHEAD')
     one.reset(); two.reset()
     phase = (np.arange(N) * 5 % 17).astype(np.int32)          # some envs finish on every step
     one.set_state(step_num=phase); two.set_state(step_num=phase)
@@ -1081,113 +1081,58 @@ def test_single_env_facades_replay_fixtures(name, variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,shares', [(5000, '1,0'), (5000, '3,1'), (5000, '4,0'), (65536, '10,1'), (65536, '63,0'), (65536, 'off'),
-                                      (70001, '40,1')])
-def test_render_frame_shares_never_change_the_frames(N, shares, monkeypatch, experiment_build):
-    """The full-frame render kernel splits the frames unevenly between even and odd workgroups (XCD-aware shares that
-    cw_create calibrates).  Whatever the split -- forced here to extreme values, either parity, or switched off --
-    every frame must be painted exactly as the dirty-cell engine paints it: the split may only change the speed.  (The shares belong to
-    the frame-per-wave painter -- CW_TUNE_RENDER_LINEAR=0 here, as for the AltObs raster and grids wider than 64 cells; the linear sweep
-    of the one-launch step runs on equal shares.)"""
-    from gym_craftingworld_amd import CraftingWorldVecEnv
-    kw = dict(size=(21, 21), max_steps=9, seed=13)
-    monkeypatch.setenv('CW_TUNE_RENDER_LINEAR', '0')
-    monkeypatch.setenv('CW_TUNE_PIECE_SWEEP', '0')
-    if shares == 'off':
-        monkeypatch.setenv('CW_TUNE_RENDER_SHARES', '0')
-    else:
-        monkeypatch.setenv('CW_TUNE_RENDER_QALL', shares)
-    full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
-    assert full.render_kernel_name() == 'cw_render_frames_step_kernel'
-    monkeypatch.delenv('CW_TUNE_RENDER_SHARES', raising=False)
-    monkeypatch.delenv('CW_TUNE_RENDER_QALL', raising=False)
-    monkeypatch.delenv('CW_TUNE_RENDER_LINEAR')
-    monkeypatch.delenv('CW_TUNE_PIECE_SWEEP')
-    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
-    of, od = full.reset(), dirty.reset()
-    full.obs_fill = of['observation'].fill_(7)            # poison: a frame the kernel skipped would keep this value
-    gen = torch.Generator(device='cuda').manual_seed(2)
-    for t in range(12):
-        a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen)
-        of, rf, df, _ = full.step(a)
-        od, rd, dd, _ = dirty.step(a)
-        assert torch.equal(of['observation'], od['observation']), t
-        assert torch.equal(rf, rd) and torch.equal(df, dd)
-        if t == 5:
-            of['observation'].fill_(9)
-    out = torch.full_like(od['observation'], 5)
-    assert torch.equal(full.render(out), od['observation'])          # cw_render (mode 2) uses the same split
-    full.close(); dirty.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (4099, 8, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'),
-                                           (3001, 10, 'ray'), (133, 128, 'ray'),
+@pytest.mark.parametrize('N,size,raster', [(3000, 21, 'ray'), (65536, 21, 'ray'), (2000, 32, 'ray'), (700, 70, 'ray'), (3001, 10, 'ray'), (133, 128, 'ray'),
+                                           (4099, 8, 'ray'), (5003, 5, 'ray'), (3333, 4, 'ray'), (2001, 9, 'ray'), (1999, 6, 'ray'), (777, 7, 'ray'),
                                            (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'), (2999, 12, 'alt'),
-                                           (3000, 21, 'alt-frames'), (65536, 21, 'alt-frames'), (1501, 32, 'alt-frames'),
-                                           (3000, 21, 'ray-rows'), (65536, 21, 'ray-rows'), (2000, 32, 'ray-rows'), (701, 70, 'ray-rows'),
-                                           (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked'), (3001, 21, 'ray-rows-chunked'), (70000, 21, 'ray-rows-chunked')])
-def test_full_pixel_step_launch_arrangements_agree(N, size, raster, monkeypatch, experiment_build):
-    """The full-frame step runs its render and its auto-resets as ONE launch (cw_render_step_kernel: the grid's first workgroups
-    sweep the frames of the envs that go on, the last ones reset the finished envs and paint their three frames).  The older
-    arrangements stay selectable -- two kernels on two streams (CW_TUNE_FUSED_RENDER=0), one stream with the resets first
-    (CW_TUNE_OVERLAP=0) -- and all three must leave exactly the frames, results and random streams of the dirty-cell engine,
-    with episodes ending on every step (phases spread out) and all at once."""
+                                           (3111, 4, 'alt'), (2777, 5, 'alt'), (1234, 8, 'alt'), (999, 11, 'alt'),
+                                           (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked'), (20000, 8, 'ray-chunked'), (30001, 5, 'ray-chunked'),
+                                           (20011, 13, 'alt-chunked'), (30000, 5, 'alt-chunked')])
+def test_full_frame_step_of_every_frame_size_equals_the_dirty_cell_engine(N, size, raster, monkeypatch):
+    """The full-frame step = step kernel (finished envs take their look-ahead records), ONE sweep of aligned 4-KiB pieces over the
+    observation array whatever the frame size (a piece overlaps two frames from 10x10 / AltObs 12x12 up, as many as nine of the smallest),
+    then the done list's kernel (INIT_OBS / desired_goal frames, the resets of envs that found no record).  Every frame size, both
+    rasters, batches that end in a partial piece, and large batches swept in chunks must leave exactly the frames, results and random
+    streams of the dirty-cell engine, with episodes of 7 steps ending on every step (phases spread out) and all at once."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
-    if raster.endswith('-chunked'):  # large batches are swept in several launches over consecutive env ranges (cw_piece_chunks / cw_sweep_chunks): here
-        raster = raster[:-8]         # 3-5 / 7-14 of them, the last one shorter, the resetting workgroups on the first
-        monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '5' if N < 10000 else '35')
-    # frames of at least 4 KiB: the per-step render is the sweep of aligned 4-KiB pieces (render_pieces) ...
-    pieces = raster in ('ray', 'alt') and (27 * size * (size + 1) if raster == 'alt' else 48 * size * size) >= 4096
-    if pieces:
-        monkeypatch.setenv('CW_TUNE_PIECE_PACE', '2')           # (forced: cw_create would otherwise keep whichever painter it measures faster)
-    else:                            # ... or the older painters (smaller frames, or when cw_create measures them faster): the Ray raster's sweep of
-        raster = raster[:3]          # cell rows (grids up to 64x64), else frame per wave
-        monkeypatch.setenv('CW_TUNE_PIECE_SWEEP', '0')
+    if raster.endswith('-chunked'):  # large batches are swept in several launches over consecutive env ranges (cw_piece_chunks): here the chunks are 4 096 envs,
+        raster = raster[:-8]         # the last one shorter
+        monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '1')
+    monkeypatch.setenv('CW_TUNE_PIECE_PACE', '2')
     kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
-    engines = {}
-    for name, var in (('one launch', None), ('two streams', 'CW_TUNE_FUSED_RENDER'), ('one stream', 'CW_TUNE_OVERLAP')):
-        if var:
-            monkeypatch.setenv(var, '0')
-        engines[name] = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
-        if var:
-            monkeypatch.delenv(var)
-    stem = 'cw_render_pieces' if pieces else 'cw_render' if (raster == 'ray' and size <= 64) else 'cw_render_frames'
-    assert engines['one launch'].render_kernel_name() == stem + '_step_kernel'
-    assert engines['two streams'].render_kernel_name() == stem + '_kernel'
+    full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    assert full.render_kernel_name() == 'cw_render_pieces_kernel'
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
-    for e in list(engines.values()) + [dirty]:
+    for e in (full, dirty):
         e.reset()
+    for k in ('observation', 'desired_goal', 'init_observation'):
+        assert torch.equal(full._observation()[k], dirty._observation()[k]), ('reset', k)
     gen = torch.Generator(device='cuda').manual_seed(5)
     for t in range(20):
         a = torch.randint(0, 6, (N,), device='cuda', dtype=torch.uint8, generator=gen)
         if t == 9:                                         # from here on the phases are spread out: env i has taken i % 7 steps
-            for e in list(engines.values()) + [dirty]:
+            for e in (full, dirty):
                 e.set_state(step_num=(np.arange(N) % 7).astype(np.int32))
         od, rd, dd, _ = dirty.step(a)
-        for name, e in engines.items():
-            o, r, d, _ = e.step(a)
-            assert torch.equal(o['observation'], od['observation']), (name, t, 'observation')
-            assert torch.equal(o['desired_goal'], od['desired_goal']), (name, t, 'desired_goal')
-            assert torch.equal(o['init_observation'], od['init_observation']), (name, t, 'init_observation')
-            assert torch.equal(r, rd) and torch.equal(d, dd), (name, t)
+        o, r, d, _ = full.step(a)
+        assert torch.equal(o['observation'], od['observation']), (t, 'observation')
+        assert torch.equal(o['desired_goal'], od['desired_goal']), (t, 'desired_goal')
+        assert torch.equal(o['init_observation'], od['init_observation']), (t, 'init_observation')
+        assert torch.equal(r, rd) and torch.equal(d, dd), t
         if t == 12:
-            for e in engines.values():
-                e._obs.fill_(9)                           # poison: a frame nobody paints would keep this value
+            full._obs.fill_(9)                            # poison: a frame nobody paints would keep this value
     kd, pd = dirty.get_rng_states()
-    for name, e in engines.items():
-        k, p_ = e.get_rng_states()
-        assert np.array_equal(k, kd) and np.array_equal(p_, pd), name
-        assert torch.equal(e.counters, dirty.counters), name
-        e.close()
+    k, p_ = full.get_rng_states()
+    assert np.array_equal(k, kd) and np.array_equal(p_, pd)
+    assert torch.equal(full.counters, dirty.counters)
+    full.close()
     dirty.close()
 
 
 @pytest.mark.gpu
-def test_regime_guard_trials_change_no_frame(monkeypatch, capfd, experiment_build):
+def test_regime_guard_trials_change_no_frame(monkeypatch, capfd):
     """cw_step's regime guard (cw_engine.cpp: cwh_regime_guard) watches the unpaced piece sweep: when its windows read 10 % above the best level seen
-    it tries the paced sweep for 32 windows and keeps it only if that is 3 % faster (decision logic: tests/test_host_logic.py).  Here the experiment
-    build's CW_TUNE_REGIME_GUARD=2 makes every watched window read "bad", so trials come round by themselves (after 32 windows, then after the
+    it tries the paced sweep for 32 windows and keeps it only if that is 3 % faster (decision logic: tests/test_host_logic.py).  Here
+    CW_TUNE_REGIME_GUARD=2 makes every watched window read "bad", so trials come round by themselves (after 32 windows, then after the
     hold-off): the sweep's pace changes under a running step sequence -- frames, results and random streams stay those of the dirty-cell engine."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     monkeypatch.setenv('CW_TUNE_VERBOSE', '1')
@@ -1195,8 +1140,8 @@ def test_regime_guard_trials_change_no_frame(monkeypatch, capfd, experiment_buil
     N, kw = 65536, dict(size=(21, 21), max_steps=300, seed=31)
     full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
     monkeypatch.delenv('CW_TUNE_REGIME_GUARD')
-    if full.render_kernel_name() != 'cw_render_pieces_step_kernel':
-        pytest.skip('cw_create kept another painter on this box')
+    if full.tuner_state()['guard_state'] < 0:
+        pytest.skip('cw_create chose a paced sweep on this box: no guard to test')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     for e in (full, dirty):
         e.reset()
@@ -1914,43 +1859,6 @@ def test_headline_perf_floor_of_the_sweep_kernel():
     assert r['kernel'] in ('cw_render_pieces_step_kernel', 'cw_render_step_kernel') and d['config']['envs_per_gpu'] == 65536
     assert r['frac_at_median_launch'] >= 0.72, r
     assert d['value'] >= 2.45e8, d['value']                         # ... and the whole step (round 1: 2.30e8, rounds 2-3: 2.72-2.80e8)
-
-
-@pytest.mark.gpu
-def test_every_placement_of_the_sweep_loop_paints_the_same_frames():
-    """cw_render_step_kernel<0..7> differ by where their batch loop lies in the code object and by nothing else: forced one by one
-    (CW_TUNE_RENDER_PLACE) they leave the same frames, results and random streams as the dirty-cell engine, resets included."""
-    from gym_craftingworld_amd import CraftingWorldVecEnv
-    N, T = 4099, 30
-    kw = dict(size=(21, 21), max_steps=9, seed=5)
-    acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(3))
-    ref = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
-    ref.reset()
-    for t in range(T):
-        ref.step(acts[t])
-    want = (ref._obs.clone(), ref._desired_img.clone(), ref._init_img.clone(), ref.reward.clone(), ref.hdr.clone(), ref.get_rng_states())
-    ref.close()
-    old = os.environ.get('CW_TUNE_RENDER_PLACE')
-    os.environ['CW_TUNE_PIECE_SWEEP'] = '0'                # (the placements are the cell-row sweep's)
-    try:
-        for k in range(8):
-            os.environ['CW_TUNE_RENDER_PLACE'] = str(k)
-            env = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
-            assert env.render_kernel_name() == 'cw_render_step_kernel'
-            env.reset()
-            for t in range(T):
-                env.step(acts[t])
-            assert torch.equal(env._obs, want[0]) and torch.equal(env._desired_img, want[1]) and torch.equal(env._init_img, want[2]), k
-            assert torch.equal(env.reward, want[3]) and torch.equal(env.hdr, want[4]), k
-            keys, pos = env.get_rng_states()
-            assert np.array_equal(keys[:, 1:], want[5][0][:, 1:]) and np.array_equal(pos, want[5][1]), k
-            env.close()
-    finally:
-        os.environ.pop('CW_TUNE_PIECE_SWEEP', None)
-        if old is None:
-            os.environ.pop('CW_TUNE_RENDER_PLACE', None)
-        else:
-            os.environ['CW_TUNE_RENDER_PLACE'] = old
 
 
 def _reference_render_of_any_state(state):

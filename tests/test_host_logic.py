@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 3
+    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header(lib, tmp_path):
@@ -175,6 +175,36 @@ def test_mt_conversion_property(seed, burn, draws):
     assert np.array_equal(rs.randint(0, 2**32, size=700, dtype=np.uint32), rs2.randint(0, 2**32, size=700, dtype=np.uint32))
 
 
+@settings(max_examples=80, deadline=None)
+@given(seed=st.integers(0, 2**32 - 1), burn=st.integers(0, 1400), ahead=st.integers(0, 3000))
+def test_mt_rewind_property(seed, burn, ahead):
+    """Look-ahead records leave an env's stream one reset AHEAD; cw_get_mt reports the position before it by rewinding the exported numpy state
+    by the record's draws (cwh_mt_rewind: within the generation, and through cwh_mt_untwist across any number of generations).  For any state:
+    export `ahead` draws later (through the engine form, as cw_get_mt does), rewind by `ahead` -> the stream from the state `burn` draws in,
+    the same position modulo 624 and the same key words from there on."""
+    from gym_craftingworld_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(seed)
+    if burn:
+        rs.randint(0, 2**32, size=burn, dtype=np.uint32)
+    want = rs.get_state()
+    state = rs.get_state()
+    s = state[1].astype(np.uint32).copy()
+    k = lib.cwh_mt_from_numpy(s.ctypes.data_as(C.c_void_p), int(state[2]))
+    for _ in range(ahead):
+        _, k = _engine_next(s, k)
+    key = np.empty(624, dtype=np.uint32)
+    lib.cwh_mt_to_numpy(s.ctypes.data_as(C.c_void_p), k, key.ctypes.data_as(C.c_void_p))
+    pos = C.c_int32(k)
+    lib.cwh_mt_rewind(key.ctypes.data_as(C.c_void_p), C.byref(pos), ahead)
+    assert 0 <= pos.value <= 624 and pos.value % 624 == int(want[2]) % 624
+    rs2 = np.random.RandomState()
+    rs2.set_state(('MT19937', key, pos.value, 0, 0.0))
+    assert np.array_equal(rs.randint(0, 2**32, size=1500, dtype=np.uint32), rs2.randint(0, 2**32, size=1500, dtype=np.uint32))
+    if int(want[2]) < 624:          # numpy holds the same generation: the words not yet consumed are its own
+        assert np.array_equal(np.asarray(want[1])[max(pos.value, 1):], key[max(pos.value, 1):])
+
+
 @settings(max_examples=200, deadline=None)
 @given(world=st.integers(1, 64), total=st.integers(1, 2**22))
 def test_shard_range_property(world, total):
@@ -238,36 +268,6 @@ def test_batch_space_adds_a_leading_axis():
     assert b['hdr'].shape == (7, 16) and b['slot_pos'].shape == (7, 8) and b['slot_pos'].dtype == np.int16
     assert int(b['slot_pos'].low.min()) == -2 and int(b['slot_pos'].high.max()) == 32767 and int(b['observation'].high.max()) == 255
     assert batch_space(Discrete(6), 5).nvec.tolist() == [6] * 5
-
-
-def test_placement_survey_holds_the_median_placement_off_the_cliff():
-    """The decision of cw_step's placement survey (cwh_choose_place, cw_engine.cpp: adapt_tick) on survey vectors recorded on MI355X boxes
-    (profiles/r03_placement.txt): of the placements within 6 % of the fastest the MEDIAN one -- never one on the cliff, never the lone
-    fast outlier while a plateau exists (it is bistable), the lone survivor when everything else is on the cliff; struck placements and
-    placements without a figure do not compete."""
-    import ctypes as C
-    from gym_craftingworld_amd import _lib
-    lib = _lib.load()
-
-    def choose(med, struck=0):
-        arr = (C.c_float * 8)(*med)
-        n = C.c_int(0)
-        return lib.cwh_choose_place(arr, struck, C.byref(n)), n.value
-
-    headline = [0.2369, 0.2359, 0.2299, 0.2346, 0.2363, 0.2343, 0.2378, 0.2424]      # 65 536 envs: 2 is the bistable fast outlier, all within 6 %
-    k, n = choose(headline)
-    assert n == 8 and k == 1 and headline[k] == sorted(headline)[3]
-    mixed = [0.4693, 0.4629, 0.5521, 0.5738, 0.5732, 0.5531, 0.4716, 0.4749]         # 131 072 envs: 2-5 are 20 % slower
-    k, n = choose(mixed)
-    assert n == 4 and k == 0
-    lone = [4.6112, 4.4330, 3.7898, 4.8034, 4.8254, 4.8369, 4.8117, 4.7773]           # 2^20 envs in 1792-round chunks: everything but 2 on the cliff
-    assert choose(lone) == (2, 1)
-    desync = [0.2568, 0.2816, 0.2890, 0.2829, 0.2815, 0.2741, 0.2526, 0.2532]        # phases spread out: 1-5 are 10 % slower
-    k, n = choose(desync)
-    assert n == 3 and k == 7
-    assert choose(headline, struck=1 << 1)[0] == 4                                  # the held placement fell out of its regime: next survey without it
-    assert choose([0, 0, 0.25, 0, 0, 0, 0, 0]) == (2, 1) and choose([0.0] * 8) == (-1, 0)
-    assert choose([0.25, 0.24, 0, 0, 0, 0, 0, 0], struck=3) == (-1, 0)
 
 
 def test_regime_guard_of_the_unpaced_piece_sweep():
