@@ -61,8 +61,7 @@ class cw_profile(C.Structure):
 
 
 class cw_tuner_state(C.Structure):
-    _fields_ = [('piece_pace', C.c_int32), ('pace_beside', C.c_int32), ('pace_beside_tuned', C.c_int32), ('guard_state', C.c_int32),
-                ('guard_trials', C.c_int32), ('lookahead', C.c_int32)]
+    _fields_ = [('period16', C.c_int32), ('piece_pace', C.c_int32), ('lookahead', C.c_int32), ('reserved', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)
@@ -106,7 +105,6 @@ HOST_HELPERS = {
     'cwh_mt_init_genrand': (None, [_VP, C.c_uint32]),
     'cwh_mt_untwist': (None, [_VP]),
     'cwh_mt_rewind': (None, [_VP, C.POINTER(C.c_int32), C.c_uint32]),
-    'cwh_regime_guard': (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_uint, C.c_int]),
     'cwh_dlpack_make': (_VP, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 

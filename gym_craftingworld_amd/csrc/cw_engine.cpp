@@ -27,7 +27,8 @@ hipError_t cwk_launch_render_onehot(const CwParams *P, const uint8_t *onehot, in
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st);
 hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, int32_t *rewards, uint8_t *dones, hipStream_t st);
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st);
-hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, int list_aware, hipStream_t st);
+hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, hipStream_t st);
+void cwk_sweep_shape(const CwParams *P, const CwTuning *T, int *n_chunks, int *waves, int *jobs_per_wave);
 hipError_t cwk_launch_idle(hipStream_t st);
 hipError_t cwk_launch_export(const CwParams *P, const CwTuning *T, uint8_t *out, int onehot, int which, hipStream_t st);
 }
@@ -67,7 +68,6 @@ struct DeviceGuard {
     }
 };
 
-enum { CW_ADAPT_RING = 256 };
 struct cw_engine {
     int device = 0;
     int obs_mode = 0;
@@ -93,34 +93,8 @@ struct cw_engine {
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
     unsigned la_steps = 0;
     int prof_cap = 0, prof_n = 0;
-    // online tuner of the sweep's pace (full-frame mode): see adapt_tick
-    struct Adapt {
-        bool on = false;
-        hipEvent_t ev[CW_ADAPT_RING] = {nullptr};   // ev[w % RING] is recorded on the caller's stream when window w begins (the host may run
-                                               // RING windows = 2 048 steps ahead of the GPU before measurements are lost)
-        unsigned seq = 0;                      // steps taken in the tuned mode
-        unsigned next_window = 0;              // first window whose duration has not been read yet
-        // (1) the extra quarter-sleeps per store on steps on which >= 32 envs finished
-        bool pace_on = false;                  // tuned (off: CW_TUNE_PACE_BESIDE forces the number)
-        int cur = 1;                           // the value currently held
-        signed char pace_of_window[CW_ADAPT_RING] = {0};  // what each recent window ran at; negative: a settling window, not counted
-        float stat[16] = {0};                  // per value: running mean step time of its counted windows (ms; 0: unknown)
-        unsigned stat_window[16] = {0};        // window of the newest sample in stat[]
-        bool tainted[CW_ADAPT_RING] = {false};            // a step of the window was bracketed by cw_profile_* events (each costs a pipeline bubble): not counted
-        // (2) the base pace: unpaced, watched by the regime guard (cwh_regime_guard)
-        bool guard_on = false;
-        float guard[41] = {};
-        int guard_pace = 0;                    //     what the guard last said: 0 unpaced, 1 paced
-        bool guard_test = false;
-        int guard_trials = 0, gpace_last = 0;
-        unsigned gsurvey_w0 = 16;
-        signed char gpace_of_window[CW_ADAPT_RING] = {};   // what the window was launched with: 0 unpaced, 1 paced, -1 the first after a change (not counted)
-    } adapt;
 };
 enum { CW_LA_PERIOD = 16 };
-enum { CW_ADAPT_W = 8, CW_ADAPT_MAX = 8, CW_GUARD_PACE = 2 /* eighths */ };
-extern "C" int cwh_regime_guard(float *s, float ms, unsigned window, int ran_paced);
-
 // ------------------------------------------------------------------------------ resident stepper (host side)
 // Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
 static int resident_park(cw_engine *e)
@@ -248,71 +222,6 @@ void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, c
     return m;
 }
 
-// The piece sweep's REGIME GUARD (adapt_tick), as a pure function fed one counted window at a time: its level (ms per step) and the pace it was LAUNCHED
-// with (0 unpaced, 1 paced; the host may be many windows ahead of the GPU, so what a window ran with is recorded when it starts, not inferred).
-// The unpaced sweep sits just short of the write path's slower, saturated regime (profiles/r03_pieces.txt B, F, N-P); should a process find itself in
-// it -- another build, another box, another driver, a neighbour on the memory system -- a paced sweep is the way out: 3 % slower than the good regime,
-// 13 % faster than the bad.
-//  * It opens with a SURVEY (state 3; the caller starts it with s[2] = 3, everything else 0): six unpaced windows, then six paced ones; paced 3 % faster than
-//    unpaced: it stays for the process (-> 2).  (Launches timed at cw_create, without the step kernel in between, do not show a build whose unpaced
-//    sweep is in the slower regime from its first step; and later there would be no better level to compare with.)
-//  * Watching (0): unpaced windows more than 10 % above the best level seen, 32 in a row -> TRIAL (1) of the paced sweep, 32 paced windows (the first
-//    two settle); 3 % faster than the 32 unpaced ones before it: it stays (-> 2); otherwise back to unpaced, the level of those windows is the new normal
-//    (the workload changed -- episode phases that spread out cost 12 % --, not the regime), and the next trial has to wait twice as long.
-// state: [0] best level, [1] bad windows in a row, [2] the state, [3] paced windows seen (trial) / unpaced (survey), [4] sum of them, [5] mean of the last
-// 32 unpaced windows before the trial / paced windows seen (survey), [6] window of the earliest next trial / sum of the paced ones (survey), [7] hold-off,
-// [8..39] ring of the last 32 unpaced levels, [40] ring position.
-// -> the pace to launch with from now on: 0 unpaced, 1 paced.
-int cwh_regime_guard(float *s, float ms, unsigned window, int ran_paced)
-{
-    enum { BEST, BAD, STATE, TRIAL_N, TRIAL_SUM, BEFORE, NEXT, HOLD, RING = 8, POS = 40 };
-    if (s[STATE] == 2.f) return 1;
-    if (s[STATE] == 3.f) {
-        if (ran_paced) { s[BEFORE] += 1.f; s[NEXT] += ms; if (ms > s[RING + 1]) s[RING + 1] = ms; }
-        else { s[TRIAL_N] += 1.f; s[TRIAL_SUM] += ms; if (ms > s[RING]) s[RING] = ms; }
-        const int n0 = (int)s[TRIAL_N], n1 = (int)s[BEFORE];
-        if (n0 < 6) return 0;
-        if (n1 < 6) return 1;
-        // (means without each side's slowest window: one may hold a step on which every env was reset)
-        const float unpaced_ms = (s[TRIAL_SUM] - s[RING]) / (float)(n0 - 1), paced_ms = (s[NEXT] - s[RING + 1]) / (float)(n1 - 1);
-        s[TRIAL_N] = s[TRIAL_SUM] = s[BEFORE] = s[NEXT] = s[RING] = s[RING + 1] = 0.f;
-        if (paced_ms < 0.97f * unpaced_ms) { s[STATE] = 2.f; s[BEST] = paced_ms; return 1; }
-        s[STATE] = 0.f;
-        s[BEST] = unpaced_ms;
-        return 0;
-    }
-    if (s[STATE] == 1.f) {
-        if (!ran_paced) return 1;                                          // (launched before the trial began)
-        s[TRIAL_N] += 1.f;
-        if (s[TRIAL_N] > 2.f) s[TRIAL_SUM] += ms;
-        if (s[TRIAL_N] < 32.f) return 1;
-        const float trial = s[TRIAL_SUM] / 30.f;
-        if (trial < 0.97f * s[BEFORE]) { s[STATE] = 2.f; return 1; }
-        s[STATE] = 0.f;                                                    // no: the new normal
-        s[BEST] = s[BEFORE];
-        s[BAD] = 0.f;
-        s[HOLD] = s[HOLD] > 0.f ? 2.f * s[HOLD] : 256.f;
-        s[NEXT] = (float)window + s[HOLD];
-        return 0;
-    }
-    if (ran_paced) return 0;                                               // (a straggler of a trial that has ended)
-    const int pos = (int)s[POS];
-    s[RING + pos] = ms;
-    s[POS] = (float)((pos + 1) & 31);
-    if (s[BEST] == 0.f || ms < s[BEST]) s[BEST] = ms;
-    s[BAD] = ms > 1.10f * s[BEST] ? s[BAD] + 1.f : 0.f;
-    if (s[BAD] >= 32.f && (float)window >= s[NEXT]) {
-        float sum = 0.f;
-        for (int i = 0; i < 32; i++) sum += s[RING + i];
-        s[BEFORE] = sum / 32.f;
-        s[STATE] = 1.f;
-        s[TRIAL_N] = 0.f;
-        s[TRIAL_SUM] = 0.f;
-        return 1;
-    }
-    return 0;
-}
-
 void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
 {
     s[0] = seed;
@@ -369,7 +278,7 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     bool ok = true;
     for (hipEvent_t &ev : evs) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int rep = 0; rep < LAUNCHES && ok; rep++)
-        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_sweep_calib(&e->P, &e->tune, e->auto_reset, nullptr) == hipSuccess &&
+        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_sweep_calib(&e->P, &e->tune, nullptr) == hipSuccess &&
              hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     float ms[LAUNCHES];
@@ -383,143 +292,46 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     return CW_OK;
 }
 
-// The sweep's base pace (cw_kernels.hip: render_pieces): eighths of a sleep per 1-KiB store.  The sweep runs fastest unpaced or nearly so -- just
-// short of the write path's slower, saturated regime -- and how much pace it takes to stay clear of that regime depends on details of the build
-// and the shape (round 3's kernel: unpaced 0.2107-0.2121 ms; a build two instructions per batch heavier: unpaced 0.229-0.244, one eighth bimodal
-// 0.210 / 0.239, two eighths a steady 0.2089; profiles/history/r03_pieces.txt F, P).  So the candidates are judged by their 90th-percentile launch, not
-// their median: the smallest pace whose slow launches are within 1.5 % of the best candidate's.  What launches timed here cannot show (the step
-// kernel runs between the sweeps of a step sequence) the regime guard watches for (adapt_tick).
-static int calibrate_pace(cw_engine *e)
+// The sweep's CLOCK (cw_kernels.hip: render_pieces): the period between two jobs of a wave, i.e. the RATE at which a launch writes --
+// waves x 4 KiB per period.  The memory system of an MI355X keeps up with 7.2 TB/s of such a stream (65 536 envs, 21x21: a period of 580 ns for
+// 1 024 waves, 0.2055 ms per launch, 0.86 of the 8 TB/s peak, the same with ~220 envs finishing on every step) and falls into its slower,
+// saturated regime just below that (560 ns: 0.214-0.235 ms, launch by launch); at 7.0 TB/s (600 ns) every launch reads 0.2112 +- 0.0005 ms
+// (profiles/r04_clock.txt).  So the default is 7.0 TB/s, and cw_create CHECKS it on the engine's own batch against 6.8, 6.6 and the unclocked
+// sweep (20 launches each).
+// CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can), CW_TUNE_PIECE_PACE the sleeps inside a job (eighths per store).
+static int calibrate_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
-    if (const char *beside = getenv("CW_TUNE_PACE_BESIDE")) tn.pace_beside = atoi(beside) & 15;
-    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) tn.period16 = (int)(atof(per) * 1.6 + 0.5);
-    if (const char *forced = getenv("CW_TUNE_PIECE_PACE")) { tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF; return CW_OK; }
-    tn.piece_pace = e->P.raster == CW_RASTER_ALT ? 4 : 0;
-    // (small batches are launch-bound: nothing to pace; host-mapped frames are PCIe-bound)
-    if (e->obs_mode != CW_OBS_PIXELS_FULL || e->host_actions || (long long)e->n * e->P.frame_bytes < (64ll << 20)) return CW_OK;
-    static const int eighths_ray[] = {0, 1, 2, 4, 8}, eighths_alt[] = {4, 0, 2, 8, 12};
-    const int *eighths = e->P.raster == CW_RASTER_ALT ? eighths_alt : eighths_ray;
-    double p90s[5] = {0, 0, 0, 0, 0}, t = 0, t90 = 0, best_p90 = 0;
-    char log[320] = "";
+    if (const char *forced = getenv("CW_TUNE_PIECE_PACE")) tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF;
+    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) { tn.period16 = (int)(atof(per) * 1.6 + 0.5); return CW_OK; }
+    int n_chunks = 1, waves = 1024, jobs_per_wave = 1;
+    cwk_sweep_shape(&e->P, &tn, &n_chunks, &waves, &jobs_per_wave);
+    auto period_ns = [&](double tb_per_s) { return (double)waves * 4096.0 / (tb_per_s * 1e12) * 1e9; };
+    tn.period16 = (int)(period_ns(7.0) * 1.6 + 0.5);
+    // (small batches are launch-bound: nothing to check; host-mapped frames are PCIe-bound: unclocked)
+    if (e->host_actions) { tn.period16 = 0; return CW_OK; }
+    if (e->obs_mode != CW_OBS_PIXELS_FULL || (double)e->n * e->P.frame_bytes < (double)(64ll << 20)) return CW_OK;
+    // the candidates, the fastest first; unclocked last (a sweep whose jobs take longer than any useful period -- several small frames per piece --
+    // paces itself: the clock then only costs its reads).  The one with the best 90th-percentile launch: in its saturated regime the memory
+    // system is slower AND erratic (7.5 TB/s: 0.214-0.235 ms launch by launch where 7.0 reads 0.2112 +- 0.0005), so the slow launches tell.
+    static const double rates[] = {7.0, 6.8, 6.6, 0.0};
+    char log[480] = "";
     size_t len = 0;
-    int rc = CW_OK;
-    for (size_t i = 0; i < 5 && rc == CW_OK; i++) {
-        tn.piece_pace = eighths[i];
-        rc = timed_render_stats(e, &t, &t90);
-        p90s[i] = t90;
-        if (rc == CW_OK && (best_p90 == 0 || t90 < best_p90)) best_p90 = t90;
-        if (len < sizeof(log) - 24) len += (size_t)snprintf(log + len, sizeof(log) - len, " %d:%.4f/%.4f", eighths[i], t, t90);
+    int rc = CW_OK, best = tn.period16;
+    double best_p90 = 0, med = 0, p90 = 0;
+    rc = timed_render_stats(e, &med, &p90);           // (a card that idled through set-up runs its first launches a few per cent slower: not counted)
+    for (size_t i = 0; i < sizeof(rates) / sizeof(rates[0]) && rc == CW_OK; i++) {
+        tn.period16 = rates[i] > 0 ? (int)(period_ns(rates[i]) * 1.6 + 0.5) : 0;
+        rc = timed_render_stats(e, &med, &p90);
+        if (len < sizeof(log) - 48) len += (size_t)snprintf(log + len, sizeof(log) - len, " %.1f TB/s (%.0f ns): %.4f/%.4f |", rates[i], tn.period16 / 1.6, med, p90);
+        if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; best = tn.period16; }
     }
-    if (rc != CW_OK) return rc;
-    int best = eighths[0];
-    for (size_t i = 0; i < 5; i++)
-        if (p90s[i] <= 1.015 * best_p90) { best = eighths[i]; break; }             // (the first in the list's order of preference)
-    tn.piece_pace = best;
+    tn.period16 = best;
+    (void)n_chunks; (void)jobs_per_wave;
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] sweep pace, ms per launch (median/90th percentile of 20) by eighths of a sleep per store:%s -> %d\n", log, best);
-    return CW_OK;
-}
-
-// Online tuner of the full-frame step's sweep.  Two things cannot be predicted from launches timed at cw_create (profiles/history/r02_pace.txt,
-// r03_pieces.txt P; profiles/r04_lookahead.txt), so cw_step keeps measuring the thing itself: an event is recorded on the caller's stream every
-// CW_ADAPT_W steps (a "window"), and the time between two consecutive ones, read whenever both have completed -- however far the host runs
-// ahead of the GPU -- is what CW_ADAPT_W whole steps took.  Only performance depends on any of it: every pace paints the same frames.
-// (1) The extra pace on steps on which envs finish.  Windows follow a fixed cycle of 24: twenty at `cur`, two at cur + 1, two at cur - 1 (the
-// first window after a change settles and is not counted; a window holding a step on which every env finished is an outlier and is not counted
-// either); each counted window updates the running figure of its value, and `cur` moves to a neighbour whose figure is 0.7 % better (figures
-// older than three cycles do not count).  With fewer than CW_BESIDE_MIN finished envs per step the value is never used by the kernel and its
-// drift is harmless.
-// (2) The regime guard of an unpaced sweep (cwh_regime_guard).
-static void adapt_tick(cw_engine *e, hipStream_t st)
-{
-    cw_engine::Adapt &a = e->adapt;
-    const unsigned w = a.seq / CW_ADAPT_W;           // the window about to start
-    if (hipEventRecord(a.ev[w % CW_ADAPT_RING], st) != hipSuccess) return;
-    a.tainted[w % CW_ADAPT_RING] = false;
-    const bool verbose = getenv("CW_TUNE_VERBOSE") != nullptr;
-    bool moved = false;
-    while (a.next_window + 1 <= w) {                 // window next_window lies between ev[next_window] and ev[next_window + 1]
-        const unsigned cw = a.next_window;
-        if (w - cw >= CW_ADAPT_RING - 1) { a.next_window++; continue; }          // (its events have been reused)
-        if (cw + 1 == w) break;                                                  // its closing event was recorded just now
-        if (hipEventQuery(a.ev[(cw + 1) % CW_ADAPT_RING]) != hipSuccess) break;
-        float ms = 0.f;
-        const int p = a.pace_of_window[cw % CW_ADAPT_RING];
-        a.next_window++;
-        const bool timed = !a.tainted[cw % CW_ADAPT_RING] && hipEventElapsedTime(&ms, a.ev[cw % CW_ADAPT_RING], a.ev[(cw + 1) % CW_ADAPT_RING]) == hipSuccess && ms > 0.f;
-        ms /= (float)CW_ADAPT_W;
-        if (a.guard_on && timed) {                                            // (2) the sweep's regime: every timed window, whatever the extra pace
-            // (guard_test, experiment build: every watched window reads 20 % above the best level, so trials come round by themselves -- for the test
-            // that a trial changes no frame)
-            const int ran = a.gpace_of_window[cw % CW_ADAPT_RING];
-            if (ran >= 0) {                                                       // (else: the first window after a change of the pace settles)
-                const float state_before = a.guard[2];
-                const int want = cwh_regime_guard(a.guard, a.guard_test && a.guard[2] == 0.f && a.guard[0] > 0.f ? 1.2f * a.guard[0] : ms, cw, ran);
-                if (verbose && state_before == 3.f && a.guard[2] != 3.f)
-                    fprintf(stderr, "[craftingworld] regime guard, opening survey (window %u): %s (level %.4f ms/step)\n", cw,
-                            a.guard[2] == 2.f ? "the paced sweep is 3 % faster than the unpaced one: it stays" : "the unpaced sweep stays", a.guard[0]);
-                if (a.guard[2] == 3.f) {                                              // (the opening survey runs on its schedule)
-                } else if (want != a.guard_pace) {
-                    if (verbose && a.guard[2] != 3.f)
-                        fprintf(stderr, "[craftingworld] regime guard (window %u): %.4f ms/step, best level %.4f -> %s\n", cw, ms, a.guard[0],
-                                want ? (a.guard[2] == 2.f ? "the paced sweep stays" : "trying the paced sweep") : "the unpaced sweep (the paced one is not 3 % faster)");
-                    a.guard_pace = want;
-                    if (want && state_before != 3.f) a.guard_trials++;
-                } else if (verbose && want && a.guard[2] == 2.f && a.guard[3] == 32.f) {
-                    fprintf(stderr, "[craftingworld] regime guard (window %u): the paced sweep is 3 %% faster than the 32 windows before it: it stays\n", cw);
-                    a.guard[3] = 33.f;
-                }
-            }
-        }
-        if (p < 0 || !timed) continue;
-        const bool known = a.stat[p] > 0 && cw - a.stat_window[p] < 80;
-        if (known && ms > 1.06f * a.stat[p]) continue;                           // a reset storm inside the window
-        a.stat[p] = known ? 0.5f * (a.stat[p] + ms) : ms;
-        a.stat_window[p] = cw;
-        moved = true;
-    }
-    if (a.guard_on) {                                // what window w is launched with (the first window after a change settles and is not counted)
-        int gp = a.guard_pace;
-        bool skip = false;
-        if (a.guard[2] == 3.f) {
-            // the opening survey is SCHEDULED by window number, not steered by what has been read: a host that enqueues ahead (bench.py: hundreds of
-            // windows) gets the guard's answers that much later.  After the first 16 windows (a card that idled through set-up runs its first
-            // launches a few per cent slower): 4 unpaced, 4 paced, 4 unpaced, 4 paced (the first of each four settles), unpaced from there on until
-            // all of them have been read and the guard has decided (repeated if the windows were lost to the ring).
-            if (w >= a.gsurvey_w0 && w - a.gsurvey_w0 >= CW_ADAPT_RING + 16) a.gsurvey_w0 = w;
-            const unsigned j = w - a.gsurvey_w0;
-            gp = (w >= a.gsurvey_w0 && j < 16) ? (int)((j >> 2) & 1) : 0;
-            skip = w < a.gsurvey_w0 || (j < 16 && (j & 3) == 0) || j == 16;
-        }
-        a.gpace_of_window[w % CW_ADAPT_RING] = (signed char)(gp != a.gpace_last || skip ? -1 : gp);
-        a.gpace_last = gp;
-        e->tune.piece_pace = gp ? CW_GUARD_PACE : 0;
-    }
-    if (moved && a.pace_on) {                        // move to a neighbour that is measurably better (figures older than ~3 cycles do not count)
-        const int c = a.cur;
-        auto fresh = [&](int p) { return p >= 0 && p <= CW_ADAPT_MAX && a.stat[p] > 0 && a.next_window - a.stat_window[p] < 80; };
-        if (fresh(c)) {
-            int best = c;
-            if (fresh(c + 1) && a.stat[c + 1] < a.stat[best] * 0.993f) best = c + 1;
-            if (fresh(c - 1) && a.stat[c - 1] < a.stat[best] * (best == c ? 0.993f : 1.0f)) best = c - 1;
-            if (best != c) {
-                if (verbose)
-                    fprintf(stderr, "[craftingworld] extra pace on steps with finished envs (online, window %u): +%d %.4f ms/step | +%d %.4f | +%d %.4f -> +%d\n", w, c,
-                            a.stat[c], c + 1, fresh(c + 1) ? a.stat[c + 1] : 0.0, c - 1, fresh(c - 1) ? a.stat[c - 1] : 0.0, best);
-                a.cur = best;
-            }
-        }
-    }
-    // the cycle: 0-19 cur | 20 (settle), 21 cur + 1 | 22 (settle), 23 cur - 1; window 0 of the cycle settles too
-    const unsigned pos = w % 24;
-    int p = a.cur;
-    const bool settle = (pos == 0 || pos == 20 || pos == 22);
-    if (a.pace_on) {
-        if (pos == 20 || pos == 21) p = a.cur + 1 > CW_ADAPT_MAX ? a.cur : a.cur + 1;
-        else if (pos >= 22) p = a.cur > 0 ? a.cur - 1 : a.cur;
-    }
-    a.pace_of_window[w % CW_ADAPT_RING] = (signed char)(settle ? -1 - p : p);
+        fprintf(stderr, "[craftingworld] sweep clock, ms per sweep (median/90th percentile of 20; 0.0 TB/s = unclocked):%s -> %s%.0f ns\n", log,
+                tn.period16 ? "" : "unclocked, ", tn.period16 / 1.6);
+    return rc;
 }
 
 extern "C" {
@@ -603,6 +415,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
+        tn.sweep_blocks_per_cu = geti("CW_TUNE_SWEEP_BLOCKS_PER_CU", tn.sweep_blocks_per_cu);
+        if (tn.sweep_blocks_per_cu < 1) tn.sweep_blocks_per_cu = 1;
     }
 
     int rc = CW_OK;
@@ -628,8 +442,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(achieved_out, N);
     ALLOC_OUT(desired_out, N);
     ALLOC_OUT(episode_length, N);
-    ALLOC(done_list, N);
-    ALLOC(done_count, 4);
     ALLOC(counters, 4);
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
@@ -638,10 +450,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         if (cfg->keep_terminal_obs && cfg->auto_reset) ALLOC_OUT(terminal_img, N * P.frame_bytes);
     }
     if (cfg->host_outputs && rc == CW_OK) rc = host_alloc(e, &e->host_actions, N);
-    if (P.terminal_img) {                            // the finished episode's last state, saved by the step kernel for its terminal frame
-        ALLOC(term_pos, N);
-        ALLOC(term_hx, N);
-    }
     // look-ahead records: every engine that resets by itself and lives in device memory (CW_TUNE_LOOKAHEAD=0: the slow path only, for A/B runs
     // and the test that both give the same results)
     P.lookahead = (cfg->auto_reset && !cfg->host_outputs && !(getenv("CW_TUNE_LOOKAHEAD") && atoi(getenv("CW_TUNE_LOOKAHEAD")) == 0)) ? 1 : 0;
@@ -691,24 +499,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     std::vector<uint32_t> seeds(N);
     for (size_t i = 0; i < N; i++) seeds[i] = (uint32_t)i;
     rc = cw_seed_int(e, seeds.data());
-    if (rc == CW_OK) rc = calibrate_pace(e);
-    if (rc == CW_OK && e->obs_mode == CW_OBS_PIXELS_FULL && e->auto_reset && !e->host_actions &&
-        !(getenv("CW_TUNE_ADAPT") && atoi(getenv("CW_TUNE_ADAPT")) == 0) && (long long)e->n * e->P.frame_bytes >= (64ll << 20)) {
-        cw_engine::Adapt &a = e->adapt;
-        a.cur = e->tune.pace_beside;
-        if (a.cur > CW_ADAPT_MAX) a.cur = CW_ADAPT_MAX;
-        a.pace_on = !getenv("CW_TUNE_PACE_BESIDE");
-        // (2) only the Ray raster's unpaced sweep (AltObs runs paced already), and only if nobody forced a pace
-        a.guard_on = e->P.raster != CW_RASTER_ALT && e->tune.piece_pace == 0 && !getenv("CW_TUNE_PIECE_PACE") &&
-                     !(getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 0);
-        a.guard_test = a.guard_on && getenv("CW_TUNE_REGIME_GUARD") && atoi(getenv("CW_TUNE_REGIME_GUARD")) == 2;
-        if (a.guard_on && !a.guard_test) a.guard[2] = 3.f;                    // (the opening survey)
-        if (a.pace_on || a.guard_on) {
-            for (hipEvent_t &ev : a.ev)
-                if (rc == CW_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: tuner set-up failed");
-            a.on = rc == CW_OK;
-        }
-    }
+    if (rc == CW_OK) rc = calibrate_sweep(e);
     if (rc != CW_OK) {
         cw_destroy(e);
         *out = nullptr;
@@ -726,7 +517,6 @@ int cw_destroy(cw_engine *e)
     (void)hipDeviceSynchronize();
     prof_free(e);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
-    for (hipEvent_t ev : e->adapt.ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
@@ -845,18 +635,6 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     PARK(e);
     e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
-    if (e->adapt.on) {                               // full-frame mode: the sweep's pace follows what the steps measure (adapt_tick)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) {
-            if (e->adapt.seq % CW_ADAPT_W == 0) adapt_tick(e, (hipStream_t)stream);
-            const int pw = e->adapt.pace_of_window[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING];
-            e->tune.pace_beside = pw < 0 ? -1 - pw : pw;
-            if (ev) e->adapt.tainted[(e->adapt.seq / CW_ADAPT_W) % CW_ADAPT_RING] = true;
-            e->adapt.seq++;
-        } else {
-            e->tune.pace_beside = e->adapt.cur;      // a captured graph keeps the values it was captured with
-        }
-    }
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -1052,19 +830,16 @@ const char *cw_render_kernel_name(const cw_engine *e)
 {
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset ? "cw_step_fused_kernel" : "cw_step_kernel";
-    return e->auto_reset ? "cw_render_pieces_step_kernel" : "cw_render_pieces_kernel";
+    return "cw_render_pieces_kernel";
 }
 
 int cw_tuner(const cw_engine *e, cw_tuner_state *out)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_tuner: null argument");
-    const cw_engine::Adapt &a = e->adapt;
+    out->period16 = e->tune.period16;
     out->piece_pace = e->tune.piece_pace;
-    out->pace_beside = a.on && a.pace_on ? a.cur : e->tune.pace_beside;
-    out->pace_beside_tuned = a.on && a.pace_on ? 1 : 0;
-    out->guard_state = a.on && a.guard_on ? (int32_t)a.guard[2] : -1;
-    out->guard_trials = a.guard_trials;
     out->lookahead = e->P.lookahead;
+    out->reserved = 0;
     return CW_OK;
 }
 

@@ -1,17 +1,14 @@
 // cw_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the CraftingWorld engine.
 //
-//   cw_step_kernel    one lane per env: step() of ray.py:301-378 on the sparse slot state, reward, done; a finished env takes over the
-//                     record of its next episode (LOOK-AHEAD, cw_layout.h) in the same lane; wave-ballot compaction of the done list.
-//                     (Full-frame mode and engines without auto-reset; in DIRTY pixel mode also render_edit(), ray.py:522-557.)
-//   cw_step_fused_kernel  state-only / dirty-cell modes: the whole auto-reset step in ONE launch -- a wave steps its 8..64 envs,
-//                     finished ones take their records, whatever is left is reset inline.
+//   cw_step_fused_kernel  step() of ray.py:301-378 for every engine that resets by itself, ONE launch: a wave steps its 8..64 envs on the
+//                     sparse slot state (reward, done), a finished env takes over the record of its next episode in its own lane
+//                     (LOOK-AHEAD, cw_layout.h), whatever is left -- an env without a record, the frames a reset changes -- by the wave.
+//   cw_step_kernel    the same step for engines without auto-reset, one lane per env (in DIRTY pixel mode also render_edit(), ray.py:522-557).
 //   cw_refill_kernel  one WAVEFRONT per env: the NEXT reset() of ray.py:156-218, ahead of time and in bulk = task draw, legacy
 //                     Fisher-Yates placement on the env's MT19937 stream (state staged in LDS, lane-parallel rejection sampling),
 //                     imagine_obs().  cw_reset_kernel: the same for every env at once (explicit reset()).
-//   cw_render_pieces_kernel  render() of ray.py:442-520 (and the AltObs raster) for a whole frame ARRAY as a sweep of aligned 4-KiB
-//                     pieces: a zero fill plus the few lit bytes of the frames a piece overlaps.  The roofline kernel.
-//   cw_list_kernel    after the sweep: INIT_OBS / desired_goal frames of the envs that finished on this step, terminal frames, and the
-//                     reset of any env that found no record.
+//   cw_render_pieces_kernel  render() of ray.py:442-520 (and the AltObs raster) for a whole frame ARRAY as a CLOCKED sweep of aligned 4-KiB
+//                     pieces: a zero fill plus the few lit bytes of the frames a piece overlaps, at a set rate.  The roofline kernel.
 //   cw_rollout_kernel persistent: T steps of every env in one launch (state-only mode).
 //   cw_resident_kernel  the single-env loop without a launch per step (doorbell in pinned host memory).
 //   cw_export_*       dense grid / one-hot views of the slot state.
@@ -21,6 +18,7 @@
 // issue/latency for the others.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cw_layout.h"
 #include "cw_mt.h"
@@ -440,6 +438,27 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
     return o;
 }
 
+// render_edit (ray.py:522-557 / altobs.py:625-640): repaint the <= 2 cells a step changed in the env's persistent frame, by the env's lane
+__device__ __forceinline__ void paint_changed_cells(const CwParams &P, int env, const uint4 &h, const uint32_t sp[8], const CwStepOut &o)
+{
+    uint8_t *frame = P.obs + (size_t)env * P.frame_bytes;
+    const uint32_t hold = (h.x >> 16) & 0xFFu;
+    const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
+    if (P.raster == 1) {
+        const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
+        alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
+        if (o.dirty1 != 0xFFFFFFFFu) {
+            const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
+            alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
+        }
+        alt_paint_strip(frame, P.size, hold, 0, 1, false);
+    } else {
+        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+        if (o.dirty1 != 0xFFFFFFFFu)
+            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+    }
+}
+
 // LOOK-AHEAD (cw_layout.h): the finished env `env` takes over the record of its next episode, if the refill kernel has left one -- the whole
 // of reset() (ray.py:156-218) as three 16-byte loads and the stores of the episode records, by the lane that stepped the env.  h / sp become
 // the new episode's header and slots (reset_header's values).  -> false: no record (the env finished twice between two refills, or the
@@ -465,17 +484,18 @@ __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uin
     unpack_pos(ipos, sp);
     return true;
 }
-#define CW_LIST_POPPED 0x80000000u    // done-list entry: the env took its look-ahead record (its state is the new episode's already)
 
-__global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype,
-                                                      int compact, int paint_dirty)
+// step() for engines WITHOUT auto-reset (the single-env loop's launch path, fixture replays): one lane per env, finished envs keep
+// stepping until cw_reset (ray.py:367); in DIRTY pixel mode also render_edit() of the <= 2 changed cells.  Engines that reset by
+// themselves run cw_step_fused_kernel.
+__global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *actions, int act_dtype, int paint_dirty)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
     }
     const bool live = i < P.n_envs;
-    bool done = false, success = false, invalid = false, popped = false;
+    bool done = false, success = false, invalid = false;
     if (live) {
         int a;
         if (act_dtype == 0) a = ((const int32_t *)actions)[i];
@@ -488,31 +508,6 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         const CwStepOut o = step_env(P, h, sp, a, [&]() { return P.init_pos[i]; });
         done = o.done; success = o.success; invalid = o.invalid;
 
-        if (paint_dirty && o.changed) {                                    // render_edit, :358 (engines without auto-reset)
-            uint8_t *frame = P.obs + (size_t)i * P.frame_bytes;
-            const uint32_t hold = (h.x >> 16) & 0xFFu;
-            const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
-            if (P.raster == 1) {                                           // altobs.py:625-640
-                const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
-                alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
-                if (o.dirty1 != 0xFFFFFFFFu) {
-                    const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
-                    alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
-                }
-                alt_paint_strip(frame, P.size, hold, 0, 1, false);
-            } else {
-                paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
-                if (o.dirty1 != 0xFFFFFFFFu)
-                    paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
-            }
-        }
-        if (done && compact) {                                             // auto-reset
-            if (P.term_pos) {                                              // keep_terminal_obs: the episode's last state, for its terminal frame
-                P.term_pos[i] = pack_pos(sp);
-                P.term_hx[i] = make_uint2(h.x, h.w);
-            }
-            if (P.lookahead) popped = pop_next_episode(P, i, h, sp, true);
-        }
         P.hdr[i] = h;
         P.pos[i] = pack_pos(sp);
         P.reward[i] = o.reward;
@@ -520,36 +515,18 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         P.achieved_out[i] = (uint16_t)o.achieved;
         P.desired_out[i] = (uint16_t)o.desired;
         if (done) P.episode_length[i] = (int32_t)o.step_num;
+        if (paint_dirty && o.changed) paint_changed_cells(P, i, h, sp, o);   // render_edit, :358
     }
-
-    // done-mask compaction with wavefront ballots (64-bit on CDNA)
-    const unsigned long long m_done = CW_BALLOT(done);
-    const unsigned long long m_succ = CW_BALLOT(success);
-    const unsigned long long m_inv = CW_BALLOT(invalid);
-    const unsigned long long m_pop = CW_BALLOT(popped);
-    if (m_done | m_inv) {
-        const int lane = threadIdx.x & (CW_WAVE - 1);
-        int base = 0, rbase = 0;
-        if (lane == 0) {
-            if (m_done) {
-                if (compact) base = atomicAdd(&P.done_count[0], __popcll(m_done));
-                atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
-            }
-            if (m_pop) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
-            if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
-            if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
-        }
-        base = __shfl(base, 0);
-        rbase = __shfl(rbase, 0);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (done && compact) P.done_list[base + __popcll(m_done & below)] = (int32_t)((uint32_t)i | (popped ? CW_LIST_POPPED : 0u));
-        if (popped) P.refill_list[rbase + __popcll(m_pop & below)] = i;      // the refill kernel computes the env's next record
+    const unsigned long long m_done = CW_BALLOT(done), m_succ = CW_BALLOT(success), m_inv = CW_BALLOT(invalid);
+    if ((m_done | m_inv) && (threadIdx.x & (CW_WAVE - 1)) == 0) {
+        if (m_done) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
+        if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
+        if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
     }
 }
 
-// The done counter is zeroed for the next step by the LAST workgroup of the last kernel that reads
-// it (a ticket in done_count[1]) -- no host-side parity and no memset node, so one cw_step is a
-// fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is.
+// a list's counter is zeroed for its next use by the LAST workgroup of the kernel that reads it (a ticket in count[1]) -- no host-side
+// parity and no memset node, so a cw_step is a fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is
 __device__ __forceinline__ void release_list(int32_t *count, int n_blocks)
 {
     __syncthreads();
@@ -688,11 +665,6 @@ __device__ __forceinline__ int nth_with_code(uint32_t v_fp, uint32_t v_fc, uint3
 #define CW_SET_LANE(v, idx, val) v = ((int)lane == (idx)) ? (val) : v
 
 #define CW_RESET_WAVES 4    // waves (= envs in flight) per workgroup
-// the sweep slows down (pace bits 12-15) only beside at least this many resetting waves: with uniform random actions a handful of the
-// 65 536 envs succeed on almost every step, and 1-5 resetting waves do not disturb the sweep -- reacting to them cost 15 us on most
-// launches of the synchronized benchmark (the "two launch modes" of profiles/history/r02_pace.txt H)
-#define CW_BESIDE_MIN 32
-
 // One env's reset() (ray.py:156-218) by one wavefront; every value in the result is wave-uniform.
 struct CwResetOut {
     uint4 init_pos;          // sample_state placement of objects 0..7
@@ -847,8 +819,10 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
     if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
 }
 
-// the three frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the wave that just reset it
-__device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, const CwResetOut &r, int lane)
+// the frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the wave that just reset it.  with_obs:
+// all three (dirty-cell engines: the frame is persistent); without: INIT_OBS and desired_goal only (full-frame engines: the observation array
+// is swept after the step kernel, every env's frame alike)
+__device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, const CwResetOut &r, int lane, bool with_obs)
 {
     const size_t off = (size_t)env * P.frame_bytes;
     uint32_t sp[8], gp[8], rgb[8], grgb[8];
@@ -859,24 +833,14 @@ __device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, c
         rgb[k] = rgb_of_code((uint32_t)k + 1u);
         grgb[k] = rgb_of_code((r.goal_codes >> (4 * k)) & 15u);
     }
+    uint8_t *const d0 = with_obs ? P.obs + off : P.init_img + off, *const d1 = with_obs ? P.init_img + off : nullptr;
     if (P.raster == 1) {
-        render_frame_alt(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, CW_ALT_FRAME_PACE);
+        render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, CW_ALT_FRAME_PACE);
         render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, CW_ALT_FRAME_PACE);
     } else {
-        render_frame(P.obs + off, P.init_img + off, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
+        render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
         render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
     }
-}
-// the last frame of the episode that just ended (keep_terminal_obs), from the state the step kernel saved before the env was reset in place
-__device__ __forceinline__ void paint_terminal_frame(const CwParams &P, int env, int lane)
-{
-    const uint2 hx = P.term_hx[env];
-    uint32_t tp[8], stp[8];
-    unpack_pos(P.term_pos[env], tp);
-#pragma unroll
-    for (int k = 0; k < 8; k++) stp[k] = __builtin_amdgcn_readfirstlane(tp[k]);
-    const uint32_t h_x = __builtin_amdgcn_readfirstlane(hx.x), codes = __builtin_amdgcn_readfirstlane(hx.y);
-    paint_state_frame(P, P.terminal_img + (size_t)env * P.frame_bytes, stp, codes, (h_x & 0xFFu) * P.size + ((h_x >> 8) & 0xFFu), (h_x >> 16) & 0xFFu, lane);
 }
 // the record of an episode as the look-ahead arrays hold it (refill) / as the episode arrays hold it after a pop
 __device__ __forceinline__ void store_next_record(const CwParams &P, int env, const CwResetOut &r)
@@ -933,56 +897,6 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
     }
 }
 
-// The done list of a full-frame step, AFTER the sweep, by the tail workgroups of the sweep's launch (most steps: nothing finished, they leave at once).
-// An env that took its look-ahead record in the step kernel is in its new episode already and its observation was an ordinary frame of the
-// sweep: INIT_OBS and desired_goal are left to paint, one frame per wave.  An env that found no record (it finished twice between two refills)
-// is reset here, the slow way, and all three of its frames painted -- the sweep showed its finished state, this comes after it in stream
-// order.  keep_terminal_obs: the last frame of the episode that ended, from the state the step kernel saved.
-// WHY NOT BESIDE THE SWEEP (rounds 1-3 reset and painted in the render launch's tail workgroups): anything that runs beside the sweep takes its
-// waves out of step and costs the launch far more than its own work -- ~220 resets per step 26 us, their frames alone (the resets gone, thanks to
-// the look-ahead records) still 26 us, the same frames painted by the sweep's own waves at their end 12-15 us; after the sweep, in this kernel,
-// the sweep runs as if nothing had finished; in a kernel of its own after the sweep the same, but an empty launch costs every step 8 us
-// (profiles/r04_lookahead.txt).
-__device__ __forceinline__ void list_block(const CwParams &P, uint32_t (*s_mt)[CW_MT_WORDS], int bid, int n_blocks, int sweep_blocks)
-{
-    const int count = __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (count == 0) return;                              // (every workgroup reads the same value: it changes only after all of them have drawn a ticket)
-    if (threadIdx.x == 0)                                // asleep until the sweep is through (its workgroups were dispatched first: they are resident or done)
-        while (__hip_atomic_load(P.done_count + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sweep_blocks) __builtin_amdgcn_s_sleep(127);
-    __syncthreads();
-    const int lane = threadIdx.x & (CW_WAVE - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int n_waves = n_blocks * CW_RESET_WAVES;
-    for (int j = bid * CW_RESET_WAVES + wave_in_block; j < 2 * count; j += n_waves) {        // two jobs per entry
-        const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane(P.done_list[j >> 1]);
-        const int env = (int)(entry & ~CW_LIST_POPPED);
-        const bool second = j & 1;
-        const size_t off = (size_t)env * P.frame_bytes;
-        if (!second && P.terminal_img) paint_terminal_frame(P, env, lane);
-        if (entry & CW_LIST_POPPED) {
-            uint32_t sp[8], codes, agent_cell, hold;
-            load_state_uniform(P, env, second ? CW_SRC_GOAL : CW_SRC_INIT, sp, codes, agent_cell, hold);
-            paint_state_frame(P, (second ? P.desired_img : P.init_img) + off, sp, codes, agent_cell, hold, lane);
-        } else if (!second) {
-            const uint4 v_h = P.hdr[env];
-            const uint32_t menu_id = __builtin_amdgcn_readfirstlane(v_h.x) >> 24;
-            const CwResetOut r = reset_env_wave(P, env, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
-            if (lane == 0) {
-                store_episode_records(P, env, r, true);               // (step_num >= 1 here)
-                P.pos[env] = r.init_pos;
-                P.hdr[env] = reset_header(P, r, menu_id);
-            }
-            paint_reset_frames(P, env, r, lane);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&P.done_count[1], 1) == n_blocks - 1) {      // the last workgroup out zeroes the list for the next step
-        P.done_count[0] = 0;
-        P.done_count[1] = 0;
-        P.done_count[2] = 0;
-    }
-}
-
 // LOOK-AHEAD refill: the next reset() of every env of the refill list (all_envs: of every env without a record), run ahead of time from
 // the env's stream and parked in the nx_* arrays; the stream is left AFTER that reset (nx_misc.w says by how many draws).  Launched by the
 // host every few steps, between steps: thousands of resets side by side at one wave each cost ~5 ns per reset where ~200 of them beside every
@@ -995,7 +909,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_refill_kernel(CwPa
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
     const int count = all_envs ? P.n_envs : P.refill_count[0];
-    if (count == 0) return;                              // (every workgroup reads the same count: see reset_list_block)
+    if (count == 0) return;                              // (every workgroup reads the same count: it changes only after all of them have drawn a ticket)
     for (int job = wave; job < count; job += n_waves) {
         const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.refill_list[job]);
         const uint32_t v_hx = P.hdr[env].x;
@@ -1180,11 +1094,14 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
     if (lane == 0) __hip_atomic_store(&R->exited, reason | (last << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One cw_step with auto-reset as a SINGLE launch (state-only and dirty-cell pixel modes): a wavefront owns `epw`
-// consecutive envs (8..64, one per lane), steps them, and resets the ones that finished itself, one after the
-// other with all 64 lanes (reset_env_wave) -- painting their frames in the pixel mode.  No done list, no second
-// launch waiting on the first: a step is bounded by one launch plus one reset's latency.  The full-frame pixel
-// mode keeps the separate kernels (its reset hides under the render kernel on a side stream).
+// step() of every engine that resets by itself, in ONE launch: a wavefront owns `epw` consecutive envs (8..64, one per lane) and steps them;
+// a finished env takes its look-ahead record over in its own lane (pop_next_episode), and what needs the whole wave comes after, one
+// finished env at a time: the reset of an env that found no record (reset_env_wave, the slow path) and, in the pixel modes, the frames a
+// reset changes.  paint 0: state-only.  paint 1 (dirty-cell frames): render_edit of the <= 2 changed cells by the env's lane; a finished
+// env's three frames by the wave.  paint 2 (full frames): only INIT_OBS and desired_goal of a finished env -- the observation array is swept
+// after this kernel (cw_render_pieces_kernel), every env's frame alike, and nothing runs beside that sweep: rounds 1-3 reset and painted
+// beside it, which cost the launch 26 us for ~220 finished envs per step (profiles/r04_lookahead.txt).  keep_terminal_obs: the finished
+// episode's last frame, from the lane's registers.  No done list, no second launch waiting on the first.
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
                                                                                 int paint, int epw)
 {
@@ -1212,24 +1129,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         P.achieved_out[env] = (uint16_t)o.achieved;
         P.desired_out[env] = (uint16_t)o.desired;
         if (o.done) P.episode_length[env] = (int32_t)o.step_num;
-        if (paint && o.changed && !o.done) {                               // render_edit, :358 (a finished env is
-            uint8_t *frame = P.obs + (size_t)env * P.frame_bytes;          //  repainted whole by its reset below)
-            const uint32_t hold = (h.x >> 16) & 0xFFu;
-            const uint32_t acell = (h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu);
-            if (P.raster == 1) {
-                const uint32_t r0 = __umulhi(o.dirty0, P.div_magic);
-                alt_paint_tile(frame, P.size, r0, o.dirty0 - r0 * P.size, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold);
-                if (o.dirty1 != 0xFFFFFFFFu) {
-                    const uint32_t r1 = __umulhi(o.dirty1, P.div_magic);
-                    alt_paint_tile(frame, P.size, r1, o.dirty1 - r1 * P.size, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold);
-                }
-                alt_paint_strip(frame, P.size, hold, 0, 1, false);
-            } else {
-                paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
-                if (o.dirty1 != 0xFFFFFFFFu)
-                    paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
-            }
-        }
+        if (paint == 1 && o.changed && !o.done) paint_changed_cells(P, env, h, sp, o);      // render_edit, :358 (a finished env is repainted whole below)
     }
     // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
     const uint4 h_last = h;                          // (the finished episode's last state: keep_terminal_obs paints it below)
@@ -1268,7 +1168,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         }
         if (took) {                                  // (the records lane l stored a moment ago, read back by the whole wave)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            paint_reset_frames(P, env_l, load_episode_record(P, env_l), lane);
+            paint_reset_frames(P, env_l, load_episode_record(P, env_l), lane, paint == 1);
             continue;
         }
         const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
@@ -1278,7 +1178,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
             h = reset_header(P, r, menu_id);
             unpack_pos(r.init_pos, sp);
         }
-        if (paint) paint_reset_frames(P, env_l, r, lane);
+        if (paint) paint_reset_frames(P, env_l, r, lane, paint == 1);
     }
     if (live) {
         P.hdr[env] = h;
@@ -1350,13 +1250,13 @@ __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, 
     }
 }
 template <int RASTER, int FPJ>
-__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int list_aware, int pace, int period16, int env_lo, int env_n, int n_blocks)
+__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int pace, int period16, int env_lo, int env_n)
 {
     constexpr int JPB = CW_WAVE / FPJ;                                      // jobs per batch of records
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wpb = blockDim.x / CW_WAVE;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int n_waves = n_blocks * wpb;
+    const int n_waves = (int)gridDim.x * wpb;
     const int wave = (int)blockIdx.x * wpb + wave_in_block;                 // (four consecutive pieces per workgroup)
     const uint32_t S = (uint32_t)P.size, FB = P.frame_bytes, row_bytes = (RASTER == 1 ? 9u : 12u) * S;
     uint8_t *const dst_base = frames + (size_t)env_lo * FB;
@@ -1377,19 +1277,14 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     const uint32_t off_flag = (3u * S + fjr) * row_bytes + 9u + 3u * (fj - 3u * fjr);      // AltObs lanes pl 10..18: the strip's nine flag pixels
     const bool marks = slot == 0u && (dy == 1u || dy == 2u);                 // Ray: the lanes that paint the agent's mark
     __builtin_amdgcn_s_setprio(3);
-    // PACING.  The write path is LESS efficient saturated than kept just short of saturation (profiles/history/r02_render_linear.txt), and where the
-    // edge lies moves with what else the memory system is doing.  `pace`: EIGHTHS of a sleep per 1-KiB store (bits 0-7: 4 = an s_sleep(1) after every
-    // other store), and bits 12-15 QUARTERS more in every launch of a step on which at least CW_BESIDE_MIN envs finished (the list kernel wrote their
-    // frames a moment ago and will again: such a sweep wants a higher pace to its end -- profiles/r04_lookahead.txt; cw_step tunes the number online)
-    const int pace_base = pace & 0xFF, pace_beside = list_aware ? 2 * ((pace >> 12) & 15) : 0;
+    // PACING.  The write path is LESS efficient saturated than kept just short of saturation (profiles/history/r02_render_linear.txt), and an
+    // unpaced sweep's rate is whatever its waves' instruction streams happen to produce: a few clocks per job -- another code placement, two
+    // more instructions -- moved rounds 2-3's sweeps between 0.83 and 0.70 of the HBM peak.  So the rate is SET (the clock below); `pace`
+    // (eighths of an s_sleep(1) per 1-KiB store inside a job) only spreads a job's four stores.
     int owed = 0;
-    struct Rec { int f, cnt; uint32_t hx, hw, o2; uint4 p; };               // (hx: agent row | col << 8 | hold << 16; o2, Ray: the colour of row 2 of the agent's mark)
-    // fetch() only ISSUES the loads of a batch's records (nothing in it depends on a loaded value, so the wave does not wait here, with its
-    // stores in flight: loads and stores retire through one in-order counter); finish() derives what the jobs need a batch later, when the
-    // loads have long returned
+    struct Rec { int f; uint32_t hx, hw, o2; uint4 p; };               // (hx: agent row | col << 8 | hold << 16; o2, Ray: the colour of row 2 of the agent's mark)
     auto fetch = [&](int base) {
         Rec r;
-        r.cnt = pace_beside ? __hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const int i = base + lane / FPJ;
         const int id = i * n_waves + wave;
         r.f = -1; r.hx = 0; r.hw = 0; r.o2 = 0;
@@ -1411,20 +1306,12 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                 }
             }
         }
-#ifdef CW_EXP_OLD_FETCH
-        if (src == CW_SRC_CURRENT) r.hx &= 0x00FFFFFFu;
-        else { const uint32_t ar = __umulhi(r.hx, P.div_magic); r.hx = ar | ((r.hx - ar * S) << 8); }
-        if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
-#endif
-        return r;
-    };
-    auto finish = [&](Rec &r) {
-#ifdef CW_EXP_OLD_FETCH
-        return;
-#endif
+        // (derived values here, not a batch later: measured -- with the wait for the loads moved to the next batch's start the sweep keeps up with
+        // 6.8 TB/s instead of 7.2, profiles/r04_clock.txt)
         if (src == CW_SRC_CURRENT) r.hx &= 0x00FFFFFFu;                       // (the menu id)
         else { const uint32_t ar = __umulhi(r.hx, P.div_magic); r.hx = ar | ((r.hx - ar * S) << 8); }      // nothing is held in those states
         if (RASTER != 1) { const uint32_t hold = (r.hx >> 16) & 0xFFu; r.o2 = hold ? rgb_of_code(hold) : 0x00FFFFFFu; }
+        return r;
     };
     Rec nxt = fetch(0);
     // THE CLOCK.  period16 != 0: job k of a wave starts no earlier than t0 + k x period (period16 = the period in 1/16 of a 10-ns tick of the
@@ -1432,11 +1319,10 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     // set rate -- bytes per second = waves x 4 KiB / period -- instead of at whatever rate the waves' instruction streams happen to produce.
     long long t_next16 = ((long long)__builtin_amdgcn_s_memrealtime() << 4) + ((long long)wave * period16) / n_waves;
     for (int base = 0; base < q_mine; base += JPB) {
-        Rec cur = nxt;
+        const Rec cur = nxt;
         if (base + JPB < q_mine) nxt = fetch(base + JPB);
-        finish(cur);
         const int in_batch = min(q_mine - base, JPB);
-        const int pace_now = pace_base + (__builtin_amdgcn_readfirstlane(cur.cnt) >= CW_BESIDE_MIN ? pace_beside : 0);
+        const int pace_now = pace & 0xFF;
         for (int k = 0; k < in_batch; k++) {
             const int f0 = __builtin_amdgcn_readlane(cur.f, FPJ * k);         // the piece's first frame
             if (f0 < 0) continue;                                             // (past the last job)
@@ -1532,34 +1418,9 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     }
 }
 template <int RASTER, int FPJ>
-__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int list_aware, int pace, int period16, int env_lo, int env_n)
+__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int pace, int period16, int env_lo, int env_n)
 {
-    render_pieces<RASTER, FPJ>(P, frames, src, list_aware, pace, period16, env_lo, env_n, (int)gridDim.x);
-}
-#ifdef CW_EXP_LIST_KERNEL
-__global__ __launch_bounds__(256) void cw_list_kernel(CwParams P)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    list_block(P, s_mt, (int)blockIdx.x, (int)gridDim.x, 0);
-}
-#endif
-// The full-frame step's launch: the sweep of the observation array (its last chunk) in the grid's first render_blocks workgroups, the done
-// list's work in the rest (list_block) -- which leave at once when nothing finished on the step and otherwise WAIT, asleep, until every sweeping
-// workgroup has signalled that it is through (done_count[2]): the list's frames must not be painted beside the sweep (see list_block).
-template <int RASTER, int FPJ>
-__global__ __launch_bounds__(256) void cw_render_pieces_step_kernel(CwParams P, int render_blocks, int pace, int period16, int env_lo, int env_n)
-{
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    if ((int)blockIdx.x < render_blocks) {
-        render_pieces<RASTER, FPJ>(P, P.obs, CW_SRC_CURRENT, 1, pace, period16, env_lo, env_n, render_blocks);
-        if (__hip_atomic_load(P.done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // somebody is waiting for the sweep
-            __threadfence();                                     // this workgroup's frames first (an env reset the slow way is repainted by the list's wave)
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(P.done_count + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        list_block(P, s_mt, (int)blockIdx.x - render_blocks, (int)gridDim.x - render_blocks, render_blocks);
-    }
+    render_pieces<RASTER, FPJ>(P, frames, src, pace, period16, env_lo, env_n);
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1764,40 +1625,26 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
     // write path saturates with few store streams and gets slower with more of them in flight
     // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt)
     long long blocks = (jobs + 3) / 4;
-    if (blocks > tn.n_cu) blocks = tn.n_cu;
+    if (blocks > (long long)tn.n_cu * tn.sweep_blocks_per_cu) blocks = (long long)tn.n_cu * tn.sweep_blocks_per_cu;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int);
-typedef void (*CwStepSweepKernel)(CwParams, int, int, int, int, int);
-static CwStepSweepKernel cw_step_sweep_kernel(int raster, int fpj)
-{
-    if (raster == 1) return fpj <= 2 ? cw_render_pieces_step_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_step_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_step_kernel<1, 8> : cw_render_pieces_step_kernel<1, 16>;
-    return fpj <= 2 ? cw_render_pieces_step_kernel<0, 2> : fpj <= 4 ? cw_render_pieces_step_kernel<0, 4> : fpj <= 8 ? cw_render_pieces_step_kernel<0, 8> : cw_render_pieces_step_kernel<0, 16>;
-}
+typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int);
 static CwSweepKernel cw_sweep_kernel(int raster, int fpj)
 {
     if (raster == 1) return fpj <= 2 ? cw_render_pieces_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_kernel<1, 8> : cw_render_pieces_kernel<1, 16>;
     return fpj <= 2 ? cw_render_pieces_kernel<0, 2> : fpj <= 4 ? cw_render_pieces_kernel<0, 4> : fpj <= 8 ? cw_render_pieces_kernel<0, 8> : cw_render_pieces_kernel<0, 16>;
 }
-// one frame array [N][frame_bytes] (16-byte aligned) painted from the envs' current / reset-time / goal states.  list_aware 1: the sweep of a
-// step (its pace follows the done list's length); 2: ... and the done list's work rides on the last chunk's launch (cw_render_pieces_step_kernel)
-static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *frames, int src, int list_aware, hipStream_t st)
+// one frame array [N][frame_bytes] (16-byte aligned) painted from the envs' current / reset-time / goal states
+static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *frames, int src, hipStream_t st)
 {
     int per = 0;
     const int n_chunks = cw_piece_chunks(P, tn, &per);
-    const int pace = tn.piece_pace | (list_aware ? (tn.pace_beside & 15) << 12 : 0);
-    const int fpj = cw_frames_per_job(P.frame_bytes);
+    const CwSweepKernel k = cw_sweep_kernel(P.raster, cw_frames_per_job(P.frame_bytes));
     for (int c = 0; c < n_chunks; c++) {
         const int env_n = min(per, P.n_envs - c * per);
         const long long pieces = ((long long)env_n * P.frame_bytes + CW_PIECE - 1) / CW_PIECE;
-        const int blocks = cw_render_grid(tn, pieces);
-#ifndef CW_EXP_LIST_KERNEL
-        if (list_aware == 2 && c == n_chunks - 1)
-            hipLaunchKernelGGL(cw_step_sweep_kernel(P.raster, fpj), dim3(blocks + tn.n_cu), dim3(256), 0, st, P, blocks, pace, tn.period16, c * per, env_n);
-        else
-#endif
-            hipLaunchKernelGGL(cw_sweep_kernel(P.raster, fpj), dim3(blocks), dim3(256), 0, st, P, frames, src, list_aware ? 1 : 0, pace, tn.period16, c * per, env_n);
+        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.piece_pace, tn.period16, c * per, env_n);
     }
 }
 
@@ -1810,20 +1657,20 @@ static inline int cw_reset_grid(const CwTuning &tn, int jobs)
     return blocks;
 }
 
-// envs per wavefront of the kernels that reset inline (resets are serial within a wave): aim for ~4096 waves
-// (4 per SIMD) -- 64 envs per wave for large batches, down to 8 for small ones
+// envs per wavefront of the kernels that reset inline (an inline reset occupies the whole wave, one finished env at a time -- rare now that
+// finished envs take their look-ahead records): aim for ~1024 waves (one per SIMD) -- 64 envs per wave for large batches, down to 8 for small ones
 static int cw_envs_per_wave(int n)
 {
+    if (const char *f = getenv("CW_EXP_EPW")) return atoi(f);
     int epw = 64;
-    while (epw > 8 && (n + epw - 1) / epw < 4096) epw >>= 1;
+    while (epw > 8 && (n + epw - 1) / epw < 1024) epw >>= 1;
     return epw;
 }
 
 extern "C" {
 
-// One engine step, everything in stream order on `st`.  FULL pixel mode: the step kernel (finished envs take their look-ahead records), the
-// sweep of the observation array, and -- engines that reset by themselves -- the done list's kernel (cw_list_kernel; most steps it finds
-// nothing).  State-only / dirty-cell modes with auto-reset: ONE kernel that steps, takes the records and resets whatever is left inline.
+// One engine step, everything in stream order on `st`: the step kernel (cw_step_fused_kernel for engines that reset by themselves,
+// cw_step_kernel for the others) and, in the FULL pixel mode, the sweep of the observation array.
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode,
                            int auto_reset, hipStream_t st, hipEvent_t *ev /* 6 or null */)
 {
@@ -1831,23 +1678,18 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     const int n = P->n_envs;
     const bool ev_all = ev && obs_mode != 1;                   // (full-frame mode: only the dominant kernel is bracketed -- every event record costs a pipeline bubble)
     if (ev_all) (void)hipEventRecord(ev[0], st);
-    if (auto_reset && obs_mode != 1) {
+    if (auto_reset) {
         const int epw = cw_envs_per_wave(n);
         const int waves = (n + epw - 1) / epw;
         hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
-                           *P, actions, act_dtype, obs_mode == 2 ? 1 : 0, epw);
-        if (ev) for (int k = 1; k < 6; k++) (void)hipEventRecord(ev[k], st);
-        return hipGetLastError();
+                           *P, actions, act_dtype, obs_mode == 2 ? 1 : obs_mode == 1 ? 2 : 0, epw);
+    } else {
+        hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype, obs_mode == 2 ? 1 : 0);
     }
-    hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype,
-                       auto_reset ? 1 : 0, obs_mode == 2 ? 1 : 0);
     if (ev_all) (void)hipEventRecord(ev[1], st);
     if (ev) for (int k = 2; k < 5; k++) (void)hipEventRecord(ev[k], st);
-    if (obs_mode == 1) cw_launch_sweep(*P, tn, P->obs, CW_SRC_CURRENT, auto_reset ? 2 : 0, st);
+    if (obs_mode == 1) cw_launch_sweep(*P, tn, P->obs, CW_SRC_CURRENT, st);
     if (ev) (void)hipEventRecord(ev[5], st);
-#ifdef CW_EXP_LIST_KERNEL
-    if (obs_mode == 1 && auto_reset) hipLaunchKernelGGL(cw_list_kernel, dim3(tn.n_cu), dim3(256), 0, st, *P);
-#endif
     return hipGetLastError();
 }
 
@@ -1871,9 +1713,9 @@ hipError_t cwk_launch_rollout(const CwParams *P, const uint8_t *actions, int T, 
 // (after cw_reset the first two show the same pixels; a restored checkpoint's do not)
 hipError_t cwk_launch_render_restore(const CwParams *P, const CwTuning *T, hipStream_t st)
 {
-    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, 0, st);
-    cw_launch_sweep(*P, *T, P->init_img, CW_SRC_INIT, 0, st);
-    cw_launch_sweep(*P, *T, P->desired_img, CW_SRC_GOAL, 0, st);
+    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, st);
+    cw_launch_sweep(*P, *T, P->init_img, CW_SRC_INIT, st);
+    cw_launch_sweep(*P, *T, P->desired_img, CW_SRC_GOAL, st);
     return hipGetLastError();
 }
 
@@ -1914,10 +1756,20 @@ hipError_t cwk_launch_pool(const CwParams *P, const CwTuning *T, hipStream_t st)
     return hipGetLastError();
 }
 
-// the sweep of the observation array exactly as cw_step issues it (cw_create's choice of the pace times this launch)
-hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, int list_aware, hipStream_t st)
+// the shape of a sweep over one frame array as cw_launch_sweep issues it: launches, waves per launch, jobs (4-KiB pieces) per wave of the first launch
+void cwk_sweep_shape(const CwParams *P, const CwTuning *T, int *n_chunks, int *waves, int *jobs_per_wave)
 {
-    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, list_aware ? 2 : 0, st);
+    int per = 0;
+    *n_chunks = cw_piece_chunks(*P, *T, &per);
+    const long long pieces = ((long long)min(per, P->n_envs) * P->frame_bytes + CW_PIECE - 1) / CW_PIECE;
+    *waves = cw_render_grid(*T, pieces) * (256 / CW_WAVE);
+    *jobs_per_wave = (int)((pieces + *waves - 1) / *waves);
+}
+
+// the sweep of the observation array exactly as cw_step issues it (cw_create's calibration times this launch)
+hipError_t cwk_launch_sweep_calib(const CwParams *P, const CwTuning *T, hipStream_t st)
+{
+    cw_launch_sweep(*P, *T, P->obs, CW_SRC_CURRENT, st);
     return hipGetLastError();
 }
 
@@ -1935,7 +1787,7 @@ hipError_t cwk_launch_idle(hipStream_t st)
 // cw_render / cw_set_state: the envs' current frames into any array
 hipError_t cwk_launch_render_ext(const CwParams *P, const CwTuning *T, uint8_t *out, hipStream_t st)
 {
-    if (((uintptr_t)out & 15u) == 0) cw_launch_sweep(*P, *T, out, CW_SRC_CURRENT, 0, st);
+    if (((uintptr_t)out & 15u) == 0) cw_launch_sweep(*P, *T, out, CW_SRC_CURRENT, st);
     else hipLaunchKernelGGL(cw_render_frames_kernel, dim3(cw_render_grid(*T, P->n_envs)), dim3(256), 0, st, *P, out);   // (the sweep's 16-byte stores want an aligned array)
     return hipGetLastError();
 }

@@ -42,9 +42,9 @@ struct CwMenuDev {
 // cw_create override them for experiments).
 struct CwTuning {
     int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
-    int piece_pace = 2;             // the sweep's pace: eighths of an s_sleep(1) per 1-KiB store (cw_create checks the neighbours on the engine's batch)
-    int period16 = 0;               // the sweep's CLOCK: a wave's jobs start one period apart; in 1/16 of a 10-ns tick (0: unclocked)
-    int pace_beside = 1;            // ... and QUARTERS more on steps on which >= 32 envs finished (cw_step tunes the number online)
+    int period16 = 0;               // the sweep's CLOCK: a wave's jobs (4-KiB pieces) start one period apart; in 1/16 of a 10-ns tick of the 100-MHz clock (0: unclocked)
+    int piece_pace = 0;             // ... and eighths of an s_sleep(1) per 1-KiB store inside a job
+    int sweep_blocks_per_cu = 1;    // workgroups (4 waves each) of a sweep per CU
     int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
                                     // 131 072 envs at 21x21 (0: one launch whatever the batch)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
@@ -87,8 +87,6 @@ struct CwParams {
     uint8_t *desired_img;
     uint8_t *init_img;
     uint8_t *terminal_img;   // or null
-    uint4 *term_pos;         // [N] keep_terminal_obs only (else null): slot positions / (hdr.x, hdr.w) of the episode's LAST state, saved by the
-    uint2 *term_hx;          //     step kernel before the env is reset in place; the terminal frame is painted from them
     // LOOK-AHEAD: the outcome of every env's NEXT reset(), computed ahead of time.  Only reset() draws from an env's RNG stream, so the next
     // episode's placement, goal state and task set are known as soon as the previous reset has been taken: the refill kernel runs them ahead in
     // bulk, off the per-step path, and a finished env just takes the record over inside the step kernel (a POP: three 16-byte loads).  An env
@@ -100,9 +98,6 @@ struct CwParams {
     int32_t *refill_list;    // [N] envs whose record was taken since the last refill (each at most once)
     int32_t *refill_count;   // [2] entries, release ticket
     int32_t lookahead;       // 0: no records are kept (engines without auto-reset, host-mapped engines, CW_TUNE_LOOKAHEAD=0)
-    // done-list compaction: done_count[0] = entries, [1] = release ticket (cw_kernels.hip)
-    int32_t *done_list;      // [N]
-    int32_t *done_count;     // [4]: + [2] = sweeping workgroups of the step's launch that are through (the list's workgroups wait for them)
     unsigned long long *counters; // [4]
     const CwMenuDev *menus;
     // constants

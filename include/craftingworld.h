@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {piece_pace, pace_beside, pace_beside_tuned, guard_state, guard_trials, lookahead}; one painter, look-ahead records */
+#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, piece_pace, lookahead, reserved}; one painter, look-ahead records */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -251,13 +251,11 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
  * (the render alone), the step kernel's name in CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
-/* What the engine's tuning holds right now (full-frame mode): the sweep's pace in eighths of a sleep per 1-KiB store, the
- * extra quarter-sleeps on steps on which >= 32 envs finished and whether cw_step tunes that number online (1) or it is fixed (0), the regime
- * guard of an unpaced sweep (-1 off, 0 watching, 1 trial of the paced sweep under way, 2 the paced sweep was kept, 3 opening survey) and the
- * trials it has run, and whether the engine keeps look-ahead records (cw_config.auto_reset, device-resident outputs).  Only performance
- * depends on any of it. */
+/* What the engine's tuning holds (full-frame mode): the period of the sweep's clock -- a wave starts a 4-KiB piece every
+ * period16 / 16 ticks of the 100-MHz clock, 0: unclocked --, the sleeps inside a job in eighths per 1-KiB store, and whether the engine
+ * keeps look-ahead records (cw_config.auto_reset, device-resident outputs).  Only performance depends on any of it. */
 typedef struct cw_tuner_state {
-    int32_t piece_pace, pace_beside, pace_beside_tuned, guard_state, guard_trials, lookahead;
+    int32_t period16, piece_pace, lookahead, reserved;
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 

@@ -270,71 +270,3 @@ def test_batch_space_adds_a_leading_axis():
     assert batch_space(Discrete(6), 5).nvec.tolist() == [6] * 5
 
 
-def test_regime_guard_of_the_unpaced_piece_sweep():
-    """The decision of cw_step's regime guard (cwh_regime_guard, cw_engine.cpp: adapt_tick) on sequences of window levels (ms per step) like
-    the ones measured on MI355X (profiles/r03_pieces.txt), each window fed with the pace it was launched with -- here the host is `lag` windows
-    ahead of the GPU, as it is in a real run: the opening survey keeps the unpaced sweep where it is as fast, the paced one where the unpaced
-    sweep is in the slower regime from the start; a steady run never leaves the unpaced sweep; the saturated regime (+17 %) is answered by a
-    trial of the paced sweep, which stays when it is 3 % faster; episode phases that spread out (+12 %, and the paced sweep no better) end the
-    trial, become the new normal, and the next trial has to wait."""
-    import ctypes as C
-    from gym_craftingworld_amd import _lib
-    lib = _lib.load()
-    rng = np.random.RandomState(5)
-
-    class Run:
-        """levels(pace) -> ms; the guard's answer takes effect `lag` windows after the window it was computed on"""
-        def __init__(self, lag, survey=True):
-            self.s = (C.c_float * 41)()
-            if survey:
-                self.s[2] = 3.0
-            self.lag, self.w, self.want, self.launched = lag, 0, 0, []
-            self.paces = []
-
-        def step(self, level_of):
-            self.launched.append(self.want)
-            if len(self.launched) > self.lag:
-                ran = self.launched[len(self.launched) - 1 - self.lag]
-                prev = self.launched[len(self.launched) - 2 - self.lag] if len(self.launched) - 2 - self.lag >= 0 else ran
-                if ran == prev:                                   # (the first window after a change settles: not fed)
-                    ms = level_of(ran) * (1 + 0.004 * rng.randn())
-                    self.want = lib.cwh_regime_guard(self.s, C.c_float(ms), self.w, ran)
-            self.w += 1
-            self.paces.append(self.want)
-
-        def run(self, n, level_of):
-            for _ in range(n):
-                self.step(level_of)
-            return self
-
-    good, bad, paced, spread = 0.2181, 0.2560, 0.2250, 0.2462
-    for lag in (0, 3, 40):
-        # a healthy build: the survey keeps the unpaced sweep; a steady run never leaves it; 6 % above the best level is not the other regime
-        r = Run(lag).run(400, lambda p: paced if p else good)
-        assert r.s[2] == 0.0 and r.want == 0 and abs(r.s[0] - good) < 0.003, (lag, list(r.s)[:8])
-        r.run(2000, lambda p: paced if p else good)
-        r.run(300, lambda p: paced if p else good * 1.06)
-        assert r.s[2] == 0.0 and r.want == 0 and set(r.paces[400:]) == {0}, lag
-        # ... the saturated regime later on: a trial, and the paced sweep (12 % faster than what was before it) stays for good
-        r.run(400, lambda p: paced if p else bad)
-        assert r.s[2] == 2.0 and r.want == 1, (lag, list(r.s)[:8])
-        r.run(100, lambda p: paced if p else good)
-        assert r.want == 1
-        # a build / box whose unpaced sweep is in the slower regime from its first step: the survey keeps the paced sweep
-        r = Run(lag).run(400, lambda p: paced if p else bad)
-        assert r.s[2] == 2.0 and r.want == 1, lag
-        # phases that spread out (the paced sweep no better): a trial, back to unpaced, the new level is the normal one, no further trial at that level
-        r = Run(lag).run(500, lambda p: paced if p else good)
-        r.run(400, lambda p: spread * 0.995 if p else spread)
-        assert r.s[2] == 0.0 and r.want == 0 and abs(r.s[0] - spread) < 0.003 and r.s[7] == 256.0, (lag, list(r.s)[:8])
-        n_paced = sum(r.paces[500:])
-        assert 30 <= n_paced <= 34 + lag, (lag, n_paced)
-        r.run(3000, lambda p: spread * 0.995 if p else spread)
-        assert r.want == 0 and sum(r.paces[900:]) == 0
-    # the hold-off: a failed trial at window ~600, the next one not before 256 windows later even if the level tips over at once
-    r = Run(0).run(500, lambda p: paced if p else good)
-    r.run(100, lambda p: spread if p else spread)
-    t_fail = max(i for i, p in enumerate(r.paces) if p) + 1
-    r.run(600, lambda p: spread * 1.17 * 0.9 if p else spread * 1.17)
-    second = [i for i, p in enumerate(r.paces) if p and i > t_fail]
-    assert second and second[0] >= t_fail - 1 + 256 and r.s[2] == 2.0                # (... and that trial, 10 % faster, is kept)
