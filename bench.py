@@ -210,11 +210,9 @@ def main():
     ap.add_argument('--mixed-menus', action='store_true',
                     help='BASELINE configs[3] shape: env i uses ordered task list i mod 8 of a fixed menu of eight (heterogeneous selected_tasks / '
                          'number_of_tasks / stacking / reward_style per env)')
-    ap.add_argument('--prewarm-steps', type=int, default=320,
+    ap.add_argument('--prewarm-steps', type=int, default=100,
                     help='untimed steps before the W warm-up steps (0: none): a card that idled through set-up runs its first ~100 launches 3-5 %% '
-                         'slower, and the engine\'s online tuner opens with surveys scheduled by step number (cw_engine.cpp: adapt_tick) -- the regime '
-                         'guard\'s paced windows against unpaced ones over steps 128-255, the cell-row sweep\'s eight placements over 256 steps; '
-                         'reported as prewarm_steps / warmup_total')
+                         'slower; reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
     ap.add_argument('--shard-check', type=int, default=0, metavar='T',
@@ -458,16 +456,14 @@ def main():
                           'figures from a second pass with one event per step (rank 0)'}
 
     # ... and the same window with the episode phases spread out (ray.py:367: episodes end at different steps once a policy succeeds;
-    # about N/max_steps envs are reset beside every sweep): the steady state of a long run, in the same process.  The engine's tuners
-    # (extra sleeps beside resets, loop placement) get an untimed stretch to settle on the new regime first.
+    # about N/max_steps envs finish on every step): the steady state of a long run, in the same process.
     window_desync = None
     if not args.quick and args.obs_mode == 'pixels' and not args.desync:
         KW_ = 2 * args.max_steps
         env.set_state(step_num=((np.arange(lo, hi) * 7) % args.max_steps).astype(np.int32))
-        for chunk in range(3):                           # 3 x 2*max_steps untimed steps, a host sync between them (the tuners read completed windows)
-            run(KW_, t_next)
-            t_next += KW_
-            torch.cuda.synchronize(dev)
+        run(KW_, t_next)                                 # 2*max_steps untimed steps: every env has finished at its own phase, the look-ahead refills are in their rhythm
+        t_next += KW_
+        torch.cuda.synchronize(dev)
         ep0 = int(env.counters[1].item())
         wd_elapsed = timed_region(KW_, t_next)
         wd_episodes = int(env.counters[1].item()) - ep0
@@ -489,34 +485,74 @@ def main():
                                       'achieved': wd_bytes / (wd_ms * 1e-3) / 1e9 if wd_ms > 0 else None,
                                       'frac': wd_bytes / (wd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if wd_ms > 0 else None,
                                       'algorithmic_bytes_per_launch': wd_bytes},
-                         'note': 'same process, after metric_window: step_num := 7 e mod max_steps, %d untimed steps for the online tuners, '
+                         'note': 'same process, after metric_window: step_num := 7 e mod max_steps, %d untimed steps, '
                                  'then the window without events (value, max over ranks) and once more with the library\'s events '
-                                 '(roofline, rank 0)' % (3 * KW_)}
+                                 '(roofline, rank 0)' % KW_}
 
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
-    # step (the reference's own render_edit strategy), state-only has no frames at all.
-    other = {}
-    if rank == 0 and world == 1 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
-        env.close()
-        for mode in ('pixels_dirty', 'state'):
-            e2 = CraftingWorldVecEnv(N, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo)
+    # step (the reference's own render_edit strategy), state-only has no frames at all.  Both are launch-bound: `value` is the per-step
+    # Python loop (a policy in the loop), beside it the same steps through cw_step_many (one library call) and as a HIP graph of 64 steps
+    # that re-reads an action ring (VecEnv.capture_steps): the card's own pace.
+    def side_modes(n_envs, modes, acts):
+        out_ = {}
+        for mode in modes:
+            e2 = CraftingWorldVecEnv(n_envs, size=(args.size, args.size), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo)
             e2.reset()
             k2 = 2 * args.max_steps
             for t in range(20):
-                e2.step_async(actions[t % rows])
+                e2.step_async(acts[t % rows])
             torch.cuda.synchronize(dev)
             dts = []
             for rep in range(3):                         # three times back to back: box / run variance of the launch-bound modes in one record
                 tt = time.perf_counter()
                 for t in range(k2):
-                    e2.step_async(actions[(20 + rep * k2 + t) % rows])
+                    e2.step_async(acts[(20 + rep * k2 + t) % rows])
                 torch.cuda.synchronize(dev)
                 dts.append(time.perf_counter() - tt)
             dt = dts[0]
-            other[mode] = {'value': N * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1,
-                           'repeats': {'n': 3, 'value': [N * k2 / x for x in dts], 'us_per_step': [x / k2 * 1e6 for x in dts]}}
+            rec = {'value': n_envs * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1, 'launch': 'eager, one cw_step per Python call',
+                   'repeats': {'n': 3, 'value': [n_envs * k2 / x for x in dts], 'us_per_step': [x / k2 * 1e6 for x in dts]}}
+            block = acts[:k2].contiguous()
+            e2.step_many(block)
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter()
+            for rep in range(3):
+                e2.step_many(block)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - tt) / 3
+            rec['step_many'] = {'value': n_envs * k2 / dt, 'us_per_step': dt / k2 * 1e6, 'launch': 'cw_step_many: %d steps per library call' % k2}
+            ring = acts[:64].clone()
+            g = e2.capture_steps(ring)
+            reps = max(1, k2 // 64)
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter()
+            for rep in range(3 * reps):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - tt) / (3 * reps * 64)
+            rec['graph_replay'] = {'value': n_envs / dt, 'us_per_step': dt * 1e6, 'launch': 'HIP graph of 64 steps reading an action ring (VecEnv.capture_steps)'}
+            if mode == 'state':
+                e2.rollout(block, record=False)
+                torch.cuda.synchronize(dev)
+                tt = time.perf_counter()
+                e2.rollout(block, record=False)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - tt
+                rec['rollout'] = {'value': n_envs * k2 / dt, 'us_per_step': dt / k2 * 1e6, 'launch': 'cw_rollout: %d steps in one persistent kernel' % k2}
+            out_[mode] = rec
             e2.close()
+        return out_
+
+    other, config1 = {}, None
+    if rank == 0 and world == 1 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
+        env.close()
+        other = side_modes(N, ('pixels_dirty', 'state'), actions)
+        # BASELINE configs[1]: 4 096 envs, default grid, state-only obs, random actions
+        config1 = side_modes(4096, ('state',), actions[:, :4096].contiguous())['state']
+        config1['workload'] = 'BASELINE configs[1]: 4096 envs, %dx%d, state-only obs, uniform random actions' % (args.size, args.size)
 
     if rank == 0:
         total_steps = float(N) * world * K
@@ -540,14 +576,19 @@ def main():
         # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)
         traffic = traffic_source = None
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
-        if pmcs and args.obs_mode == 'pixels' and N == 65536 and S == 21:
+        mine = {'envs_per_gpu': N, 'size': S, 'obs_mode': args.obs_mode, 'raster': args.raster,
+                'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start',
+                'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)'}
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic*.json')), reverse=True):      # the newest committed summary of THIS shape
             try:
-                traffic = json.load(open(pmcs[-1])).get('hbm_bytes_per_launch')
-                traffic_source = ('not measured in this run: quoted from %s (separate rocprofv3 --pmc passes of the same command, '
-                                  'tools/profile_pmc.sh)' % os.path.relpath(pmcs[-1], ROOT))
+                pj = json.load(open(f))
             except Exception:  # noqa: BLE001
-                traffic = None
+                continue
+            if pj.get('shape') == mine and pj.get('hbm_bytes_per_launch'):
+                traffic = pj['hbm_bytes_per_launch'] * pj.get('launches_per_sweep', 1)      # (a sweep of several chunk launches: the bracketed region holds them all)
+                traffic_source = ('not measured in this run: quoted from %s (separate rocprofv3 --pmc passes of the same shape, '
+                                  'tools/profile_pmc.sh)' % os.path.relpath(f, ROOT))
+                break
         # the practical ceiling beside the spec peak: a plain device fill of the same number of bytes,
         # timed on this box right now (torch's vectorised fill kernel, median of 9)
         fill_gbs = None
@@ -570,10 +611,16 @@ def main():
                                    'actions, max_steps=%d' % (N, S, S, {'pixels': 'full-frame 4x4-cell uint8 pixel',
                                                                         'pixels_dirty': 'dirty-cell-repaint pixel',
                                                                         'state': 'state-only'}[args.obs_mode], args.max_steps),
-                       'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode,
+                       'envs_per_gpu': N, 'size': S, 'max_steps': args.max_steps, 'obs_mode': args.obs_mode, 'raster': args.raster,
                        'sharding': 'contiguous env ranges per rank, no data-path collective',
                        'task_lists': 'eight ordered menus, env i uses menu i mod 8' if args.mixed_menus else 'one (all nine tasks)',
-                       'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start'},
+                       'launch': launch_desc, 'episode_phases': 'spread out (--desync)' if args.desync else 'synchronized start',
+                       'timed_region': ('placed between two of the steps on which every env times out at once (K < max_steps: %d untimed steps '
+                                        'before the W warm-up steps instead of %d); metric_window holds them in their true proportion'
+                                        % (prewarm_steps, max(args.prewarm_steps, 0))) if prewarm_steps != max(args.prewarm_steps, 0) else
+                                       'the first K steps after the warm-up, wherever the all-env time-out steps fall'},
+            # the figures to quote: the 2*max_steps window with both all-env time-out steps inside, and the same with the episode phases spread out
+            'quote': {'metric_window': window['value'] if window else None, 'metric_window_desync': window_desync['value'] if window_desync else None},
             'roofline': {'bound': 'hbm', 'kernel': dominant,
                          # (a rocprofv3 trace lists the sweep by raster and frames per job: cw_render_pieces_kernel<raster, 2> for frames of 4 KiB and more)
                          'kernel_in_trace': (('%s<%d, %d>' % (dominant, 1 if args.raster == 'alt' else 0, frames_per_job(frame))) if dominant.startswith('cw_render_pieces') else dominant),
@@ -603,6 +650,7 @@ def main():
             'metric_window_desync': window_desync,
             'dist_backend': backend_used,
             'other_obs_modes_1gpu': other,
+            'config1_state_4096': config1,
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (task contract)
             out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)

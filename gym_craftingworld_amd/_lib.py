@@ -75,6 +75,7 @@ ABI = {
     'cw_generate_fixed_states': (C.c_int, [_VP, _VP]),
     'cw_reset': (C.c_int, [_VP, _VP]),
     'cw_step': (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    'cw_step_many': (C.c_int, [_VP, _VP, C.c_int, C.c_int32, _VP]),
     'cw_rollout': (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP]),
     'cw_render': (C.c_int, [_VP, _VP, _VP]),
     'cw_render_onehot': (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP]),

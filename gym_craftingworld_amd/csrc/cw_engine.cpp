@@ -645,6 +645,24 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     return CW_OK;
 }
 
+// n_steps consecutive steps from an action array [n_steps][N]: what a loop over cw_step enqueues, without the caller's per-step cost (a Python
+// loop spends more per step than a state-only step takes on the card).  Capturable into a HIP graph as one piece; inside a capture the
+// look-ahead refill rides at the head of the sequence too, so that a replayed graph of fewer than CW_LA_PERIOD steps still refills.
+int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_steps, cw_stream_t stream)
+{
+    if (!e || !actions) return fail(CW_ERR_INVALID, "cw_step_many: null argument");
+    if (n_steps < 1) return fail(CW_ERR_INVALID, "cw_step_many: n_steps must be >= 1");
+    if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step_many: bad action dtype %d", action_dtype);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (e->P.lookahead && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = CW_LA_PERIOD;
+    const size_t row = (size_t)e->n * (action_dtype == CW_ACT_I32 ? 4 : action_dtype == CW_ACT_I64 ? 8 : 1);
+    for (int32_t t = 0; t < n_steps; t++) {
+        const int rc = cw_step(e, (const unsigned char *)actions + (size_t)t * row, action_dtype, stream);
+        if (rc != CW_OK) return rc;
+    }
+    return CW_OK;
+}
+
 // One step of the single-env loop WITHOUT a kernel launch: ring the resident kernel's doorbell, spin on its answer (cw_kernels.hip:
 // cw_resident_kernel).  The kernel is (re)launched on demand -- the first call, after it idled out (2 ms without a request), after its
 // time slice (200 ms), after any other entry point parked it -- and a request that raced with its exit is served by the next instance:

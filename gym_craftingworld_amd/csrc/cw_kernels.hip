@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
     uint4 h = P.hdr[e];
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
-    const CwStepOut o = step_env(P, h, sp, a, [&]() { return P.init_pos[e]; });
+    const uint4 ip = P.init_pos[e];                  // (asked for with the rest: a second memory round trip only for lanes that hold something costs the wave the same)
+    const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
     const bool done = live && o.done;
     if (live) {
         P.reward[env] = o.reward;

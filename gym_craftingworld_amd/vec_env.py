@@ -360,6 +360,33 @@ class CraftingWorldVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
+    def step_many(self, actions):
+        """K consecutive steps from a device tensor `actions` [K, N] (uint8 / int32 / int64): exactly what K calls of step_async enqueue, in ONE
+        library call -- a Python loop costs more per step than a state-only step takes on the card.  Nothing is returned: read the usual
+        views (reward, done, the observation tensors: the last step's) afterwards.  Auto-reset as in step()."""
+        if not (type(actions) is torch.Tensor and actions.dtype in _ACT_DTYPES and actions.device == self.device and actions.is_contiguous()
+                and actions.dim() == 2 and actions.shape[1] == self.num_envs):
+            raise ValueError('actions must be a contiguous [K, num_envs] tensor of dtype uint8 / int32 / int64 on %s' % (self.device,))
+        self._actions_keepalive = actions
+        L.check(self._lib.cw_step_many(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], int(actions.shape[0]), self._stream()),
+                'cw_step_many')
+
+    def capture_steps(self, actions):
+        """-> a torch.cuda.CUDAGraph that takes K = actions.shape[0] steps per replay(), reading row t of the device tensor `actions` [K, N] on
+        step t: fill the tensor IN PLACE (the ring a policy or an action sampler writes into), call graph.replay(), read the views.  One graph
+        launch per K steps instead of K library calls: the way to run the launch-bound modes (state-only, dirty-cell frames) at the card's pace
+        rather than the host's.  The envs' episode bookkeeping needs nothing from the host, so replays can be queued back to back."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                    # torch's capture warm-up protocol: the same calls once, eagerly, on a side stream
+            self.step_many(actions)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step_many(actions)
+        return graph
+
     def rollout(self, actions, record=True):
         """T consecutive steps (auto-reset included) in ONE persistent kernel launch, for action streams
         known up front: actions uint8 [T, N] on the device.  Bit-identical to T calls of step().

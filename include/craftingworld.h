@@ -159,13 +159,16 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
 /* --- step(action) for every env (ray.py:301-378) + auto-reset of finished envs --------------
  * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
  * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
- * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues, in CW_OBS_PIXELS_FULL: step kernel,
- * then ONE launch whose first workgroups render every env that goes on and whose last workgroups reset the finished envs
- * (ballot-compacted done list) and paint their three frames (keep_terminal_obs engines and grids wider than 64 cells: the same
- * two parts as two kernels, the resets on an engine-owned stream that forks from and joins back into `stream`); in the other
- * modes one kernel that steps and resets inline.
+ * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues the step kernel -- engines with auto_reset: finished envs take
+ * over the record of their next episode, computed ahead of time by a refill kernel that rides on every 16th call; an env that finishes twice
+ * between two refills is reset on the spot -- and, in CW_OBS_PIXELS_FULL, the sweep that paints the observation array.
  * With cw_config.host_outputs `actions` may be cw_buffer_table.host_actions. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
+
+/* --- n_steps consecutive step()s from a DEVICE action array [n_steps][N] (dtype as cw_step): exactly what n_steps calls of cw_step enqueue,
+ * in one call (a host loop in Python costs more per call than a state-only step takes on the card).  The frames and outputs left behind are
+ * the last step's.  Capturable into a HIP graph as one piece (a replay re-reads the action array: refill it in place between replays). */
+int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_steps, cw_stream_t stream);
 
 /* --- n_steps consecutive step()s (+ auto-reset) for every env in ONE persistent kernel launch --
  * For scripted / random action streams known up front (BASELINE config 2 style): actions is a DEVICE

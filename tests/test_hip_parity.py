@@ -413,9 +413,10 @@ def test_single_env_facade_matches_golden():
 
 @pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty', 'state'])
 def test_step_captured_in_hip_graph(obs_mode):
-    """One cw_step is a fixed launch sequence (no host-side state in kernel arguments, fork/join of
-    the side stream included), so it can be captured into a HIP graph and replayed: the replayed
-    env must stay bit-identical to an eagerly stepped twin."""
+    """One cw_step is a fixed launch sequence (no host-side state in kernel arguments), so it can be captured into a HIP graph and
+    replayed: the replayed env must stay bit-identical to an eagerly stepped twin.  (A graph of ONE step carries the look-ahead refill
+    only if it was captured on a 16th step: here it never refills and finished envs are reset on the spot -- same results; capture_steps /
+    cw_step_many is the way to capture.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     N, T, kw = 2048, 90, dict(size=(7, 7), max_steps=25)
     keys, pos = _np_states(N, 99)
@@ -450,6 +451,49 @@ def test_step_captured_in_hip_graph(obs_mode):
         for k in ('observation', 'desired_goal', 'init_observation'):
             assert torch.equal(eager._observation()[k], graphed._observation()[k]), k
     assert int(eager.counters[1].item()) == int(graphed.counters[1].item()) > 0
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode,K', [('state', 5), ('state', 48), ('pixels_dirty', 7), ('pixels', 20)])
+def test_step_many_and_captured_graphs_equal_stepping(obs_mode, K):
+    """VecEnv.step_many (cw_step_many: K steps from an action array in one library call) and VecEnv.capture_steps (the same K steps as a HIP
+    graph that re-reads the action ring on every replay) against an eagerly stepped twin: rewards and dones of every K-th step, and at the end
+    state, frames, counters and random streams.  Episodes of 25 steps: finished envs take look-ahead records and the refill kernel rides
+    inside the sequences (K = 5 < the refill period: a captured graph carries its own)."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, rounds, kw = 3000, 8, dict(size=(7, 7), max_steps=25, seed=5)
+    envs = [CraftingWorldVecEnv(N, obs_mode=obs_mode, **kw) for _ in range(3)]
+    for e in envs:
+        e.reset()
+    eager, many, graphed = envs
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    ring = torch.zeros((K, N), dtype=torch.uint8, device='cuda')
+    graph = graphed.capture_steps(ring)                      # (the warm-up pass inside stepped `graphed` K times with zeros ...)
+    zeros = torch.zeros((K, N), dtype=torch.uint8, device='cuda')
+    many.step_many(zeros)                                    # (... so the twins take the same K steps)
+    for t in range(K):
+        eager.step(zeros[t])
+    for r_ in range(rounds):
+        acts = torch.randint(0, 6, (K, N), device='cuda', dtype=torch.uint8, generator=gen)
+        ring.copy_(acts)
+        graph.replay()
+        many.step_many(acts)
+        for t in range(K):
+            eager.step(acts[t])
+        for e in (many, graphed):
+            assert torch.equal(e.reward, eager.reward) and torch.equal(e.done, eager.done), (r_, e is many)
+    for e in (many, graphed):
+        assert torch.equal(e.hdr, eager.hdr) and torch.equal(e.slot_pos, eager.slot_pos) and torch.equal(e.counters, eager.counters)
+        if obs_mode != 'state':
+            for k in ('observation', 'desired_goal', 'init_observation'):
+                assert torch.equal(e._observation()[k], eager._observation()[k]), k
+    assert int(eager.counters[1].item()) > N
+    ke, pe = eager.get_rng_states()
+    for e in (many, graphed):
+        k2, p2 = e.get_rng_states()
+        assert np.array_equal(k2, ke) and np.array_equal(p2, pe)
     for e in envs:
         e.close()
 
