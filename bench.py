@@ -265,27 +265,18 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # The default group is gloo (CPU, rendezvous over MASTER_ADDR:MASTER_PORT): it carries the control plane -- above all the agreement
         # on whether RCCL works.  RCCL (backend "nccl") is a second group for the two timing collectives; no data-path collective exists.
-        # Every rank tries one all-reduce on it, then all ranks MIN-reduce an "ok" flag over gloo: either everybody uses RCCL or nobody
-        # does, whatever subset of ranks saw the failure (a rank whose peers never join waits out the 60-s group timeout first).
+        # sharding.agree_on_rccl: every rank publishes its status over gloo after creating the group and again after one all-reduce on it --
+        # everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  (A rank whose all-reduce throws while its peers block in
+        # theirs: they wait out the 60-s group timeout; with torch's asynchronous error handling the watchdog would abort them instead of raising.)
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
         dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         backend_used = args.dist_backend
         if args.dist_backend == 'nccl':
-            ok, why = 1, ''
-            try:
-                timing_group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=60))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=timing_group)
-                torch.cuda.synchronize(dev)
-                ok = int(probe.item() == world)
-            except Exception as exc:  # noqa: BLE001
-                ok, why = 0, '%s: %s' % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '')
-                sys.stderr.write('[bench] rank %d: RCCL group failed (%s)\n' % (rank, why))
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) != 1:
-                timing_group = None
+            from gym_craftingworld_amd.sharding import agree_on_rccl
+            timing_group, why = agree_on_rccl(dev, log=lambda m: sys.stderr.write('[bench] %s\n' % m))
+            if timing_group is None:
                 args.dist_backend = 'gloo'
-                backend_used = 'gloo (RCCL group failed on at least one rank%s)' % ((': ' + why) if why else '')
+                backend_used = 'gloo (RCCL group failed on at least one rank: %s)' % why
 
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from gym_craftingworld_amd.sharding import gather_over_ranks, max_over_ranks, shard_range

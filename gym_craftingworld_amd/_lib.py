@@ -61,7 +61,7 @@ class cw_profile(C.Structure):
 
 
 class cw_tuner_state(C.Structure):
-    _fields_ = [('period16', C.c_int32), ('piece_pace', C.c_int32), ('lookahead', C.c_int32), ('reserved', C.c_int32)]
+    _fields_ = [('period16', C.c_int32), ('piece_pace', C.c_int32), ('lookahead', C.c_int32), ('resident', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)
@@ -144,10 +144,12 @@ def load():
     return lib
 
 
-def check(rc, what):
+def check(rc, what, lib=None):
+    """rc of a library call -> None, ValueError (CW_ERR_INVALID) or CraftingWorldError; `lib`: the library the call went to (a process may hold
+    several builds: the error text is that library's)"""
     if rc == CW_OK:
         return
-    msg = ((_lib or load()).cw_last_error() or b'').decode(errors='replace')
+    msg = ((lib or _lib or load()).cw_last_error() or b'').decode(errors='replace')
     if rc == CW_ERR_INVALID:
         raise ValueError('%s: %s' % (what, msg))
     raise CraftingWorldError('%s failed (%d): %s' % (what, rc, msg))

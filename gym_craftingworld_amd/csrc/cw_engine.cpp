@@ -86,8 +86,9 @@ struct cw_engine {
     hipStream_t res_stream = nullptr;
     bool res_running = false;          // a cw_resident_kernel may be on the card
     uint32_t res_seq = 0;              // last sequence number rung
-    hipStream_t last_stream = nullptr; // the stream of the last cw_reset / cw_step / cw_rollout: a resident kernel starts only after that work
-    bool last_stream_set = false;
+    hipEvent_t last_work = nullptr;    // recorded after the last cw_reset / cw_step / cw_rollout on the caller's stream: a resident kernel starts only after that
+    bool last_work_set = false;        //   work (an event of the engine's own: the caller may destroy its stream any time after cw_synchronize)
+    unsigned long long res_ticks_per_us = 100;   // the device's constant clock (wall_clock64), hipDeviceAttributeWallClockRate
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
     // look-ahead (cw_layout.h): the refill kernel is launched every CW_LA_PERIOD steps, ahead of the step, on the step's stream
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
@@ -489,6 +490,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
             e->host_allocs.push_back(p);
             e->res = (CwResident *)p;
             if (host_alloc(e, &e->P.res_onehot, (size_t)e->ncell * 12) != CW_OK) e->P.res_onehot = nullptr;
+            int khz = 0;                                 // the kernel's idle-out and time slice are counted on the constant clock
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz >= 1000) e->res_ticks_per_us = (unsigned long long)khz / 1000ull;
+            if (hipEventCreateWithFlags(&e->last_work, hipEventDisableTiming) != hipSuccess) {       // (no event: no resident stepper)
+                e->last_work = nullptr;
+                e->res = nullptr;
+            }
         } else {
             if (p) (void)hipHostFree(p);
             e->res_stream = nullptr;                 // (no resident stepper: cw_step_resident reports it)
@@ -517,6 +524,7 @@ int cw_destroy(cw_engine *e)
     (void)hipDeviceSynchronize();
     prof_free(e);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
+    if (e->last_work) (void)hipEventDestroy(e->last_work);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
@@ -621,7 +629,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
         e->la_steps = 0;
     }
     e->has_reset = true;
-    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
+    if (e->res && hipEventRecord(e->last_work, (hipStream_t)stream) == hipSuccess) e->last_work_set = true;
     return CW_OK;
 }
 
@@ -633,7 +641,6 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
-    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
@@ -642,6 +649,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, ev));
     if (ev) e->prof_n++;
+    if (e->res && hipEventRecord(e->last_work, (hipStream_t)stream) == hipSuccess) e->last_work_set = true;
     return CW_OK;
 }
 
@@ -664,7 +672,7 @@ int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_
 }
 
 // One step of the single-env loop WITHOUT a kernel launch: ring the resident kernel's doorbell, spin on its answer (cw_kernels.hip:
-// cw_resident_kernel).  The kernel is (re)launched on demand -- the first call, after it idled out (2 ms without a request), after its
+// cw_resident_kernel).  The kernel is (re)launched on demand -- the first call, after it idled out (0.5 ms without a request), after its
 // time slice (200 ms), after any other entry point parked it -- and a request that raced with its exit is served by the next instance:
 // `ack` says which sequence number was served last, and a new instance starts from there.
 int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
@@ -691,12 +699,13 @@ int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
                 __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
                 return CW_OK;
             }
-            // (the new instance reads the env's records: whatever cw_reset / cw_step enqueued last on the caller's stream comes first)
-            if (e->last_stream_set) { HIP_TRY(hipStreamSynchronize(e->last_stream)); e->last_stream_set = false; }
+            // (the new instance reads the env's records: whatever cw_reset / cw_step enqueued last comes first -- an event of the engine's own,
+            // recorded when that work was enqueued: the caller's stream may be gone by now)
+            if (e->last_work_set) { HIP_TRY(hipStreamWaitEvent(e->res_stream, e->last_work, 0)); e->last_work_set = false; }
             __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
             __atomic_store_n(&R->ack, (seq - 1u) & 0xFFFFFFu, __ATOMIC_RELEASE);
             HIP_TRY(cwk_launch_resident(&e->P, R, (seq - 1u) & 0xFFFFFFu, e->obs_mode == CW_OBS_PIXELS_DIRTY ? 1 : 0,
-                                        200000ull /* 2 ms idle */, 20000000ull /* 200 ms slice */, e->res_stream));
+                                        500ull * e->res_ticks_per_us /* 0.5 ms idle */, 200000ull * e->res_ticks_per_us /* 200 ms slice */, e->res_stream));
             e->res_running = true;
             continue;
         }
@@ -705,8 +714,18 @@ int cw_step_resident(cw_engine *e, int32_t action, int32_t want_onehot)
             struct timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) {
-                (void)resident_park(e);
-                return fail(CW_ERR_HIP, "cw_step_resident: no answer from the resident kernel within 5 s (parked)");
+                // WITHDRAW the request before parking: the kernel serves a pending sequence number before it honours the stop bit, so the doorbell
+                // goes back to the last number it answered, with the stop bit -- and if it did serve the step meanwhile, that is the answer
+                const uint32_t acked = __atomic_load_n(&R->ack, __ATOMIC_ACQUIRE);
+                __atomic_store_n(&R->bell, (1ull << 32) | ((unsigned long long)acked << 8), __ATOMIC_RELEASE);
+                const hipError_t he = hipStreamSynchronize(e->res_stream);
+                e->res_running = false;
+                const uint32_t now_acked = __atomic_load_n(&R->ack, __ATOMIC_ACQUIRE);
+                __atomic_store_n(&R->bell, (unsigned long long)now_acked << 8, __ATOMIC_RELEASE);
+                __atomic_store_n(&R->exited, 0u, __ATOMIC_RELEASE);
+                e->res_seq = now_acked;
+                if (he == hipSuccess && now_acked == seq) return CW_OK;
+                return fail(CW_ERR_HIP, "cw_step_resident: no answer from the resident kernel within 5 s (request withdrawn, kernel parked: the step was not taken)");
             }
         }
     }
@@ -730,7 +749,6 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
-    e->last_stream = (hipStream_t)stream; e->last_stream_set = true;
     if (e->P.lookahead) {
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -857,7 +875,7 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
     out->period16 = e->tune.period16;
     out->piece_pace = e->tune.piece_pace;
     out->lookahead = e->P.lookahead;
-    out->reserved = 0;
+    out->resident = e->res ? 1 : 0;
     return CW_OK;
 }
 

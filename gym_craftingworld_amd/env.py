@@ -77,9 +77,10 @@ class CraftingWorldEnv:
         self._act = v._host_actions
         self._act_p = C.c_void_p(self._act.ctypes.data)
         # step() without a kernel launch: a resident single-wave kernel polls a doorbell in pinned host memory (cw_step_resident; it leaves by
-        # itself after 2 ms without a request and is parked by every other call).  resident=False (or CW_RESIDENT=0) keeps "launch + stream sync".
+        # itself after 0.5 ms without a request and is parked by every other call).  resident=False (or CW_RESIDENT=0) keeps "launch + stream sync".
         import os
         self._resident = (os.environ.get('CW_RESIDENT', '1') != '0') if resident is None else bool(resident)
+        self._resident = self._resident and bool(v.tuner_state()['resident'])     # (no pinned control block / stream at cw_create: the launch path)
         self._step_resident = self._lib.cw_step_resident
         self._want_onehot = 0                       # (the one-hot class: the resident step also leaves obs_one_hot in pinned host memory)
         self.store_gif, self.render_save_rate = False, render_save_rate            # ray.py:135-136

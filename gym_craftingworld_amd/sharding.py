@@ -45,3 +45,45 @@ def sum_over_ranks(values, device='cpu'):
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
+
+
+def agree_on_rccl(device, timeout_s=60, new_group=None, log=None):
+    """The timing collectives of a multi-rank run go over RCCL (backend "nccl") -- a second process group beside the default gloo one -- if it works
+    on EVERY rank, over gloo otherwise: either everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  Two rounds, each closed
+    by a MIN-reduce of the ranks' "ok" flags over gloo BEFORE anybody depends on the other ranks having got as far: (1) creating the group (nothing is
+    sent yet: a rank that fails here keeps its peers out of RCCL's first collective, where they would otherwise wait out the group's timeout);
+    (2) one all-reduce on it.  A group that failed is destroyed.  -> (group or None, None or the reason as text).  Needs the default (gloo) group."""
+    import datetime
+    new_group = new_group or dist.new_group
+    world = dist.get_world_size()
+
+    def agreed(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    group, why = None, ''
+    try:
+        group = new_group(backend='nccl', timeout=datetime.timedelta(seconds=timeout_s))
+    except Exception as exc:  # noqa: BLE001
+        why = 'creating the group: %s: %s' % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '')
+    if agreed(group is not None):
+        try:
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe, group=group)
+            if getattr(probe, 'is_cuda', False):
+                torch.cuda.synchronize(device)
+            if int(probe.item()) != world:
+                why = 'the probe all-reduce returned %r, not the world size' % probe.item()
+        except Exception as exc:  # noqa: BLE001
+            why = 'the probe all-reduce: %s: %s' % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '')
+        if agreed(not why):
+            return group, None
+    if why and log:
+        log('RCCL group failed on rank %d (%s)' % (dist.get_rank(), why))
+    if group is not None:
+        try:
+            dist.destroy_process_group(group)
+        except Exception:  # noqa: BLE001
+            pass
+    return None, why or 'on another rank'

@@ -154,13 +154,13 @@ class CraftingWorldVecEnv:
         cfg.menus = self._menus
         cfg.env_menu = env_menu.ctypes.data_as(C.POINTER(C.c_uint8)) if env_menu is not None else None
         h_ = C.c_void_p()
-        L.check(self._lib.cw_create(C.byref(cfg), self.device.index, C.byref(h_)), 'cw_create')
+        L.check(self._lib.cw_create(C.byref(cfg), self.device.index, C.byref(h_)), 'cw_create', self._lib)
         self._h = h_
         _LIVE.add(self)
 
         # zero-copy views of the engine's buffers
         tab = L.cw_buffer_table()
-        L.check(self._lib.cw_buffers(self._h, C.byref(tab)), 'cw_buffers')
+        L.check(self._lib.cw_buffers(self._h, C.byref(tab)), 'cw_buffers', self._lib)
         N, di = self.num_envs, self.device.index
         # frame geometry: ray.py:84 (4W,4H,3) / craftingworld_altobs.py:115 ((W+1)*3, H*3, 3)
         self.frame_shape = (3 * self.size + 3, 3 * self.size, 3) if raster == 'alt' else (4 * self.size, 4 * self.size, 3)
@@ -202,9 +202,11 @@ class CraftingWorldVecEnv:
             init_observation=Box(0, 1, (self.size, self.size, 12), np.uint8)))
         self._pending = False
         self._actions_keepalive = None
+        self._cw_step, self._di = self._lib.cw_step, self.device.index
+        self._raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda di: torch.cuda.current_stream(di).cuda_stream)
         self.seed(seed)                                              # ray.py:70 (OS entropy when None)
         if self.fixed_init_state:                                    # ray.py:116-118
-            L.check(self._lib.cw_generate_fixed_states(self._h, self._stream()), 'cw_generate_fixed_states')
+            L.check(self._lib.cw_generate_fixed_states(self._h, self._stream()), 'cw_generate_fixed_states', self._lib)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -261,7 +263,7 @@ class CraftingWorldVecEnv:
             self.set_rng_states(keys, pos)
         else:
             arr = np.array([s & 0xFFFFFFFF for s in seeds], dtype=np.uint32)
-            L.check(self._lib.cw_seed_int(self._h, arr.ctypes.data_as(C.c_void_p)), 'cw_seed_int')
+            L.check(self._lib.cw_seed_int(self._h, arr.ctypes.data_as(C.c_void_p)), 'cw_seed_int', self._lib)
         return seeds
 
     def set_rng_states(self, keys, pos):
@@ -270,13 +272,13 @@ class CraftingWorldVecEnv:
         pos = np.ascontiguousarray(pos, dtype=np.int32)
         if keys.shape != (self.num_envs, L.CW_MT_N) or pos.shape != (self.num_envs,):
             raise ValueError('keys must be [N,624] and pos [N]')
-        L.check(self._lib.cw_seed_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_seed_mt')
+        L.check(self._lib.cw_seed_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_seed_mt', self._lib)
 
     def get_rng_states(self):
         """-> (keys uint32 [N,624], pos int32 [N]) accepted by RandomState.set_state, same stream."""
         keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
         pos = np.empty(self.num_envs, dtype=np.int32)
-        L.check(self._lib.cw_get_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_get_mt')
+        L.check(self._lib.cw_get_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_get_mt', self._lib)
         return keys, pos
 
     # ------------------------------------------------------------------ gym.vector surface
@@ -287,14 +289,14 @@ class CraftingWorldVecEnv:
                 'init_observation': self._init_img}                  # achieved_goal IS observation, ray.py:194-196
 
     def _sync(self):
-        L.check(self._lib.cw_synchronize(self._h, self._stream()), 'cw_synchronize')
+        L.check(self._lib.cw_synchronize(self._h, self._stream()), 'cw_synchronize', self._lib)
 
     def synchronize(self):
         """Block until everything this env enqueued on the current stream (and on its own side stream) has finished."""
         self._sync()
 
     def reset_async(self):
-        L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset')     # enqueues; nothing waits
+        L.check(self._lib.cw_reset(self._h, self._stream()), 'cw_reset', self._lib)     # enqueues; nothing waits
         self._has_reset = True
         self._reset_pending = True
 
@@ -311,20 +313,23 @@ class CraftingWorldVecEnv:
         return self.reset_wait()
 
     def step_async(self, actions):
+        # the per-step path: a device tensor of the right shape goes to cw_step with nothing built on the way (pointer and stream as plain ints)
+        if type(actions) is torch.Tensor and actions.is_cuda:
+            dt = _ACT_DTYPES.get(actions.dtype)
+            if dt is not None and actions.numel() == self.num_envs and actions.is_contiguous() and actions.device == self.device:
+                self._actions_keepalive = actions
+                rc = self._cw_step(self._h, actions.data_ptr(), dt, self._raw_stream(self._di))
+                if rc:
+                    L.check(rc, 'cw_step', self._lib)
+                self._pending = True
+                return
         if self.host_outputs and not (torch.is_tensor(actions) and actions.is_cuda):
             a = np.asarray(actions).reshape(-1)             # host actions go through the engine's mapped buffer
             if a.size != self.num_envs:
                 raise ValueError('expected %d actions, got %d' % (self.num_envs, a.size))
             self._host_actions[:] = a
             L.check(self._lib.cw_step(self._h, C.c_void_p(self._host_actions.ctypes.data), L.CW_ACT_I32, self._stream()),
-                    'cw_step')
-            self._pending = True
-            return
-        if type(actions) is torch.Tensor and actions.dtype in _ACT_DTYPES and actions.device == self.device \
-                and actions.is_contiguous() and actions.numel() == self.num_envs:
-            self._actions_keepalive = actions               # fast path: nothing to convert
-            L.check(self._lib.cw_step(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], self._stream()),
-                    'cw_step')
+                    'cw_step', self._lib)
             self._pending = True
             return
         if not torch.is_tensor(actions):
@@ -338,7 +343,7 @@ class CraftingWorldVecEnv:
             raise ValueError('expected %d actions, got %d' % (self.num_envs, actions.numel()))
         self._actions_keepalive = actions
         L.check(self._lib.cw_step(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], self._stream()),
-                'cw_step')
+                'cw_step', self._lib)
         self._pending = True
 
     def step_wait(self):
@@ -369,7 +374,7 @@ class CraftingWorldVecEnv:
             raise ValueError('actions must be a contiguous [K, num_envs] tensor of dtype uint8 / int32 / int64 on %s' % (self.device,))
         self._actions_keepalive = actions
         L.check(self._lib.cw_step_many(self._h, C.c_void_p(actions.data_ptr()), _ACT_DTYPES[actions.dtype], int(actions.shape[0]), self._stream()),
-                'cw_step_many')
+                'cw_step_many', self._lib)
 
     def capture_steps(self, actions):
         """-> a torch.cuda.CUDAGraph that takes K = actions.shape[0] steps per replay(), reading row t of the device tensor `actions` [K, N] on
@@ -401,7 +406,7 @@ class CraftingWorldVecEnv:
         don = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device) if record else None
         L.check(self._lib.cw_rollout(self._h, C.c_void_p(actions.data_ptr()), T,
                                      C.c_void_p(rew.data_ptr()) if record else None,
-                                     C.c_void_p(don.data_ptr()) if record else None, self._stream()), 'cw_rollout')
+                                     C.c_void_p(don.data_ptr()) if record else None, self._stream()), 'cw_rollout', self._lib)
         self._actions_keepalive = actions
         return (rew, don.view(torch.bool)) if record else None
 
@@ -410,7 +415,7 @@ class CraftingWorldVecEnv:
         """render() of ray.py:442-520 for every env -> uint8 [N,4S,4S,3] (works in every obs_mode)."""
         if out is None:
             out = torch.empty((self.num_envs,) + self.frame_shape, dtype=torch.uint8, device=self.device)
-        L.check(self._lib.cw_render(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_render')
+        L.check(self._lib.cw_render(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_render', self._lib)
         return out
 
     def render_states(self, one_hot):
@@ -424,7 +429,7 @@ class CraftingWorldVecEnv:
             raise ValueError('states must have shape [M, %d, %d, 12]' % (self.size, self.size))
         out = torch.empty((oh.shape[0],) + self.frame_shape, dtype=torch.int16, device=self.device)
         L.check(self._lib.cw_render_onehot(self._h, C.c_void_p(oh.data_ptr()), oh.shape[0], C.c_void_p(out.data_ptr()), self._stream()),
-                'cw_render_onehot')
+                'cw_render_onehot', self._lib)
         self._states_keepalive = oh
         return out
 
@@ -432,7 +437,7 @@ class CraftingWorldVecEnv:
         """Dense cell codes uint8 [N,S,S] (0 empty, k+1 = OBJECTS[k])."""
         if out is None:
             out = torch.empty((self.num_envs, self.size, self.size), dtype=torch.uint8, device=self.device)
-        L.check(self._lib.cw_export_grid(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_grid')
+        L.check(self._lib.cw_export_grid(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_grid', self._lib)
         return out
 
     def one_hot(self, out=None, which='current'):
@@ -441,7 +446,7 @@ class CraftingWorldVecEnv:
         if out is None:
             out = torch.empty((self.num_envs, self.size, self.size, 12), dtype=torch.uint8, device=self.device)
         w = {'current': 0, 'goal': 1, 'init': 2}[which]
-        L.check(self._lib.cw_export_onehot_of(self._h, w, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_onehot_of')
+        L.check(self._lib.cw_export_onehot_of(self._h, w, C.c_void_p(out.data_ptr()), self._stream()), 'cw_export_onehot_of', self._lib)
         return out
 
     def mask_to_vector(self, mask):
@@ -458,7 +463,7 @@ class CraftingWorldVecEnv:
                    hold=np.empty(N, np.uint8), achieved=np.empty(N, np.uint16), desired=np.empty(N, np.uint16),
                    step_num=np.empty(N, np.int32), ep_no=np.empty(N, np.int32))
         view = L.cw_state_view(**{k: a.ctypes.data_as(C.c_void_p) for k, a in out.items()})
-        L.check(self._lib.cw_get_state(self._h, C.byref(view)), 'cw_get_state')
+        L.check(self._lib.cw_get_state(self._h, C.byref(view)), 'cw_get_state', self._lib)
         return out
 
     def set_state(self, **fields):
@@ -477,7 +482,7 @@ class CraftingWorldVecEnv:
             if keep[k].shape[0] != self.num_envs:
                 raise ValueError('%s must have num_envs rows' % k)
             setattr(view, k, keep[k].ctypes.data_as(C.c_void_p))
-        L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state')
+        L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state', self._lib)
 
     # ------------------------------------------------------------------ checkpoint / resume
     def save_checkpoint(self, path):
@@ -486,7 +491,7 @@ class CraftingWorldVecEnv:
         step's outputs, counters) behind a header that pins the configuration (cw_checkpoint_save; synchronises)."""
         n = int(self._lib.cw_checkpoint_bytes(self._h))
         buf = np.empty(n, dtype=np.uint8)
-        L.check(self._lib.cw_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_save')
+        L.check(self._lib.cw_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_save', self._lib)
         with open(path, 'wb') as f:
             buf.tofile(f)
 
@@ -496,12 +501,12 @@ class CraftingWorldVecEnv:
         the state-mode observation tensors (hdr, slot_pos) equal the uninterrupted run's too; frames are repainted.  Per-env
         menu ids, reward rules, pools and counters come from the file."""
         buf = np.fromfile(path, dtype=np.uint8)
-        L.check(self._lib.cw_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.size), 'cw_checkpoint_load')
+        L.check(self._lib.cw_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.size), 'cw_checkpoint_load', self._lib)
         self._has_reset = True
 
     def profile_begin(self, max_steps):
         """Bracket each kernel of the following step() calls with HIP events on the launch stream."""
-        L.check(self._lib.cw_profile_begin(self._h, int(max_steps)), 'cw_profile_begin')
+        L.check(self._lib.cw_profile_begin(self._h, int(max_steps)), 'cw_profile_begin', self._lib)
 
     def render_kernel_name(self):
         """Name of the kernel `profile_end()['ms_render_kernel']` brackets (as a rocprofv3 kernel trace lists it)."""
@@ -510,7 +515,7 @@ class CraftingWorldVecEnv:
     def profile_end(self):
         """-> dict of average per-launch kernel durations (ms) since profile_begin."""
         p = L.cw_profile()
-        L.check(self._lib.cw_profile_end(self._h, C.byref(p)), 'cw_profile_end')
+        L.check(self._lib.cw_profile_end(self._h, C.byref(p)), 'cw_profile_end', self._lib)
         return {k: getattr(p, k) for k, _ in p._fields_}
 
     def tuner_state(self):
@@ -519,7 +524,7 @@ class CraftingWorldVecEnv:
         tunes it online), `guard_state` (-1 off, 0 watching, 1 trial, 2 the paced sweep was kept, 3 opening survey), `guard_trials`, `lookahead`
         (1: the outcome of every env's next reset() is computed ahead of time)."""
         t = L.cw_tuner_state()
-        L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner')
+        L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner', self._lib)
         return {k: int(getattr(t, k)) for k, _ in t._fields_}
 
     def compute_reward_batch(self, achieved_mask, desired_mask, subset=None):

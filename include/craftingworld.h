@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, piece_pace, lookahead, reserved}; one painter, look-ahead records */
+#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, piece_pace, lookahead, resident}; one painter, look-ahead records */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -183,7 +183,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
  * For engines with num_envs == 1, host_outputs, auto_reset == 0 and obs_mode CW_OBS_STATE or CW_OBS_PIXELS_DIRTY: a resident
  * single-wavefront kernel polls a doorbell word in pinned host memory; this call rings it and spins until the step's outputs (reward, done,
  * masks, the <= 2 repainted cells of the host-mapped frame) are visible -- a few microseconds instead of a launch plus a stream
- * synchronisation.  Results are those of cw_step with the same action (0..127; larger ids than 5 are the counted no-op of cw_step).  The kernel is started on demand and leaves by itself: after 2 ms
+ * synchronisation.  Results are those of cw_step with the same action (0..127; larger ids than 5 are the counted no-op of cw_step).  The kernel is started on demand and leaves by itself: after 0.5 ms
  * without a request, after a 200-ms time slice, or when any other entry point of this engine is called (they park it first; cw_resident_stop
  * does only that).  Synchronous.  A new instance of the kernel waits for the stream of the engine's last cw_reset / cw_step / cw_rollout first, so
  * `cw_reset(e, s); cw_step_resident(e, a, 0);` needs no synchronisation in between. */
@@ -256,9 +256,10 @@ const char *cw_render_kernel_name(const cw_engine *e);
 
 /* What the engine's tuning holds (full-frame mode): the period of the sweep's clock -- a wave starts a 4-KiB piece every
  * period16 / 16 ticks of the 100-MHz clock, 0: unclocked --, the sleeps inside a job in eighths per 1-KiB store, and whether the engine
- * keeps look-ahead records (cw_config.auto_reset, device-resident outputs).  Only performance depends on any of it. */
+ * keeps look-ahead records (cw_config.auto_reset, device-resident outputs); `resident`: 1 if cw_step_resident can be used on this engine.
+ * Only performance depends on any of it. */
 typedef struct cw_tuner_state {
-    int32_t period16, piece_pace, lookahead, reserved;
+    int32_t period16, piece_pace, lookahead, resident;
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 

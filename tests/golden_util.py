@@ -19,6 +19,7 @@ def load(name):
     meta = json.loads(bytes(d.pop('meta')).decode())
     kw = meta['kwargs']
     kw['size'] = tuple(kw['size'])
+    meta['stacked_obs'] = bool(kw.pop('stacked_obs', False))      # (a kwarg of the N=1 AltObs class only: the return convention, not the dynamics)
     return meta, kw, d
 
 

@@ -334,19 +334,23 @@ def test_shard_equivalence_and_batch_position_invariance():
 
 
 @pytest.mark.parametrize('size,max_steps', [(21, 300), (32, 40)])
-def test_full_size_properties_65536(size, max_steps):
-    """BASELINE configs 3 and 5 at full batch size, through size-independent properties:
-    the frame is a pure function of the state (full-frame render == dirty-cell repaint == render()
-    of the current state), the first 256 envs equal the CPU oracle, counters add up."""
+def test_full_size_properties_65536(size, max_steps, monkeypatch):
+    """BASELINE configs 3 and 5 at full batch size, through size-independent properties: the frame is a pure function of the state
+    (full-frame render == dirty-cell repaint == render() of the current state), counters add up -- and a SAMPLE of the envs against the
+    CPU oracle, all three frames: the first 64 envs, a stride through the batch, the LAST 32 (the array's partial last piece), and the envs
+    on either side of every chunk boundary of the sweep (CW_TUNE_RENDER_CHUNK_ROUNDS makes it three launches: 24 576 + 24 576 + 16 384 envs)."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from oracle import OracleBatch
     N, T = 65536, 45
     kw = dict(size=(size, size), max_steps=max_steps)
+    monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '150' if size == 21 else '350')
     full = CraftingWorldVecEnv(N, obs_mode='pixels', seed=123, **kw)
+    monkeypatch.delenv('CW_TUNE_RENDER_CHUNK_ROUNDS')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', seed=123, **kw)
     keys, pos = full.get_rng_states()
-    M = 256
-    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in range(M)], **kw)
+    idx = sorted(set(list(range(64)) + [24574, 24575, 24576, 24577, 49150, 49151, 49152, 49153] + list(range(1000, N, 4099))[:48] + list(range(N - 32, N))))
+    idx_t = torch.as_tensor(idx, device='cuda')
+    ora = OracleBatch(len(idx), rng_states=[(keys[i], int(pos[i])) for i in idx], **kw)
     full.reset()
     dirty.reset()
     ora.reset()
@@ -357,16 +361,17 @@ def test_full_size_properties_65536(size, max_steps):
         of, rf, df, _ = full.step(a)
         od, rd, dd, _ = dirty.step(a)
         assert torch.equal(rf, rd) and torch.equal(df, dd), t
-        o_rew, o_done = ora.step(a[:M].cpu().numpy())
-        assert np.array_equal(rf[:M].cpu().numpy(), o_rew) and np.array_equal(df[:M].cpu().numpy(), o_done), t
+        o_rew, o_done = ora.step(a[idx_t].cpu().numpy())
+        assert np.array_equal(rf[idx_t].cpu().numpy(), o_rew) and np.array_equal(df[idx_t].cpu().numpy(), o_done), t
         dones += int(df.sum().item())
         if t % 11 == 0 or t == T - 1:
             assert torch.equal(of['observation'], od['observation']), t
             assert torch.equal(of['desired_goal'], od['desired_goal']), t
             assert torch.equal(of['init_observation'], od['init_observation']), t
             assert torch.equal(full.render(), of['observation']), t
-    for i, s in enumerate(ora.states()):
-        assert np.array_equal(of['observation'][i].cpu().numpy(), s['obs']), i
+    obs, des, ini = (of[k][idx_t].cpu().numpy() for k in ('observation', 'desired_goal', 'init_observation'))
+    for j_, s in enumerate(ora.states()):
+        assert np.array_equal(obs[j_], s['obs']) and np.array_equal(des[j_], s['desired_img']) and np.array_equal(ini[j_], s['init_img']), idx[j_]
     assert torch.equal(full.hdr, dirty.hdr) and torch.equal(full.slot_pos, dirty.slot_pos)
     assert int(full.counters[1].item()) == dones and int(full.counters[0].item()) == N * T
     if max_steps <= T:
@@ -531,12 +536,13 @@ def test_terminal_observation_vs_oracle(obs_mode):
     env.close()
 
 
-def test_multi_device_facade_and_gymnasium_adapter():
-    """One process driving several engines (here: two shards on the one visible GPU) equals the
-    single batch; the gymnasium adaptor splits done into terminated (success) / truncated (time-out)."""
+@pytest.mark.parametrize('obs_mode', ['pixels_dirty', 'pixels'])
+def test_multi_device_facade_and_gymnasium_adapter(obs_mode):
+    """One process driving several engines (here: two engines, each on a stream of its own, on the one visible GPU) equals the
+    single batch, in the dirty-cell and the full-frame mode; the gymnasium adaptor splits done into terminated (success) / truncated (time-out)."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from gym_craftingworld_amd.adapters import GymnasiumVecAdapter, MultiDeviceVecEnv
-    N, T, kw = 300, 60, dict(size=(5, 5), max_steps=15, obs_mode='pixels_dirty')
+    N, T, kw = 300, 60, dict(size=(5, 5), max_steps=15, obs_mode=obs_mode)
     keys, pos = _np_states(N, 2222)
     acts = torch.as_tensor(np.random.RandomState(1).randint(0, 6, size=(T, N)).astype(np.int32), device='cuda')
     single = CraftingWorldVecEnv(N, **kw)
@@ -661,7 +667,7 @@ def test_config4_shard_shape_mixed_menus_131072():
     kw = dict(size=(21, 21), max_steps=10)
     env = CraftingWorldVecEnv(N, obs_mode='pixels', seed=4242, task_menus=menus, env_menu=env_menu, **kw)
     keys, pos = env.get_rng_states()
-    sample = np.arange(0, N, 1021)[:128]
+    sample = np.unique(np.concatenate([np.arange(0, N, 1021)[:120], np.arange(N - 8, N)]))      # (a stride through the batch and the last envs: the array's last piece)
     ora = OracleBatch(len(sample), rng_states=[(keys[i], int(pos[i])) for i in sample],
                       per_env_kwargs=[menus[env_menu[i]] for i in sample], **kw)
     env.reset()
@@ -677,6 +683,9 @@ def test_config4_shard_shape_mixed_menus_131072():
     goals = obs['desired_goal'][sidx].cpu().numpy()
     for j, s in enumerate(ora.states()):
         assert np.array_equal(frames[j], s['obs']) and np.array_equal(goals[j], s['desired_img']), sample[j]
+    inits = obs['init_observation'][sidx].cpu().numpy()
+    for j, s in enumerate(ora.states()):
+        assert np.array_equal(inits[j], s['init_img']), sample[j]
     assert int(env.counters[0].item()) == N * T and int(env.counters[1].item()) >= 2 * N
     env.close()
 
@@ -1121,6 +1130,37 @@ def test_single_env_facades_replay_fixtures(name, variant):
         assert over == int((g['obs_max'] > 255).sum()) and (over == 9 if name == 'alt4_double' else True)
         if 'stacked' not in variant:
             assert np.array_equal(env.obs_image.astype(np.int16), g['final_obs16'])
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('reference_dtypes', [True, False])
+def test_altobs_stacked_obs_replays_the_reference_fixture(reference_dtypes):
+    """CraftingWorldEnvAltObs(stacked_obs=True) (altobs.py:116-119, 258-261, 408-412): reset() and step() return ONE array, the four images
+    stacked.  tests/golden/alt6_stacked.npz was captured from the reference class built with stacked_obs=True and holds the CRC of every array
+    it returned (84 resets, 3 000 steps; int16 view): the facade must return the same stacks -- order, shape and values, exactly with
+    reference_dtypes=True (int64), modulo 256 in the default uint8."""
+    import gym_craftingworld_amd as cw
+    meta, kw, g = load('alt6_stacked')
+    assert meta['stacked_obs'] and meta['env'] == 'CraftingWorldEnvAltObs'
+    env = cw.CraftingWorldEnvAltObs(**kw, stacked_obs=True, reference_dtypes=reference_dtypes)
+    env.set_rng_state(g['key0'], int(g['pos0']))
+    assert tuple(env.observation_space.shape) == tuple(g['stack_shape'])
+    calls = iter(g['stack_crc16'])
+
+    def check(o, wraps=False):
+        assert isinstance(o, np.ndarray) and tuple(o.shape) == tuple(g['stack_shape']) and o.dtype == (np.int64 if reference_dtypes else np.uint8)
+        want = next(calls)
+        if reference_dtypes or not wraps:                       # (uint8 frames hold the reference's values modulo 256: compared where nothing exceeds 255)
+            assert crc(o.astype(np.int16)) == want
+    check(env.reset())
+    for t in range(len(g['action'])):
+        o, r, d, info = env.step(int(g['action'][t]))
+        assert r == g['reward'][t] and d == bool(g['done'][t]), t
+        check(o, wraps=int(g['obs_max'][t]) > 255)
+        if d:
+            check(env.reset())
+    assert next(calls, None) is None                            # every returned array was compared
     env.close()
 
 
@@ -1593,9 +1633,10 @@ def test_facade_render_of_states_with_duplicated_objects():
 @pytest.mark.parametrize('keep_terminal', [False, True])
 def test_headline_shape_reset_storm_65536(keep_terminal):
     """The headline shape (65 536 envs, 21x21, full-frame pixel obs) across steps on which EVERY env times out at once
-    (max_steps=20, T=45: storms at t=19 and t=39 -- ray.py:367 then reset ray.py:156-218 for the whole batch, beside the
-    render kernel on the forked stream): full frames == dirty-cell frames on the storm step itself and after it, the
-    first 256 envs == the CPU oracle (all three frames, terminal frame, RNG stream position), counters."""
+    (max_steps=20, T=45: storms at t=19 and t=39 -- ray.py:367 then reset ray.py:156-218 for the whole batch: on the first every env takes its
+    look-ahead record, on the second -- four steps after a refill -- too): full frames == dirty-cell frames on the storm step itself and after
+    it, a sample of 256 envs (the first 128, a stride through the batch, the last 64) == the CPU oracle (all three frames, terminal frame, RNG
+    stream position), counters."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     from oracle import OracleBatch
     N, T, M = 65536, 45, 256
@@ -1603,7 +1644,10 @@ def test_headline_shape_reset_storm_65536(keep_terminal):
     full = CraftingWorldVecEnv(N, obs_mode='pixels', seed=321, keep_terminal_obs=keep_terminal, **kw)
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', seed=321, keep_terminal_obs=keep_terminal, **kw)
     keys, pos = full.get_rng_states()
-    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in range(M)], **kw)
+    idx = list(range(128)) + list(range(300, N - 64, (N - 364) // 64))[:64] + list(range(N - 64, N))
+    assert len(idx) == M and idx[-1] == N - 1
+    idx_t = torch.as_tensor(idx, device='cuda')
+    ora = OracleBatch(M, rng_states=[(keys[i], int(pos[i])) for i in idx], **kw)
     full.reset(); dirty.reset(); ora.reset()
     gen = torch.Generator(device='cuda').manual_seed(77)
     dones = storms = 0
@@ -1614,7 +1658,7 @@ def test_headline_shape_reset_storm_65536(keep_terminal):
         assert torch.equal(rf, rd) and torch.equal(df, dd), t
         n_done = int(df.sum().item())
         dones += n_done
-        an = a[:M].cpu().numpy()
+        an = a[idx_t].cpu().numpy()
         term_ref = {}
         o_done = np.zeros(M, bool)
         o_rew = np.zeros(M, np.int32)
@@ -1623,7 +1667,7 @@ def test_headline_shape_reset_storm_65536(keep_terminal):
             if o_done[i]:
                 term_ref[i] = o['observation'].copy()
                 e.reset()
-        assert np.array_equal(rf[:M].cpu().numpy(), o_rew) and np.array_equal(df[:M].cpu().numpy(), o_done), t
+        assert np.array_equal(rf[idx_t].cpu().numpy(), o_rew) and np.array_equal(df[idx_t].cpu().numpy(), o_done), t
         storm = n_done > N * 0.9
         if storm or t % 13 == 0 or t == T - 1:
             storms += int(storm)
@@ -1633,16 +1677,16 @@ def test_headline_shape_reset_storm_65536(keep_terminal):
             if keep_terminal:
                 d = df.nonzero().flatten()
                 assert torch.equal(inf['terminal_observation'][d], ind['terminal_observation'][d]), t
-                term = inf['terminal_observation'][:M].cpu().numpy()
+                term = inf['terminal_observation'][idx_t].cpu().numpy()
                 for i, fr in term_ref.items():
                     assert np.array_equal(term[i], fr), (t, i)
-            fo, fg, fi = (of[k][:M].cpu().numpy() for k in ('observation', 'desired_goal', 'init_observation'))
+            fo, fg, fi = (of[k][idx_t].cpu().numpy() for k in ('observation', 'desired_goal', 'init_observation'))
             for i, s in enumerate(ora.states()):
-                assert np.array_equal(fo[i], s['obs']) and np.array_equal(fg[i], s['desired_img']) and np.array_equal(fi[i], s['init_img']), (t, i)
+                assert np.array_equal(fo[i], s['obs']) and np.array_equal(fg[i], s['desired_img']) and np.array_equal(fi[i], s['init_img']), (t, idx[i])
     assert storms == 2 and dones >= 2 * N
     _, p2 = full.get_rng_states()
     for i, e in enumerate(ora.envs):
-        assert p2[i] % 624 == e.get_rng()[1] % 624, i
+        assert p2[idx[i]] % 624 == e.get_rng()[1] % 624, idx[i]
     assert torch.equal(full.hdr, dirty.hdr) and torch.equal(full.slot_pos, dirty.slot_pos)
     assert int(full.counters[1].item()) == dones == int(dirty.counters[1].item()) and int(full.counters[0].item()) == N * T
     full.close(); dirty.close()

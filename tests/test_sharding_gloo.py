@@ -76,3 +76,57 @@ def test_shard_range_covers_everything():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
     with pytest.raises(ValueError):
         shard_range(2, 2, 10)
+
+
+def _rccl_worker(rank, world, port, q, failing_rank, fail_at):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import time
+    from gym_craftingworld_amd.sharding import agree_on_rccl
+
+    # stands in for dist.new_group(backend='nccl') -- there is no GPU here -- with RCCL's semantics: creating the group sends nothing (the
+    # communicator is built lazily, by the group's first collective); collectives "on" it go over the default gloo group
+    def new_group(backend, timeout):
+        if rank == failing_rank and fail_at == 'create':
+            raise RuntimeError('injected: ncclCommInitRank failed')
+        return 'fake-rccl'
+
+    real_all_reduce = dist.all_reduce
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+        if group == 'fake-rccl':
+            if rank == failing_rank and fail_at == 'probe':
+                raise RuntimeError('injected: ncclAllReduce failed')
+            group = None
+        return real_all_reduce(t, op=op, group=group)
+
+    dist.all_reduce = all_reduce
+    t0 = time.time()
+    group, why = agree_on_rccl('cpu', timeout_s=20, new_group=new_group)
+    q.put((rank, group is not None, why, time.time() - t0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('failing_rank,fail_at,expect_group', [(1, 'create', False), (0, 'create', False), (None, None, True)])
+def test_rccl_agreement_when_one_rank_fails(failing_rank, fail_at, expect_group):
+    """bench.py's timing collectives go over RCCL only if it works on EVERY rank (sharding.agree_on_rccl).  One of two ranks fails to create its
+    RCCL group (injected; the group is a gloo one here): both must land on gloo at once -- the healthy rank must not enter the group's first
+    collective and wait out its timeout.  Nobody fails: both keep the group."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q, failing_rank, fail_at)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[1] for o in out] == [expect_group, expect_group], out
+    assert all(o[3] < 15.0 for o in out), out                  # (nobody waited out the 20-s group timeout)
+    if not expect_group:
+        assert 'injected' in out[failing_rank][2] and out[1 - failing_rank][2] == 'on another rank'

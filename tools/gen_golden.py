@@ -51,6 +51,9 @@ ALT_SCENARIOS = [
     ('alt5_random',       dict(size=(5, 5), max_steps=40),                       55,    4000, 'random',   2),
     ('alt8_scripted',     dict(size=(8, 8), max_steps=60, reward_style='subset'), 88,   3000, 'scripted', 1),
     ('alt4_double',       dict(size=(4, 4), max_steps=120),                      109,   5000, 'random',   1),   # sticks held over sticks on 9 steps: values up to 320
+    # stacked_obs=True (altobs.py:116-119, 258-261, 408-412): reset() / step() return ONE array, the four images stacked; the fixture pins the
+    # reference's stack (order, shape, dtype) by the CRC of what it returned
+    ('alt6_stacked',      dict(size=(6, 6), max_steps=40, stacked_obs=True),     606,   3000, 'scripted', 1),
 ]
 
 
@@ -78,12 +81,18 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
     key0, pos0 = st[1].copy(), int(st[2])
     env = make_ref_env(cls, rng, **kwargs)
     flat, onehot = env_name == 'CraftingWorldEnvFlat', env_name == 'CraftingWorldEnvOneHot'
+    stacked, stack_crc, stack_shape = bool(kwargs.get('stacked_obs')), [], []
 
     def views(ret):
         """(observation, desired_goal, init_observation) as the class hands them out"""
         if flat:
             assert ret is env.obs_image
             return ret, env.desired_goal, env.INIT_OBS
+        if stacked:                                   # np.stack([observation, desired_goal, achieved_goal, init_observation]), altobs.py:258-261
+            assert isinstance(ret, np.ndarray) and ret.shape[0] == 4 and np.array_equal(ret[0], ret[2])
+            stack_crc.append(crc(ret.astype(np.int16)))
+            stack_shape[:] = list(ret.shape)
+            return ret[0], ret[1], ret[3]
         assert ret['achieved_goal'] is ret['observation']
         return ret['observation'], ret['desired_goal'], ret['init_observation']
     pol_rng = np.random.RandomState(seed ^ 0x5EED)
@@ -190,6 +199,9 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
         out['r_desired_img_crc16'] = np.array(R['desired_img_crc16'], np.uint32)
         out['r_init_img_crc16'] = np.array(R['init_img_crc16'], np.uint32)
         out['final_obs16'] = np.asarray(env.obs_image).astype(np.int16)
+    if stacked:                                       # CRC (int16 view) of every array reset() / step() returned, in call order, and its shape
+        out['stack_crc16'] = np.array(stack_crc, np.uint32)
+        out['stack_shape'] = np.array(stack_shape, np.int32)
     if onehot:
         out['r_goal_grid'] = np.array(R['goal_grid'], np.uint8)
         out['r_goal_agent'] = np.array(R['goal_agent'], np.uint8)
