@@ -93,6 +93,13 @@ struct cw_engine {
     // look-ahead (cw_layout.h): the refill kernel is launched every CW_LA_PERIOD steps, ahead of the step, on the step's stream
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
     unsigned la_steps = 0;
+    // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
+    int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
+    double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;
+    bool guard_on = false, guard_pending = false;
+    hipEvent_t guard_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned guard_step = 0;
+    int guard_late = 0, guard_slowdowns = 0, guard_period16 = 0;
     int prof_cap = 0, prof_n = 0;
 };
 enum { CW_LA_PERIOD = 16 };
@@ -297,18 +304,22 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 // waves x 4 KiB per period.  The memory system of an MI355X keeps up with 7.2 TB/s of such a stream (65 536 envs, 21x21: a period of 580 ns for
 // 1 024 waves, 0.2055 ms per launch, 0.86 of the 8 TB/s peak, the same with ~220 envs finishing on every step) and falls into its slower,
 // saturated regime just below that (560 ns: 0.214-0.235 ms, launch by launch); at 7.0 TB/s (600 ns) every launch reads 0.2112 +- 0.0005 ms
-// (profiles/r04_clock.txt).  So the default is 7.0 TB/s, and cw_create CHECKS it on the engine's own batch against 6.8, 6.6 and the unclocked
-// sweep (20 launches each).
+// (profiles/r04_clock.txt); at 7.2 TB/s the synchronized case reads 0.2065 but launches with ~220 / ~440 finished envs per step turn erratic
+// (0.2129 average, 131 072 envs 0.436 against 0.415 at 7.0).  So: 7.0 TB/s, which cw_create checks against 6.8, 6.6 and the unclocked sweep on
+// the engine's own batch (20 launches each), and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep that does not keep its schedule
+// any more is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can), CW_TUNE_PIECE_PACE the sleeps inside a job (eighths per store).
+static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
+
 static int calibrate_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
     if (const char *forced = getenv("CW_TUNE_PIECE_PACE")) tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF;
     if (const char *per = getenv("CW_TUNE_PERIOD_NS")) { tn.period16 = (int)(atof(per) * 1.6 + 0.5); return CW_OK; }
-    int n_chunks = 1, waves = 1024, jobs_per_wave = 1;
-    cwk_sweep_shape(&e->P, &tn, &n_chunks, &waves, &jobs_per_wave);
-    auto period_ns = [&](double tb_per_s) { return (double)waves * 4096.0 / (tb_per_s * 1e12) * 1e9; };
-    tn.period16 = (int)(period_ns(7.0) * 1.6 + 0.5);
+    int n_chunks = 1, jobs_per_wave = 1;
+    cwk_sweep_shape(&e->P, &tn, &n_chunks, &e->sweep_waves, &jobs_per_wave);
+    e->sweep_jobs = (double)n_chunks * jobs_per_wave;
+    tn.period16 = (int)(sweep_period_ns(e, 7.0) * 1.6 + 0.5);
     // (small batches are launch-bound: nothing to check; host-mapped frames are PCIe-bound: unclocked)
     if (e->host_actions) { tn.period16 = 0; return CW_OK; }
     if (e->obs_mode != CW_OBS_PIXELS_FULL || (double)e->n * e->P.frame_bytes < (double)(64ll << 20)) return CW_OK;
@@ -318,21 +329,64 @@ static int calibrate_sweep(cw_engine *e)
     static const double rates[] = {7.0, 6.8, 6.6, 0.0};
     char log[480] = "";
     size_t len = 0;
-    int rc = CW_OK, best = tn.period16;
+    int rc = CW_OK;
     double best_p90 = 0, med = 0, p90 = 0;
     rc = timed_render_stats(e, &med, &p90);           // (a card that idled through set-up runs its first launches a few per cent slower: not counted)
-    for (size_t i = 0; i < sizeof(rates) / sizeof(rates[0]) && rc == CW_OK; i++) {
-        tn.period16 = rates[i] > 0 ? (int)(period_ns(rates[i]) * 1.6 + 0.5) : 0;
+    // what a sweep costs beside its jobs (a launch's ramp and tail, the events around it), at a rate the memory system keeps up with easily: the guard's yardstick
+    tn.period16 = (int)(sweep_period_ns(e, 6.4) * 1.6 + 0.5);
+    if (rc == CW_OK) rc = timed_render_stats(e, &med, &p90);
+    e->sweep_beside_ms = med - e->sweep_jobs * sweep_period_ns(e, 6.4) * 1e-6;
+    const char *forced_rate = getenv("CW_TUNE_RATE_TBS");                      // (the starting rate, the guard stays on: the test that it slows a saturated sweep down)
+    if (forced_rate && atof(forced_rate) > 0) { e->sweep_rate = atof(forced_rate); best_p90 = 1e-9; }
+    for (size_t i = 0; i < sizeof(rates) / sizeof(rates[0]) && rc == CW_OK && !forced_rate; i++) {
+        tn.period16 = rates[i] > 0 ? (int)(sweep_period_ns(e, rates[i]) * 1.6 + 0.5) : 0;
         rc = timed_render_stats(e, &med, &p90);
         if (len < sizeof(log) - 48) len += (size_t)snprintf(log + len, sizeof(log) - len, " %.1f TB/s (%.0f ns): %.4f/%.4f |", rates[i], tn.period16 / 1.6, med, p90);
-        if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; best = tn.period16; }
+        if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; e->sweep_rate = rates[i]; }
     }
-    tn.period16 = best;
-    (void)n_chunks; (void)jobs_per_wave;
+    tn.period16 = e->sweep_rate > 0 ? (int)(sweep_period_ns(e, e->sweep_rate) * 1.6 + 0.5) : 0;
+    e->guard_on = rc == CW_OK && e->sweep_rate > 0 && e->auto_reset && !(getenv("CW_TUNE_GUARD") && atoi(getenv("CW_TUNE_GUARD")) == 0);
+    if (e->guard_on)
+        for (hipEvent_t &ev : e->guard_ev)
+            if (hipEventCreate(&ev) != hipSuccess) e->guard_on = false;
     if (getenv("CW_TUNE_VERBOSE"))
         fprintf(stderr, "[craftingworld] sweep clock, ms per sweep (median/90th percentile of 20; 0.0 TB/s = unclocked):%s -> %s%.0f ns\n", log,
                 tn.period16 ? "" : "unclocked, ", tn.period16 / 1.6);
     return rc;
+}
+
+// The GUARD of the sweep's clock.  Every CW_GUARD_EVERY-th step's sweep is bracketed by two events on the caller's stream; when they have completed
+// (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + what a launch costs
+// beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 5-15 % and erratically; one that keeps up
+// by less than 1 %.  Three samples in a row more than 4 % late: the rate goes down by 0.2 TB/s for the rest of the process (never up again: the
+// point of a clock is that it does not hunt).  -> the event array for this step's launch, or null.
+enum { CW_GUARD_EVERY = 64 };
+static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
+{
+    if (++e->guard_step % CW_GUARD_EVERY) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;     // (a captured graph keeps the rate it was captured with)
+    if (e->guard_pending) {
+        if (hipEventQuery(e->guard_ev[5]) != hipSuccess) return nullptr;                                        // (the sampled sweep has not run yet)
+        float ms = 0.f;
+        e->guard_pending = false;
+        if (hipEventElapsedTime(&ms, e->guard_ev[4], e->guard_ev[5]) == hipSuccess && ms > 0.f && e->guard_period16 == e->tune.period16) {
+            const double scheduled = e->sweep_jobs * (e->tune.period16 / 1.6) * 1e-6 + e->sweep_beside_ms;
+            e->guard_late = ms > 1.04 * scheduled ? e->guard_late + 1 : 0;
+            if (e->guard_late >= 3 && e->sweep_rate > 5.5) {
+                e->sweep_rate -= 0.2;
+                e->tune.period16 = (int)(sweep_period_ns(e, e->sweep_rate) * 1.6 + 0.5);
+                e->guard_late = 0;
+                e->guard_slowdowns++;
+                if (getenv("CW_TUNE_VERBOSE"))
+                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f scheduled, three samples in a row -> %.1f TB/s (%.0f ns)\n", ms, scheduled,
+                            e->sweep_rate, e->tune.period16 / 1.6);
+            }
+        }
+    }
+    e->guard_pending = true;
+    e->guard_period16 = e->tune.period16;
+    return e->guard_ev;
 }
 
 extern "C" {
@@ -416,8 +470,6 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
-        tn.sweep_blocks_per_cu = geti("CW_TUNE_SWEEP_BLOCKS_PER_CU", tn.sweep_blocks_per_cu);
-        if (tn.sweep_blocks_per_cu < 1) tn.sweep_blocks_per_cu = 1;
     }
 
     int rc = CW_OK;
@@ -525,6 +577,7 @@ int cw_destroy(cw_engine *e)
     prof_free(e);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
     if (e->last_work) (void)hipEventDestroy(e->last_work);
+    for (hipEvent_t ev : e->guard_ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;
@@ -642,13 +695,15 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
+    const bool profiled = ev != nullptr;
+    if (e->guard_on && !ev) ev = sweep_guard_tick(e, (hipStream_t)stream);
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
         e->la_steps = 0;
     }
     HIP_TRY(cwk_launch_step(&e->P, &e->tune, actions, action_dtype, e->obs_mode, e->auto_reset, (hipStream_t)stream, ev));
-    if (ev) e->prof_n++;
+    if (profiled) e->prof_n++;
     if (e->res && hipEventRecord(e->last_work, (hipStream_t)stream) == hipSuccess) e->last_work_set = true;
     return CW_OK;
 }
@@ -876,6 +931,7 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
     out->piece_pace = e->tune.piece_pace;
     out->lookahead = e->P.lookahead;
     out->resident = e->res ? 1 : 0;
+    out->guard_slowdowns = e->guard_on ? e->guard_slowdowns : -1;
     return CW_OK;
 }
 

@@ -18,7 +18,6 @@
 // issue/latency for the others.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "cw_layout.h"
 #include "cw_mt.h"
@@ -1624,9 +1623,10 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
 {
     // 4 waves per block, persistent grid-stride.  ONE block per CU (1024 waves chip-wide): the HBM
     // write path saturates with few store streams and gets slower with more of them in flight
-    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt)
+    // (0.27 ms at 1 block/CU, 0.30 at 2, 0.32 at 4-8: profiles/history/r01_render_sweeps.txt; the instruction-bound sweeps of small frames gain
+    // nothing from a second one either: 8x8 0.0468 vs 0.0473 ms, profiles/r04_clock.txt)
     long long blocks = (jobs + 3) / 4;
-    if (blocks > (long long)tn.n_cu * tn.sweep_blocks_per_cu) blocks = (long long)tn.n_cu * tn.sweep_blocks_per_cu;
+    if (blocks > tn.n_cu) blocks = tn.n_cu;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -1662,7 +1662,6 @@ static inline int cw_reset_grid(const CwTuning &tn, int jobs)
 // finished envs take their look-ahead records): aim for ~1024 waves (one per SIMD) -- 64 envs per wave for large batches, down to 8 for small ones
 static int cw_envs_per_wave(int n)
 {
-    if (const char *f = getenv("CW_EXP_EPW")) return atoi(f);
     int epw = 64;
     while (epw > 8 && (n + epw - 1) / epw < 1024) epw >>= 1;
     return epw;

@@ -44,7 +44,6 @@ struct CwTuning {
     int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
     int period16 = 0;               // the sweep's CLOCK: a wave's jobs (4-KiB pieces) start one period apart; in 1/16 of a 10-ns tick of the 100-MHz clock (0: unclocked)
     int piece_pace = 0;             // ... and eighths of an s_sleep(1) per 1-KiB store inside a job
-    int sweep_blocks_per_cu = 1;    // workgroups (4 waves each) of a sweep per CU
     int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
                                     // 131 072 envs at 21x21 (0: one launch whatever the batch)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels

@@ -1213,6 +1213,41 @@ def test_full_frame_step_of_every_frame_size_equals_the_dirty_cell_engine(N, siz
 
 
 @pytest.mark.gpu
+def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
+    """The sweep's clock sets the rate at which a launch writes; its guard (cw_engine.cpp: sweep_guard_tick) holds every 64th sweep against its
+    schedule and lowers the rate when three samples in a row are more than 4 % late.  Started at 9 TB/s -- more than the memory system takes --
+    the guard must have stepped the rate down within 2 000 steps; at the default rate it must not move; the frames are the dirty-cell engine's
+    either way."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, kw = 65536, dict(size=(21, 21), max_steps=300, seed=3)
+    acts = torch.randint(0, 6, (64, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(2))
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    dirty.reset()
+    for rate, T in (('9.0', 2000), (None, 1000)):
+        if rate:
+            monkeypatch.setenv('CW_TUNE_RATE_TBS', rate)
+        e = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+        monkeypatch.delenv('CW_TUNE_RATE_TBS', raising=False)
+        p0 = e.tuner_state()['period16']
+        e.reset()
+        for t in range(T):                                   # (alone on the card: the guard times this engine's sweeps)
+            e.step_async(acts[t % 64])
+            if t % 250 == 249:
+                torch.cuda.synchronize()
+        ts = e.tuner_state()
+        if rate:
+            assert ts['guard_slowdowns'] >= 1 and ts['period16'] > p0 > 0, ts
+            for t in range(T):
+                dirty.step_async(acts[t % 64])
+            for k in ('observation', 'desired_goal', 'init_observation'):
+                assert torch.equal(e._observation()[k], dirty._observation()[k]), k
+        else:
+            assert ts['guard_slowdowns'] == 0 and ts['period16'] == p0, ts
+        e.close()
+    dirty.close()
+
+
+@pytest.mark.gpu
 def test_full_frame_soak_equals_dirty_cell_engine(monkeypatch):
     """3 000 steps of 65 536 full-frame envs with the episode phases spread out (~220 envs finish on every step and take their look-ahead
     records; the refill kernel runs every 16 steps): every 250 steps all three frames, and at the end results, counters and random

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ['CW_LIB_PATH'] = os.path.join(ROOT, 'gym_craftingworld_amd', 'libcraftingworld_trace.so')
-os.environ.setdefault('CW_TUNE_FUSED_STEP', '0')
+os.environ.setdefault('CW_TUNE_LOOKAHEAD', '0')      # (the slow path: resets inline in the step kernel, where the stamps are)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from gym_craftingworld_amd import CraftingWorldVecEnv, _lib  # noqa: E402

@@ -44,7 +44,7 @@ if use_graph:     # GPU-side time without the host's launch path: 16 steps per g
     ms = torch.tensor([ev[r].elapsed_time(ev[r + 1]) / G for r in range(R)])
     srt = ms.sort().values
     print('%s N=%d %s fused=%s graph of %d steps: per step median %.2f us, p90 %.2f us, mean %.2f us' % (
-        mode, N, 'desync' if desync else 'sync', os.environ.get('CW_TUNE_FUSED_STEP', '1'), G,
+        mode, N, 'desync' if desync else 'sync', os.environ.get('CW_TUNE_LOOKAHEAD', '1'), G,
         1e3 * srt[R // 2], 1e3 * srt[int(R * 0.9)], 1e3 * ms.mean()))
     env.close()
     sys.exit(0)
@@ -57,6 +57,6 @@ ms = torch.tensor([ev[t].elapsed_time(ev[t + 1]) for t in range(T)])
 srt = ms.sort().values
 top = ms.topk(4)
 print('%s N=%d %s fused=%s: median %.1f us, p90 %.1f us, mean %.1f us, slowest steps %s' % (
-    mode, N, 'desync' if desync else 'sync', os.environ.get('CW_TUNE_FUSED_STEP', '1'), 1e3 * srt[T // 2], 1e3 * srt[int(T * 0.9)], 1e3 * ms.mean(),
+    mode, N, 'desync' if desync else 'sync', os.environ.get('CW_TUNE_LOOKAHEAD', '1'), 1e3 * srt[T // 2], 1e3 * srt[int(T * 0.9)], 1e3 * ms.mean(),
     ', '.join('t=%d: %.0f us' % (20 + i, 1e3 * v) for v, i in zip(top.values.tolist(), top.indices.tolist()))))
 env.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box only: where do the render kernel's cycles go (cw_render_pieces_step_kernel / cw_render_step_kernel; the render alone with CW_TUNE_FUSED_RENDER=0)?  One --pmc pass per
+# GPU box only: where do the sweep's cycles go (cw_render_pieces_kernel)?  One --pmc pass per
 # counter group (SQ: 8 slots, TCC: 4 slots per pass), kernel-trace only beside it.   usage: bash tools/profile_counters.sh [tag] [bench.py arguments, e.g. --desync]
 set -e -o pipefail
 export TMPDIR=/tmp
