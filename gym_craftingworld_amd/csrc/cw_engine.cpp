@@ -93,6 +93,7 @@ struct cw_engine {
     // look-ahead (cw_layout.h): the refill kernel is launched every CW_LA_PERIOD steps, ahead of the step, on the step's stream
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
     unsigned la_steps = 0;
+    bool in_step_many = false;         // (cw_step_many decides about the refill of a captured sequence itself)
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
     int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
     double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;
@@ -697,6 +698,11 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     const bool profiled = ev != nullptr;
     if (e->guard_on && !ev) ev = sweep_guard_tick(e, (hipStream_t)stream);
+    if (e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < CW_LA_PERIOD && !e->in_step_many) {
+        // a step captured into a HIP graph on its own carries the refill with it: a replayed graph would otherwise never refill
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = CW_LA_PERIOD;
+    }
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -719,11 +725,11 @@ int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (e->P.lookahead && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = CW_LA_PERIOD;
     const size_t row = (size_t)e->n * (action_dtype == CW_ACT_I32 ? 4 : action_dtype == CW_ACT_I64 ? 8 : 1);
-    for (int32_t t = 0; t < n_steps; t++) {
-        const int rc = cw_step(e, (const unsigned char *)actions + (size_t)t * row, action_dtype, stream);
-        if (rc != CW_OK) return rc;
-    }
-    return CW_OK;
+    e->in_step_many = true;
+    int rc = CW_OK;
+    for (int32_t t = 0; t < n_steps && rc == CW_OK; t++) rc = cw_step(e, (const unsigned char *)actions + (size_t)t * row, action_dtype, stream);
+    e->in_step_many = false;
+    return rc;
 }
 
 // One step of the single-env loop WITHOUT a kernel launch: ring the resident kernel's doorbell, spin on its answer (cw_kernels.hip:

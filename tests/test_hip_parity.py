@@ -419,9 +419,8 @@ def test_single_env_facade_matches_golden():
 @pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty', 'state'])
 def test_step_captured_in_hip_graph(obs_mode):
     """One cw_step is a fixed launch sequence (no host-side state in kernel arguments), so it can be captured into a HIP graph and
-    replayed: the replayed env must stay bit-identical to an eagerly stepped twin.  (A graph of ONE step carries the look-ahead refill
-    only if it was captured on a 16th step: here it never refills and finished envs are reset on the spot -- same results; capture_steps /
-    cw_step_many is the way to capture.)"""
+    replayed: the replayed env must stay bit-identical to an eagerly stepped twin.  (A step captured on its own carries the look-ahead refill
+    with it -- cw_step sees the capture -- so the replayed env refills on every step where the eager one does on every 16th: same results.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     N, T, kw = 2048, 90, dict(size=(7, 7), max_steps=25)
     keys, pos = _np_states(N, 99)
