@@ -90,9 +90,10 @@ struct cw_engine {
     bool last_work_set = false;        //   work (an event of the engine's own: the caller may destroy its stream any time after cw_synchronize)
     unsigned long long res_ticks_per_us = 100;   // the device's constant clock (wall_clock64), hipDeviceAttributeWallClockRate
     std::vector<hipEvent_t> prof_ev;   // 6 per recorded step
-    // look-ahead (cw_layout.h): the refill kernel is launched every CW_LA_PERIOD steps, ahead of the step, on the step's stream
+    // look-ahead (cw_layout.h): the refill kernel is launched every e->la_period steps, ahead of the step, on the step's stream
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
     unsigned la_steps = 0;
+    unsigned la_period = 16;
     bool in_step_many = false;         // (cw_step_many decides about the refill of a captured sequence itself)
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
     int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
@@ -103,7 +104,9 @@ struct cw_engine {
     int guard_late = 0, guard_slowdowns = 0, guard_period16 = 0;
     int prof_cap = 0, prof_n = 0;
 };
-enum { CW_LA_PERIOD = 16 };
+// look-ahead refill: every la_period-th step.  A refill costs one reset's latency (~15 us) whatever the list holds, so rarely is cheap -- but an env
+// that finishes twice between two refills is reset the slow way: a quarter of the episode length, 8..64 steps
+static int la_period_for(int max_steps) { const int p = max_steps / 4; return p < 8 ? 8 : p > 64 ? 64 : p; }
 // ------------------------------------------------------------------------------ resident stepper (host side)
 // Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
 static int resident_park(cw_engine *e)
@@ -460,6 +463,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.size = e->S;
     P.ncell = e->ncell;
     P.max_steps = cfg->max_steps;
+    e->la_period = (unsigned)la_period_for(cfg->max_steps);
     P.task_mask = (1u << cfg->n_task_list) - 1u;
     P.pool_k = e->K;
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
@@ -698,12 +702,12 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     const bool profiled = ev != nullptr;
     if (e->guard_on && !ev) ev = sweep_guard_tick(e, (hipStream_t)stream);
-    if (e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < CW_LA_PERIOD && !e->in_step_many) {
+    if (e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < e->la_period && !e->in_step_many) {
         // a step captured into a HIP graph on its own carries the refill with it: a replayed graph would otherwise never refill
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = CW_LA_PERIOD;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = e->la_period;
     }
-    if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= CW_LA_PERIOD)) {      // look-ahead refill, between two steps
+    if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= e->la_period)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
         e->la_steps = 0;
@@ -716,14 +720,14 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
 
 // n_steps consecutive steps from an action array [n_steps][N]: what a loop over cw_step enqueues, without the caller's per-step cost (a Python
 // loop spends more per step than a state-only step takes on the card).  Capturable into a HIP graph as one piece; inside a capture the
-// look-ahead refill rides at the head of the sequence too, so that a replayed graph of fewer than CW_LA_PERIOD steps still refills.
+// look-ahead refill rides at the head of the sequence too, so that a replayed graph of fewer than e->la_period steps still refills.
 int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_steps, cw_stream_t stream)
 {
     if (!e || !actions) return fail(CW_ERR_INVALID, "cw_step_many: null argument");
     if (n_steps < 1) return fail(CW_ERR_INVALID, "cw_step_many: n_steps must be >= 1");
     if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step_many: bad action dtype %d", action_dtype);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (e->P.lookahead && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = CW_LA_PERIOD;
+    if (e->P.lookahead && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = e->la_period;
     const size_t row = (size_t)e->n * (action_dtype == CW_ACT_I32 ? 4 : action_dtype == CW_ACT_I64 ? 8 : 1);
     e->in_step_many = true;
     int rc = CW_OK;
