@@ -103,7 +103,7 @@ __device__ __forceinline__ u32x3 overlay_dwords(u32x3 d, uint32_t o)
 
 // render_edit (ray.py:522-557): repaint one cell of the persistent frame, one lane does 4 x 12 B
 __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell, uint32_t code,
-                                           bool agent_here, uint32_t hold, uint32_t div_magic)
+                                           bool agent_here, uint32_t hold, uint32_t div_magic, bool mark_rows_only = false)
 {
     const uint32_t r = __umulhi(cell, div_magic);
     const uint32_t c = cell - r * S;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
             uint32_t o = (dy == 2 && hold != 0) ? rgb_of_code(hold) : 0x00FFFFFFu;
             d = overlay_dwords(d, o);
         }
-        *(u32x3_a4 *)(p + dy * row_bytes) = d;
+        if (dy == 1 || dy == 2 || !mark_rows_only) *(u32x3_a4 *)(p + dy * row_bytes) = d;      // (rows 0, 3 never carry the mark)
     }
 }
 
@@ -315,6 +315,7 @@ struct CwStepOut {
     int reward;
     bool done, success, invalid, changed;
     uint32_t dirty0, dirty1;       // cells to repaint (render_edit): dirty1 = 0xFFFFFFFF if only one
+    bool mark0, mark1;             // only the agent's mark came or went in that cell (a move that left the cell's object as it was): pixel rows 1, 2 suffice
     uint32_t step_num, achieved, desired;
 };
 
@@ -339,6 +340,7 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
     const uint32_t code_here = code_of(codes, idx_here);
     o.dirty0 = cell;
     o.dirty1 = 0xFFFFFFFFu;
+    o.mark0 = o.mark1 = false;
 
     if (a == 4) {                                             // pickup, ray.py:314-327
         if (code_here >= STICKS && code_here <= HAMMER && hold == 0) {
@@ -369,6 +371,7 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
             if (!cant) {
                 changed = true;
                 o.dirty1 = ncell;
+                o.mark0 = true;                               // (what lies in the cell it leaves stays)
                 ar = nr; ac = nc;
                 old_obj = t;                                  // :411 (None when empty, :417-419)
                 uint32_t nw = t;
@@ -384,6 +387,7 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
                     }
                 }
                 cur_code = nw;
+                o.mark1 = nw == t;
             }
         }
         // eval_task_edit, ray.py:646-703 -- runs after every move action, failed ones included
@@ -452,9 +456,9 @@ __device__ __forceinline__ void paint_changed_cells(const CwParams &P, int env, 
         }
         alt_paint_strip(frame, P.size, hold, 0, 1, false);
     } else {
-        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic, o.mark0);
         if (o.dirty1 != 0xFFFFFFFFu)
-            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic, o.mark1);
     }
 }
 
@@ -1052,9 +1056,9 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
                         }
                         alt_paint_strip(frame, P.size, hold, 0, 1, false);
                     } else {
-                        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic);
+                        paint_cell(frame, P.size, o.dirty0, code_of(h.w, slot_at(sp, o.dirty0)), o.dirty0 == acell, hold, P.div_magic, o.mark0);
                         if (o.dirty1 != 0xFFFFFFFFu)
-                            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic);
+                            paint_cell(frame, P.size, o.dirty1, code_of(h.w, slot_at(sp, o.dirty1)), o.dirty1 == acell, hold, P.div_magic, o.mark1);
                     }
                 }
                 atomicAdd(&P.counters[0], 1ull);
@@ -1395,17 +1399,23 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                         if (at + 2u - a0 < win) dst_base[at + 2u] = (uint8_t)(p_val >> 16);
                     }
                 } else {
-                    // the object of this lane's slot: pixel row dy of its cell, 12 bytes R G B R | G B R G | B R G B (ray.py:476-481)
+                    // the object of this lane's slot: pixel row dy of its cell, 12 bytes R G B R | G B R G | B R G B (ray.py:476-481).  A row wholly
+                    // inside the piece leaves as ONE 12-byte store -- one write request to the L2 where three dword stores were three, and the L2's
+                    // request rate is what bounds the sweep of small frames (profiles/r04_clock.txt F) -- a row across the piece's edge dword by dword
                     const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
                     const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
                     const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
                     const u32x3 d = cell_row_dwords(rgb_of_code(code));
                     const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
-                    if (is_obj && seg - a0 < win) *(uint32_t *)(dst_base + seg) = d.x;
-                    if (is_obj && seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
-                    if (is_obj && seg + 8u - a0 < win) *(uint32_t *)(dst_base + seg + 8u) = d.z;
+                    const bool in0 = seg - a0 < win, in2 = seg + 8u - a0 < win;
+                    if (is_obj && in0 && in2) *(u32x3_a4 *)(dst_base + seg) = d;
+                    else if (is_obj) {
+                        if (in0) *(uint32_t *)(dst_base + seg) = d.x;
+                        if (seg + 4u - a0 < win) *(uint32_t *)(dst_base + seg + 4u) = d.y;
+                        if (in2) *(uint32_t *)(dst_base + seg + 8u) = d.z;
+                    }
                     // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
-                    // the colour of what it holds (ray.py:483-486)
+                    // the colour of what it holds (ray.py:483-486)   (carried by the object's own rows instead, it costs more than it saves: r04_clock.txt F)
                     const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
                     const uint32_t o = dy == 2u ? o2 : 0x00FFFFFFu;
                     const bool is_mark = frame_on && marks;
