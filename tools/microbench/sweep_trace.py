@@ -1,0 +1,42 @@
+"""GPU box: where a launch of the clocked sweep spends the time beside its schedule.  Needs a trace build of the library
+(git apply the patch quoted in profiles/r04_clock.txt H; make exp EXP=-DCW_EXP_SWEEP_TRACE=1 NAME=strace; CW_LIB_PATH=.../libcw_exp_strace.so):
+every wave leaves its entry time, the time its last store was issued and had drained, and what its clock forgave."""
+import ctypes as C
+import sys
+import numpy as np
+import torch
+from gym_craftingworld_amd import CraftingWorldVecEnv
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 21
+desync = len(sys.argv) > 3 and sys.argv[3] == 'desync'
+env = CraftingWorldVecEnv(n, size=(size, size), obs_mode='pixels', device='cuda:0')
+env.seed(0)
+env.reset()
+g = torch.Generator(device='cuda').manual_seed(1)
+acts = torch.randint(0, 6, (400, n), device='cuda', dtype=torch.int32, generator=g)
+if desync:
+    env.set_state(step_num=((np.arange(n) * 7) % 300).astype(np.int32))
+for t in range(250):
+    env.step_async(acts[t]); env.step_wait()
+torch.cuda.synchronize()
+period = env.tuner_state()['period16'] / 16.0            # ticks of 10 ns
+buf = (C.c_ulonglong * (1024 * 8))()
+for rep in range(5):
+    env.step_async(acts[300 + rep]); env.step_wait()
+    torch.cuda.synchronize()
+    assert env._lib.cwk_trace_read(buf) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+    t_in, t_issue, t_drain = a[:, 0], a[:, 2], a[:, 3]
+    n_forg, forg_sum, n_late, max_late = a[:, 4], a[:, 5] / 16.0, a[:, 6], a[:, 7] / 16.0
+    z = t_in.min()
+    frame_bytes = 48 * size * size
+    jobs = -(-(n * frame_bytes) // 4096)
+    q = -(-jobs // 1024)
+    print('launch %d: period %.1f ns, %d jobs per wave, schedule %.1f us' % (rep, period * 10, q, q * period / 100))
+    print('   entry   (after the first wave)    med %6.2f  max %6.2f us' % (np.median(t_in - z) / 100, (t_in - z).max() / 100))
+    print('   last store issued                 med %6.2f  min %6.2f  max %6.2f us' % (np.median(t_issue - z) / 100, (t_issue - z).min() / 100, (t_issue - z).max() / 100))
+    print('   drained                           med %6.2f  max %6.2f us   (drain itself: med %5.2f max %5.2f us)' %
+          (np.median(t_drain - z) / 100, (t_drain - z).max() / 100, np.median(t_drain - t_issue) / 100, (t_drain - t_issue).max() / 100))
+    print('   forgiven: events per wave med %d max %d; time per wave med %.2f max %.2f us; late starts per wave med %d; worst lateness med %.2f max %.2f us' %
+          (np.median(n_forg), n_forg.max(), np.median(forg_sum) / 100, forg_sum.max() / 100, np.median(n_late), np.median(max_late) / 100, max_late.max() / 100))
