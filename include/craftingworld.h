@@ -160,7 +160,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
  * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
  * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
  * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues the step kernel -- engines with auto_reset: finished envs take
- * over the record of their next episode, computed ahead of time by a refill kernel that rides on every 16th call; an env that finishes twice
+ * over the record of their next episode, computed ahead of time by a refill kernel that rides on every max_steps/4-th call (8 ... 64); an env that finishes twice
  * between two refills is reset on the spot -- and, in CW_OBS_PIXELS_FULL, the sweep that paints the observation array.
  * With cw_config.host_outputs `actions` may be cw_buffer_table.host_actions. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);

@@ -420,7 +420,7 @@ def test_single_env_facade_matches_golden():
 def test_step_captured_in_hip_graph(obs_mode):
     """One cw_step is a fixed launch sequence (no host-side state in kernel arguments), so it can be captured into a HIP graph and
     replayed: the replayed env must stay bit-identical to an eagerly stepped twin.  (A step captured on its own carries the look-ahead refill
-    with it -- cw_step sees the capture -- so the replayed env refills on every step where the eager one does on every 16th: same results.)"""
+    with it -- cw_step sees the capture -- so the replayed env refills on every step where the eager one does on every max_steps/4-th (8 ... 64): same results.)"""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     N, T, kw = 2048, 90, dict(size=(7, 7), max_steps=25)
     keys, pos = _np_states(N, 99)
@@ -954,7 +954,7 @@ def test_systematic_transition_table():
 @pytest.mark.parametrize('obs_mode,raster,N', [('state', 'ray', 1003), ('state', 'ray', 70001), ('pixels_dirty', 'ray', 5000),
                                                ('pixels_dirty', 'alt', 777), ('pixels', 'ray', 5000), ('pixels', 'alt', 777)])
 def test_lookahead_records_equal_the_slow_path(obs_mode, raster, N, monkeypatch):
-    """Engines that reset by themselves keep the outcome of every env's NEXT reset() ready (cw_refill_kernel, every 16 steps) and a finished
+    """Engines that reset by themselves keep the outcome of every env's NEXT reset() ready (cw_refill_kernel, every max_steps/4 steps, 8 ... 64) and a finished
     env takes it over inside the step kernel; an env that finishes again before the next refill is reset the slow way, on the spot.
     CW_TUNE_LOOKAHEAD=0 keeps no records at all.  Same seeds and actions, episodes of at most 17 steps ending on every step (so both ways are
     taken all the time): every buffer, counter and RNG stream must agree, with batch sizes that leave the last wavefront partly filled."""
@@ -1249,7 +1249,7 @@ def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
 @pytest.mark.gpu
 def test_full_frame_soak_equals_dirty_cell_engine(monkeypatch):
     """3 000 steps of 65 536 full-frame envs with the episode phases spread out (~220 envs finish on every step and take their look-ahead
-    records; the refill kernel runs every 16 steps): every 250 steps all three frames, and at the end results, counters and random
+    records; the refill kernel runs every max_steps/4 steps, 8 ... 64): every 250 steps all three frames, and at the end results, counters and random
     streams, must equal the dirty-cell engine's."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     N, T = 65536, 3000
