@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: A/B of throw-away builds (make exp NAME=x) against the product on a set of shapes -- r04_ab.sh "<lib names>" 
+# GPU box: A/B of throw-away builds (make exp NAME=x) against the product on a set of shapes -- r04_ab.sh "<lib names>"
 cd ${GRAFT_REPO_ROOT:-.}
 run() { label=$1; shift
   python bench.py --quick --steps 600 "$@" 2>/dev/null | python -c "
@@ -12,6 +12,9 @@ for V in $1; do
   run "65536 21x21"
   run "65536 21x21 desync" --desync
   run "131072 mixed desync" --envs-per-gpu 131072 --mixed-menus --desync
+  run "65536 32x32" --size 32
+  run "65536 alt 21x21" --raster alt
+  run "65536 alt 21x21 desync" --raster alt --desync
   run "65536 12x12" --size 12
   run "65536 8x8" --size 8 --max-steps 100
   run "262144 8x8" --size 8 --max-steps 100 --envs-per-gpu 262144
