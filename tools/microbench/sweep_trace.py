@@ -36,7 +36,8 @@ for rep in range(3):
     q = -(-jobs // 1024)
     print('launch %d: period %.1f ns, %d jobs per wave, schedule %.1f us' % (rep, period * 10, q, q * period / 100))
     print('   entry   (after the first wave)    med %6.2f  max %6.2f us' % (np.median(t_in - z) / 100, (t_in - z).max() / 100))
-    print('   first batch prepared (clock t0)   med %6.2f  max %6.2f us' % (np.median(t_t0 - z) / 100, (t_t0 - z).max() / 100))
+    if t_t0.any():                                        # (a build that stamps the end of the first batch's fetch)
+        print('   first batch prepared (clock t0)   med %6.2f  max %6.2f us' % (np.median(t_t0 - z) / 100, (t_t0 - z).max() / 100))
     print('   last store issued                 med %6.2f  min %6.2f  max %6.2f us' % (np.median(t_issue - z) / 100, (t_issue - z).min() / 100, (t_issue - z).max() / 100))
     print('   drained                           med %6.2f  max %6.2f us   (drain itself: med %5.2f max %5.2f us)' %
           (np.median(t_drain - z) / 100, (t_drain - z).max() / 100, np.median(t_drain - t_issue) / 100, (t_drain - t_issue).max() / 100))
