@@ -305,13 +305,12 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 }
 
 // The sweep's CLOCK (cw_kernels.hip: render_pieces): the period between two jobs of a wave, i.e. the RATE at which a launch writes --
-// waves x 4 KiB per period.  The memory system of an MI355X keeps up with 7.2 TB/s of such a stream (65 536 envs, 21x21: a period of 580 ns for
-// 1 024 waves, 0.2055 ms per launch, 0.86 of the 8 TB/s peak, the same with ~220 envs finishing on every step) and falls into its slower,
-// saturated regime just below that (560 ns: 0.214-0.235 ms, launch by launch); at 7.0 TB/s (600 ns) every launch reads 0.2112 +- 0.0005 ms
-// (profiles/r04_clock.txt); at 7.2 TB/s the synchronized case reads 0.2065 but launches with ~220 / ~440 finished envs per step turn erratic
-// (0.2129 average, 131 072 envs 0.436 against 0.415 at 7.0).  So: 7.0 TB/s, which cw_create checks against 6.8, 6.6 and the unclocked sweep on
-// the engine's own batch (20 launches each), and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep that does not keep its schedule
-// any more is slowed down a notch.
+// waves x 4 KiB per period.  In a row of back-to-back launches the memory system of an MI355X takes 7.0-7.2 TB/s of such a stream (65 536 envs,
+// 21x21, 1 024 waves: 599 ns 0.2105 ms per launch, 582 ns 0.2080, the same with ~220 envs finishing on every step; 0.84-0.85 of the 8 TB/s peak)
+// and falls into its slower, saturated regime just beyond (567 ns: 131 072 envs and the AltObs raster read 0.78 of the peak with the episode phases
+// spread out; 540 ns: erratic everywhere) -- profiles/r04_clock.txt C, F.  So cw_create tries 7.2, 7.0, 6.8, 6.6 TB/s and the unclocked sweep on
+// the engine's own batch (20 launches each) and takes the best 90th percentile, and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep
+// that does not keep its schedule any more is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can), CW_TUNE_PIECE_PACE the sleeps inside a job (eighths per store).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
 
@@ -330,8 +329,8 @@ static int calibrate_sweep(cw_engine *e)
     // the candidates, the fastest first; unclocked last (a sweep whose jobs take longer than any useful period -- several small frames per piece --
     // paces itself: the clock then only costs its reads).  The one with the best 90th-percentile launch: in its saturated regime the memory
     // system is slower AND erratic (7.5 TB/s: 0.214-0.235 ms launch by launch where 7.0 reads 0.2112 +- 0.0005), so the slow launches tell.
-    static const double rates[] = {7.0, 6.8, 6.6, 0.0};
-    char log[480] = "";
+    static const double rates[] = {7.2, 7.0, 6.8, 6.6, 0.0};
+    char log[600] = "";
     size_t len = 0;
     int rc = CW_OK;
     double best_p90 = 0, med = 0, p90 = 0;
