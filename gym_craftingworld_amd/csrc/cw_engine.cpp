@@ -305,49 +305,55 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 }
 
 // The sweep's CLOCK (cw_kernels.hip: render_pieces): the period between two jobs of a wave, i.e. the RATE at which a launch writes --
-// waves x 4 KiB per period.  In a row of back-to-back launches the memory system of an MI355X takes 7.0-7.2 TB/s of such a stream (65 536 envs,
-// 21x21, 1 024 waves: 599 ns 0.2105 ms per launch, 582 ns 0.2080, the same with ~220 envs finishing on every step; 0.84-0.85 of the 8 TB/s peak)
-// and falls into its slower, saturated regime just beyond (567 ns: 131 072 envs and the AltObs raster read 0.78 of the peak with the episode phases
-// spread out; 540 ns: erratic everywhere) -- profiles/r04_clock.txt C, F.  So cw_create tries 7.2, 7.0, 6.8, 6.6 TB/s and the unclocked sweep on
-// the engine's own batch (20 launches each) and takes the best 90th percentile, and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep
-// that does not keep its schedule any more is slowed down a notch.
-// CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can), CW_TUNE_PIECE_PACE the sleeps inside a job (eighths per store).
+// waves x 4 KiB per period.  In a row of back-to-back launches the memory system of an MI355X takes 7.2-7.4 TB/s of such a stream (65 536 envs,
+// 21x21, 1 024 waves: 582 ns 0.2049 ms per launch in step / 0.2054 with ~220 envs finishing on every step, 567 ns 0.2004 / 0.2032-0.2046: 0.86-0.88 of
+// the 8 TB/s peak) and falls into its slower, saturated regime just beyond (555 ns: 0.228 spread out; 131 072 envs spread out already at 567 ns: 0.435
+// against 0.406 at 582) -- profiles/r04_clock.txt K.  So cw_create tries 7.4, 7.2, 7.0, 6.8, 6.6 TB/s and the unclocked sweep on the engine's own
+// batch (20 launches each) and takes the best 90th percentile, and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep that does not keep
+// its schedule any more -- the steady state of a big batch at 7.4 -- is slowed down a notch.
+// CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
+// both periods of the clock from one rate: the sweep after a step on which envs finished runs CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
+static const double CW_BUSY_NOTCH = 0.2, CW_RATE_FLOOR = 5.4;
+static void set_sweep_rate(cw_engine *e, double tb_per_s)
+{
+    e->tune.period16 = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s) * 1.6 + 0.5) : 0;
+    e->tune.period16_busy = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s - CW_BUSY_NOTCH > CW_RATE_FLOOR ? tb_per_s - CW_BUSY_NOTCH : CW_RATE_FLOOR) * 1.6 + 0.5) : 0;
+}
 
 static int calibrate_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
-    if (const char *forced = getenv("CW_TUNE_PIECE_PACE")) tn.piece_pace = atoi(forced) < 0 ? 0 : atoi(forced) & 0xFF;
-    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) { tn.period16 = (int)(atof(per) * 1.6 + 0.5); return CW_OK; }
+    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) { tn.period16 = tn.period16_busy = (int)(atof(per) * 1.6 + 0.5); return CW_OK; }
     int n_chunks = 1, jobs_per_wave = 1;
     cwk_sweep_shape(&e->P, &tn, &n_chunks, &e->sweep_waves, &jobs_per_wave);
     e->sweep_jobs = (double)n_chunks * jobs_per_wave;
-    tn.period16 = (int)(sweep_period_ns(e, 7.0) * 1.6 + 0.5);
+    set_sweep_rate(e, 7.0);
     // (small batches are launch-bound: nothing to check; host-mapped frames are PCIe-bound: unclocked)
-    if (e->host_actions) { tn.period16 = 0; return CW_OK; }
+    if (e->host_actions) { set_sweep_rate(e, 0); return CW_OK; }
     if (e->obs_mode != CW_OBS_PIXELS_FULL || (double)e->n * e->P.frame_bytes < (double)(64ll << 20)) return CW_OK;
     // the candidates, the fastest first; unclocked last (a sweep whose jobs take longer than any useful period -- several small frames per piece --
     // paces itself: the clock then only costs its reads).  The one with the best 90th-percentile launch: in its saturated regime the memory
     // system is slower AND erratic (7.5 TB/s: 0.214-0.235 ms launch by launch where 7.0 reads 0.2112 +- 0.0005), so the slow launches tell.
-    static const double rates[] = {7.2, 7.0, 6.8, 6.6, 0.0};
-    char log[600] = "";
+    static const double rates[] = {7.4, 7.2, 7.0, 6.8, 6.6, 0.0};
+    char log[720] = "";
     size_t len = 0;
     int rc = CW_OK;
     double best_p90 = 0, med = 0, p90 = 0;
     rc = timed_render_stats(e, &med, &p90);           // (a card that idled through set-up runs its first launches a few per cent slower: not counted)
     // what a sweep costs beside its jobs (a launch's ramp and tail, the events around it), at a rate the memory system keeps up with easily: the guard's yardstick
-    tn.period16 = (int)(sweep_period_ns(e, 6.4) * 1.6 + 0.5);
+    set_sweep_rate(e, 6.4);
     if (rc == CW_OK) rc = timed_render_stats(e, &med, &p90);
     e->sweep_beside_ms = med - e->sweep_jobs * sweep_period_ns(e, 6.4) * 1e-6;
     const char *forced_rate = getenv("CW_TUNE_RATE_TBS");                      // (the starting rate, the guard stays on: the test that it slows a saturated sweep down)
     if (forced_rate && atof(forced_rate) > 0) { e->sweep_rate = atof(forced_rate); best_p90 = 1e-9; }
     for (size_t i = 0; i < sizeof(rates) / sizeof(rates[0]) && rc == CW_OK && !forced_rate; i++) {
-        tn.period16 = rates[i] > 0 ? (int)(sweep_period_ns(e, rates[i]) * 1.6 + 0.5) : 0;
+        set_sweep_rate(e, rates[i]);
         rc = timed_render_stats(e, &med, &p90);
         if (len < sizeof(log) - 48) len += (size_t)snprintf(log + len, sizeof(log) - len, " %.1f TB/s (%.0f ns): %.4f/%.4f |", rates[i], tn.period16 / 1.6, med, p90);
         if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; e->sweep_rate = rates[i]; }
     }
-    tn.period16 = e->sweep_rate > 0 ? (int)(sweep_period_ns(e, e->sweep_rate) * 1.6 + 0.5) : 0;
+    set_sweep_rate(e, e->sweep_rate);
     e->guard_on = rc == CW_OK && e->sweep_rate > 0 && e->auto_reset && !(getenv("CW_TUNE_GUARD") && atoi(getenv("CW_TUNE_GUARD")) == 0);
     if (e->guard_on)
         for (hipEvent_t &ev : e->guard_ev)
@@ -374,11 +380,11 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
         float ms = 0.f;
         e->guard_pending = false;
         if (hipEventElapsedTime(&ms, e->guard_ev[4], e->guard_ev[5]) == hipSuccess && ms > 0.f && e->guard_period16 == e->tune.period16) {
-            const double scheduled = e->sweep_jobs * (e->tune.period16 / 1.6) * 1e-6 + e->sweep_beside_ms;
+            const double scheduled = e->sweep_jobs * (e->tune.period16_busy / 1.6) * 1e-6 + e->sweep_beside_ms;      // (the slower of the two periods: a quiet step is early)
             e->guard_late = ms > 1.04 * scheduled ? e->guard_late + 1 : 0;
-            if (e->guard_late >= 3 && e->sweep_rate > 5.5) {
+            if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {
                 e->sweep_rate -= 0.2;
-                e->tune.period16 = (int)(sweep_period_ns(e, e->sweep_rate) * 1.6 + 0.5);
+                set_sweep_rate(e, e->sweep_rate);
                 e->guard_late = 0;
                 e->guard_slowdowns++;
                 if (getenv("CW_TUNE_VERBOSE"))
@@ -499,7 +505,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(achieved_out, N);
     ALLOC_OUT(desired_out, N);
     ALLOC_OUT(episode_length, N);
-    ALLOC(counters, 4);
+    ALLOC(counters, 8);
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
         ALLOC_OUT(desired_img, N * P.frame_bytes);
@@ -937,7 +943,7 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_tuner: null argument");
     out->period16 = e->tune.period16;
-    out->piece_pace = e->tune.piece_pace;
+    out->period16_busy = e->tune.period16_busy;
     out->lookahead = e->P.lookahead;
     out->resident = e->res ? 1 : 0;
     out->guard_slowdowns = e->guard_on ? e->guard_slowdowns : -1;

@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, uint8
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
 #define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/history/r03_pieces.txt G)
 #define CW_PIECE_STORES 4          // 1-KiB stores per piece
+#define CW_BUSY_FINISHED 16ull     // finished envs on a step from which the sweep runs at its second rate
 // the array's last, partial piece: zeros for [a0, a1), 16-byte chunks where a whole chunk fits, single bytes after it
 __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, uint32_t a0, uint32_t a1, int lane)
 {
@@ -1254,7 +1255,7 @@ __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, 
     }
 }
 template <int RASTER, int FPJ>
-__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int pace, int period16, int env_lo, int env_n)
+__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int period16, int env_lo, int env_n)
 {
     constexpr int JPB = CW_WAVE / FPJ;                                      // jobs per batch of records
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -1271,7 +1272,9 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     const uint32_t half = (uint32_t)lane >> 5, pl = (uint32_t)lane & 31u;
     // what lane pl paints.  AltObs: pl = pixel (0..7 object slots, 8 agent, 9 held item, 10..18 flag).  Ray: pl = 4 slot + pixel row.
     const uint32_t slot = RASTER == 1 ? (pl & 7u) : (pl >> 2), dy = pl & 3u;
-    const uint32_t v_cpv = cpv_color(lane & 15);                            // AltObs: lane k <= 8 holds CPV_COLORS[k]
+    // the colour tables, one entry per lane, read with ds_bpermute (a select chain is 24 instruction slots): AltObs CPV_COLORS[k] (altobs.py:26-27),
+    // Ray COLORS_N by cell code (ray.py:28-30)
+    const uint32_t v_cpv = cpv_color(lane & 15), v_rgb = rgb_of_code((uint32_t)lane & 15u);
     const uint32_t m_slot = (RASTER != 1 || pl < 8u) ? 0xFFFFFFFFu : 0u, m_agent = pl == 8u ? 0xFFFFFFFFu : 0u, m_held = pl == 9u ? 0xFFFFFFFFu : 0u;
     const uint32_t m_flag = (pl >= 10u && pl < 19u) ? 0xFFFFFFFFu : 0u;
     const uint32_t sh_pos = 16u * (slot & 1u), sh_item = 4u * slot;
@@ -1281,11 +1284,9 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     const uint32_t off_flag = (3u * S + fjr) * row_bytes + 9u + 3u * (fj - 3u * fjr);      // AltObs lanes pl 10..18: the strip's nine flag pixels
     const bool marks = slot == 0u && (dy == 1u || dy == 2u);                 // Ray: the lanes that paint the agent's mark
     __builtin_amdgcn_s_setprio(3);
-    // PACING.  The write path is LESS efficient saturated than kept just short of saturation (profiles/history/r02_render_linear.txt), and an
-    // unpaced sweep's rate is whatever its waves' instruction streams happen to produce: a few clocks per job -- another code placement, two
-    // more instructions -- moved rounds 2-3's sweeps between 0.83 and 0.70 of the HBM peak.  So the rate is SET (the clock below); `pace`
-    // (eighths of an s_sleep(1) per 1-KiB store inside a job) only spreads a job's four stores.
-    int owed = 0;
+    // A JOB'S INSTRUCTIONS COUNT.  One wave per SIMD issues an instruction every ~5 clocks, and a job of ~170 instructions is ~590 ns of a wave's time:
+    // about the period the memory system takes (580 ns at 7.2 TB/s).  A dozen instructions less per job moved the sweep from 0.846 to 0.858 of the
+    // peak at that clock and let it follow a faster one (profiles/r04_clock.txt K): hence the colour table, the 24-bit multiplies and the 32-bit clock.
     struct Rec { int f; uint32_t hx, hw, o2; uint4 p; };               // (hx: agent row | col << 8 | hold << 16; o2, Ray: the colour of row 2 of the agent's mark)
     auto fetch = [&](int base) {
         Rec r;
@@ -1321,12 +1322,11 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     // THE CLOCK.  period16 != 0: job k of a wave starts no earlier than t0 + k x period (period16 = the period in 1/16 of a 10-ns tick of the
     // constant 100-MHz clock, s_memrealtime), the waves' t0 spread evenly over one period: the launch's stores leave as ONE smooth stream at a
     // set rate -- bytes per second = waves x 4 KiB / period -- instead of at whatever rate the waves' instruction streams happen to produce.
-    long long t_next16 = ((long long)__builtin_amdgcn_s_memrealtime() << 4) + ((long long)wave * period16) / n_waves;
+    uint32_t t_next16 = ((uint32_t)__builtin_amdgcn_s_memrealtime() << 4) + (uint32_t)(((long long)wave * period16) / n_waves);      // (32 bits of it: 2.7 s)
     for (int base = 0; base < q_mine; base += JPB) {
         const Rec cur = nxt;
         if (base + JPB < q_mine) nxt = fetch(base + JPB);
         const int in_batch = min(q_mine - base, JPB);
-        const int pace_now = pace & 0xFF;
         for (int k = 0; k < in_batch; k++) {
             const int f0 = __builtin_amdgcn_readlane(cur.f, FPJ * k);         // the piece's first frame
             if (f0 < 0) continue;                                             // (past the last job)
@@ -1348,21 +1348,19 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
             };
             if (RASTER != 1) gather(0);
             if (period16) {                                                   // ---- the job's slot (THE CLOCK above)
-                const long long now16 = (long long)__builtin_amdgcn_s_memrealtime() << 4, wait16 = t_next16 - now16;
+                const uint32_t now16 = (uint32_t)__builtin_amdgcn_s_memrealtime() << 4;
+                const int wait16 = (int)(t_next16 - now16);
                 if (wait16 > 0) {
-                    for (int z = (int)((wait16 * 5) >> 8); z > 0; z--) __builtin_amdgcn_s_sleep(1);       // (64 clocks each: a little short of the slot ...)
-                    while (((long long)__builtin_amdgcn_s_memrealtime() << 4) < t_next16) { }              // (... the rest on the clock)
-                } else if (wait16 < -(long long)period16) t_next16 = now16 - period16;                     // fell behind by more than a job: the debt is forgiven
-                t_next16 += period16;
+                    for (int z = (wait16 * 5) >> 8; z > 0; z--) __builtin_amdgcn_s_sleep(1);               // (64 clocks each: a little short of the slot ...)
+                    while ((int)(t_next16 - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 4)) > 0) { }    // (... the rest on the clock)
+                } else if (wait16 < -period16) t_next16 = now16 - (uint32_t)period16;                      // fell behind by more than a job: the debt is forgiven
+                t_next16 += (uint32_t)period16;
             }
             // ---- the fill
             uint8_t *const job = dst_base + a0;
             if (win == CW_PIECE) {
 #pragma unroll
-                for (int s = 0; s < CW_PIECE_STORES; s++) {
-                    *(uint4 *)(job + 1024 * s + 16 * lane) = make_uint4(0, 0, 0, 0);
-                    for (owed += pace_now; owed >= 8; owed -= 8) __builtin_amdgcn_s_sleep(1);  // (PACING above)
-                }
+                for (int s = 0; s < CW_PIECE_STORES; s++) *(uint4 *)(job + 1024 * s + 16 * lane) = make_uint4(0, 0, 0, 0);
             } else piece_fill_partial(dst_base, a0, a1, lane);
             // ---- the lit items of the piece's frames, a pair at a time (branch-free: colours from select chains / the table register)
 #pragma unroll
@@ -1370,17 +1368,17 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                 if (FPJ > 2 && pair > 0 && ((uint32_t)f0 + 2u * pair >= (uint32_t)env_n || ((uint32_t)f0 + 2u * pair) * FB >= a1)) break;   // (wave-uniform)
                 if (RASTER == 1 || pair > 0) gather(pair);
                 const uint32_t fi = (uint32_t)f0 + 2u * (uint32_t)pair + half;      // this half's frame
-                const uint32_t f_base = fi * FB;
+                const uint32_t f_base = __umul24(fi, FB);                             // (24-bit operands throughout: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter)
                 const bool frame_on = fi < (uint32_t)env_n && f_base < a1;
                 const uint32_t hold = (hx >> 16) & 0xFFu;
                 if (RASTER == 1) {
-                    const uint32_t agent_cell = (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu);
+                    const uint32_t agent_cell = __umul24(hx & 0xFFu, S) + ((hx >> 8) & 0xFFu);
                     // pl 0..7: object slots; 8: the agent, pixel 8 (altobs.py:536); 9: the held item, on its own object pixel at the agent's cell
                     const uint32_t pos = (((pd >> sh_pos) & 0xFFFFu) & m_slot) | (agent_cell & ~m_slot);
                     const uint32_t item = (((hw >> sh_item) & 15u) & m_slot) | (9u & m_agent) | (hold & m_held);
-                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S, kk = item - 1u;
+                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - __umul24(r, S), kk = item - 1u;
                     const uint32_t k3 = (kk >= 6u) ? 2u : (kk >= 3u) ? 1u : 0u;
-                    const uint32_t off_obj = (3u * r + k3) * row_bytes + 9u * c + 3u * (kk - 3u * k3);
+                    const uint32_t off_obj = __umul24(3u * r + k3, row_bytes) + 9u * c + 3u * (kk - 3u * k3);
                     const uint32_t col_obj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((kk & 15u) << 2), (int)v_cpv);      // (a select chain here compiles to branches)
                     const bool is_obj = (m_flag == 0u) && pl < 10u && item != 0 && pos < (uint32_t)P.ncell;
                     const bool is_flag = (m_flag & hold) != 0;                            // the strip's flag (altobs.py:557-559)
@@ -1403,9 +1401,10 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                     // inside the piece leaves as ONE 12-byte store -- one write request to the L2 where three dword stores were three, and the L2's
                     // request rate is what bounds the sweep of small frames (profiles/r04_clock.txt F) -- a row across the piece's edge dword by dword
                     const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
-                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - r * S;
-                    const uint32_t seg = f_base + (4u * r + dy) * row_bytes + 12u * c;
-                    const u32x3 d = cell_row_dwords(rgb_of_code(code));
+                    const uint32_t rgb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_rgb);
+                    const uint32_t r = __umulhi(pos, P.div_magic), c = pos - __umul24(r, S);
+                    const uint32_t seg = f_base + __umul24(4u * r + dy, row_bytes) + 12u * c;
+                    const u32x3 d = cell_row_dwords(rgb);
                     const bool is_obj = frame_on && code != 0 && pos < (uint32_t)P.ncell;
                     const bool in0 = seg - a0 < win, in2 = seg + 8u - a0 < win;
                     if (is_obj && in0 && in2) *(u32x3_a4 *)(dst_base + seg) = d;
@@ -1416,7 +1415,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                     }
                     // the agent's mark, over the object it stands on or the black floor: pixels 1, 2 of rows 1, 2 of its cell -- white, and in row 2
                     // the colour of what it holds (ray.py:483-486)   (carried by the object's own rows instead, it costs more than it saves: r04_clock.txt F)
-                    const uint32_t aseg = f_base + (4u * (hx & 0xFFu) + dy) * row_bytes + 12u * ((hx >> 8) & 0xFFu);
+                    const uint32_t aseg = f_base + __umul24(4u * (hx & 0xFFu) + dy, row_bytes) + 12u * ((hx >> 8) & 0xFFu);
                     const uint32_t o = dy == 2u ? o2 : 0x00FFFFFFu;
                     const bool is_mark = frame_on && marks;
                     if (is_mark && aseg - a0 < win) dst_base[aseg + 3u] = (uint8_t)o;
@@ -1428,9 +1427,17 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     }
 }
 template <int RASTER, int FPJ>
-__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int pace, int period16, int env_lo, int env_n)
+__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int period16, int period16_busy, int last_chunk,
+                                                               int env_lo, int env_n)
 {
-    render_pieces<RASTER, FPJ>(P, frames, src, pace, period16, env_lo, env_n);
+    // TWO RATES.  On a step on which envs finished, the step kernel has just written their INIT_OBS / desired_goal frames (the steady state of a
+    // policy that finishes episodes: ~220 envs, 9 MB, on EVERY step), and the write path takes a notch less from the sweep that follows than on a
+    // quiet step (7.4 TB/s: 0.88 of the peak quiet, 0.77-0.87 box by box after such a step; 7.2: 0.86 either way -- profiles/r04_clock.txt K).
+    // The sweep of the observation array sees it for itself: the engine's count of finished envs against what the last such sweep saw.
+    const unsigned long long done_now = P.counters[1];
+    const bool busy = src != CW_SRC_CURRENT || done_now - P.counters[4] >= CW_BUSY_FINISHED;
+    render_pieces<RASTER, FPJ>(P, frames, src, __builtin_amdgcn_readfirstlane(busy ? period16_busy : period16), env_lo, env_n);
+    if (src == CW_SRC_CURRENT && last_chunk && blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = done_now;      // (every wave has read it long ago)
 }
 
 // ------------------------------------------------------------------------------------ exports
@@ -1640,7 +1647,7 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int);
+typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int);
 static CwSweepKernel cw_sweep_kernel(int raster, int fpj)
 {
     if (raster == 1) return fpj <= 2 ? cw_render_pieces_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_kernel<1, 8> : cw_render_pieces_kernel<1, 16>;
@@ -1655,7 +1662,7 @@ static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *fram
     for (int c = 0; c < n_chunks; c++) {
         const int env_n = min(per, P.n_envs - c * per);
         const long long pieces = ((long long)env_n * P.frame_bytes + CW_PIECE - 1) / CW_PIECE;
-        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.piece_pace, tn.period16, c * per, env_n);
+        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.period16, tn.period16_busy, c == n_chunks - 1 ? 1 : 0, c * per, env_n);
     }
 }
 

@@ -43,7 +43,7 @@ struct CwMenuDev {
 struct CwTuning {
     int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
     int period16 = 0;               // the sweep's CLOCK: a wave's jobs (4-KiB pieces) start one period apart; in 1/16 of a 10-ns tick of the 100-MHz clock (0: unclocked)
-    int piece_pace = 0;             // ... and eighths of an s_sleep(1) per 1-KiB store inside a job
+    int period16_busy = 0;          // ... on a step on which envs finished (their frames were written just before the sweep: the write path takes a notch less then)
     int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
                                     // 131 072 envs at 21x21 (0: one launch whatever the batch)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
@@ -97,7 +97,7 @@ struct CwParams {
     int32_t *refill_list;    // [N] envs whose record was taken since the last refill (each at most once)
     int32_t *refill_count;   // [2] entries, release ticket
     int32_t lookahead;       // 0: no records are kept (engines without auto-reset, host-mapped engines, CW_TUNE_LOOKAHEAD=0)
-    unsigned long long *counters; // [4]
+    unsigned long long *counters; // [4] steps, finished, successes, invalid actions (+ [4]: the finished count the last sweep of the observation array saw)
     const CwMenuDev *menus;
     // constants
     int32_t n_envs;

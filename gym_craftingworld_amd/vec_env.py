@@ -519,10 +519,9 @@ class CraftingWorldVecEnv:
         return {k: getattr(p, k) for k, _ in p._fields_}
 
     def tuner_state(self):
-        """What the engine's tuning holds right now (full-frame mode; performance only): dict with `piece_pace` (the sweep's pace in eighths of
-        a sleep per 1-KiB store), `pace_beside` (quarter-sleeps more on steps on which >= 32 envs finished) and `pace_beside_tuned` (1: cw_step
-        tunes it online), `guard_state` (-1 off, 0 watching, 1 trial, 2 the paced sweep was kept, 3 opening survey), `guard_trials`, `lookahead`
-        (1: the outcome of every env's next reset() is computed ahead of time)."""
+        """What the engine's tuning holds right now (full-frame mode; performance only): dict with `period16` (the period of the sweep's clock in
+        1/16 of a 10-ns tick, 0: unclocked; `period16_busy`: on a step on which envs finished), `lookahead` (1: the outcome of every env's next reset() is computed ahead of time), `resident` (1: the
+        N=1 doorbell stepper is available) and `guard_slowdowns` (how often the clock's guard has lowered the rate; -1: no guard)."""
         t = L.cw_tuner_state()
         L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner', self._lib)
         return {k: int(getattr(t, k)) for k, _ in t._fields_}

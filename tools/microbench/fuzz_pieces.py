@@ -14,7 +14,7 @@ for case in range(n_cases):
     N = int(min(rng.choice([1, 2, 3, 7, 64, 65, 333, 1000, 1024, 1025, 4099, 9000, 20000]), (1 << 30) // fb))
     max_steps = int(rng.choice([3, 5, 7, 11, 19]))
     os.environ['CW_TUNE_PERIOD_NS'] = str(int(rng.choice([0, 300, 600, 2000])))
-    os.environ['CW_TUNE_PIECE_PACE'] = str(int(rng.choice([0, 1, 4])))
+    rng.choice([0, 1, 4])                                   # (a draw of the first runs' seeds: the pace inside a job, a knob that is gone)
     os.environ['CW_TUNE_LOOKAHEAD'] = str(int(rng.rand() < 0.8))
     if rng.rand() < 0.4:
         os.environ['CW_TUNE_RENDER_CHUNK_ROUNDS'] = '1'
@@ -41,8 +41,8 @@ for case in range(n_cases):
     kf, pf = full.get_rng_states(); kd, pd = dirty.get_rng_states()
     if not (np.array_equal(kf, kd) and np.array_equal(pf, pd)): ok = False
     bad += not ok
-    print('%3d %s %-4s S=%-3d N=%-5d max_steps=%-2d chunked=%s period=%s pace=%s lookahead=%s' % (case, 'ok ' if ok else 'BAD', raster, S, N, max_steps,
-          'CW_TUNE_RENDER_CHUNK_ROUNDS' in os.environ, os.environ['CW_TUNE_PERIOD_NS'], os.environ['CW_TUNE_PIECE_PACE'], os.environ['CW_TUNE_LOOKAHEAD']), flush=True)
+    print('%3d %s %-4s S=%-3d N=%-5d max_steps=%-2d chunked=%s period=%s lookahead=%s' % (case, 'ok ' if ok else 'BAD', raster, S, N, max_steps,
+          'CW_TUNE_RENDER_CHUNK_ROUNDS' in os.environ, os.environ['CW_TUNE_PERIOD_NS'], os.environ['CW_TUNE_LOOKAHEAD']), flush=True)
     full.close(); dirty.close()
 print('cases', n_cases, 'bad', bad)
 sys.exit(1 if bad else 0)
