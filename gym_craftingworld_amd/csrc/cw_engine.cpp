@@ -313,8 +313,10 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 // its schedule any more -- the steady state of a big batch at 7.4 -- is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
-// both periods of the clock from one rate: the sweep after a step on which envs finished runs CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
-static const double CW_BUSY_NOTCH = 0.2, CW_RATE_FLOOR = 5.4;
+// both periods of the clock from one rate: after a step on which envs finished a launch's first CW_HEAD_JOBS jobs run CW_BUSY_NOTCH slower
+// (cw_render_pieces_kernel)
+static const double CW_BUSY_NOTCH = 0.7, CW_RATE_FLOOR = 5.4;
+static const int CW_HEAD_JOBS_HOST = 64;
 static void set_sweep_rate(cw_engine *e, double tb_per_s)
 {
     e->tune.period16 = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s) * 1.6 + 0.5) : 0;
@@ -380,7 +382,8 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
         float ms = 0.f;
         e->guard_pending = false;
         if (hipEventElapsedTime(&ms, e->guard_ev[4], e->guard_ev[5]) == hipSuccess && ms > 0.f && e->guard_period16 == e->tune.period16) {
-            const double scheduled = e->sweep_jobs * (e->tune.period16_busy / 1.6) * 1e-6 + e->sweep_beside_ms;      // (the slower of the two periods: a quiet step is early)
+            const double scheduled = (e->sweep_jobs * (e->tune.period16 / 1.6) + CW_HEAD_JOBS_HOST * ((e->tune.period16_busy - e->tune.period16) / 1.6)) * 1e-6 +
+                                     e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
             e->guard_late = ms > 1.04 * scheduled ? e->guard_late + 1 : 0;
             if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {
                 e->sweep_rate -= 0.2;

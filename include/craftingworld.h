@@ -255,7 +255,8 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
 const char *cw_render_kernel_name(const cw_engine *e);
 
 /* What the engine's tuning holds (full-frame mode): the period of the sweep's clock -- a wave starts a 4-KiB piece every
- * period16 / 16 ticks of the 100-MHz clock, 0: unclocked; period16_busy on a step on which envs finished --, and whether the engine
+ * period16 / 16 ticks of the 100-MHz clock, 0: unclocked; period16_busy: the period of a launch's first 64 jobs after a step on which envs
+ * finished --, and whether the engine
  * keeps look-ahead records (cw_config.auto_reset, device-resident outputs); `resident`: 1 if cw_step_resident can be used on this engine;
  * guard_slowdowns: how often the clock's guard has lowered the rate because sweeps stopped keeping their schedule (-1: no guard).
  * Only performance depends on any of it. */
