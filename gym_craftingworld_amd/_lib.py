@@ -61,7 +61,8 @@ class cw_profile(C.Structure):
 
 
 class cw_tuner_state(C.Structure):
-    _fields_ = [('period16', C.c_int32), ('period16_busy', C.c_int32), ('lookahead', C.c_int32), ('resident', C.c_int32), ('guard_slowdowns', C.c_int32)]
+    _fields_ = [('period16', C.c_int32), ('period16_head', C.c_int32), ('period16_busy', C.c_int32), ('lookahead', C.c_int32), ('resident', C.c_int32),
+                ('guard_slowdowns', C.c_int32)]
 
 
 # every symbol include/craftingworld.h declares: name -> (restype, argtypes)

@@ -313,23 +313,29 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 // its schedule any more -- the steady state of a big batch at 7.4 -- is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
-// both periods of the clock from one rate: after a step on which envs finished a launch's first CW_HEAD_JOBS jobs run CW_BUSY_NOTCH slower
-// (cw_render_pieces_kernel)
-static const double CW_BUSY_NOTCH = 0.7, CW_RATE_FLOOR = 5.4;
+// the clock's three periods from one rate: a launch's first CW_HEAD_JOBS jobs run CW_HEAD_NOTCH slower, after a step on which envs finished
+// CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
+static const double CW_HEAD_NOTCH = 0.4, CW_BUSY_NOTCH = 0.75, CW_RATE_FLOOR = 5.0;
 static const int CW_HEAD_JOBS_HOST = 64;
 static void set_sweep_rate(cw_engine *e, double tb_per_s)
 {
     e->tune.period16 = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s) * 1.6 + 0.5) : 0;
+    e->tune.period16_head = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s - CW_HEAD_NOTCH > CW_RATE_FLOOR ? tb_per_s - CW_HEAD_NOTCH : CW_RATE_FLOOR) * 1.6 + 0.5) : 0;
     e->tune.period16_busy = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s - CW_BUSY_NOTCH > CW_RATE_FLOOR ? tb_per_s - CW_BUSY_NOTCH : CW_RATE_FLOOR) * 1.6 + 0.5) : 0;
 }
 
 static int calibrate_sweep(cw_engine *e)
 {
     CwTuning &tn = e->tune;
-    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) { tn.period16 = tn.period16_busy = (int)(atof(per) * 1.6 + 0.5); return CW_OK; }
     int n_chunks = 1, jobs_per_wave = 1;
     cwk_sweep_shape(&e->P, &tn, &n_chunks, &e->sweep_waves, &jobs_per_wave);
     e->sweep_jobs = (double)n_chunks * jobs_per_wave;
+    if (const char *per = getenv("CW_TUNE_PERIOD_NS")) {                         // (the heads keep their distance: a forced 545 ns is 7.7 TB/s with 7.3 / 6.95 heads)
+        const double ns = atof(per);
+        set_sweep_rate(e, ns > 0 ? (double)e->sweep_waves * 4096.0 / (ns * 1e-9) * 1e-12 : 0.0);
+        if (ns > 0) tn.period16 = (int)(ns * 1.6 + 0.5);
+        return CW_OK;
+    }
     set_sweep_rate(e, 7.0);
     // (small batches are launch-bound: nothing to check; host-mapped frames are PCIe-bound: unclocked)
     if (e->host_actions) { set_sweep_rate(e, 0); return CW_OK; }
@@ -337,8 +343,8 @@ static int calibrate_sweep(cw_engine *e)
     // the candidates, the fastest first; unclocked last (a sweep whose jobs take longer than any useful period -- several small frames per piece --
     // paces itself: the clock then only costs its reads).  The one with the best 90th-percentile launch: in its saturated regime the memory
     // system is slower AND erratic (7.5 TB/s: 0.214-0.235 ms launch by launch where 7.0 reads 0.2112 +- 0.0005), so the slow launches tell.
-    static const double rates[] = {7.4, 7.2, 7.0, 6.8, 6.6, 0.0};
-    char log[720] = "";
+    static const double rates[] = {7.7, 7.4, 7.2, 7.0, 6.8, 6.6, 0.0};
+    char log[840] = "";
     size_t len = 0;
     int rc = CW_OK;
     double best_p90 = 0, med = 0, p90 = 0;
@@ -946,6 +952,7 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
 {
     if (!e || !out) return fail(CW_ERR_INVALID, "cw_tuner: null argument");
     out->period16 = e->tune.period16;
+    out->period16_head = e->tune.period16_head;
     out->period16_busy = e->tune.period16_busy;
     out->lookahead = e->P.lookahead;
     out->resident = e->res ? 1 : 0;

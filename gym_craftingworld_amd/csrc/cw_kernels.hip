@@ -1244,8 +1244,8 @@ __global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, uint8
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
 #define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/history/r03_pieces.txt G)
 #define CW_PIECE_STORES 4          // 1-KiB stores per piece
-#define CW_BUSY_FINISHED 16ull     // finished envs on a step from which the sweep that follows starts at its second rate ...
-#define CW_HEAD_JOBS 64            // ... for this many jobs of every wave (~40 us)
+#define CW_HEAD_JOBS 64            // the jobs of every wave at a launch's start that run a notch slower (~40 us) ...
+#define CW_BUSY_FINISHED 16ull     // ... two notches after a step on which at least this many envs finished
 // the array's last, partial piece: zeros for [a0, a1), 16-byte chunks where a whole chunk fits, single bytes after it
 __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, uint32_t a0, uint32_t a1, int lane)
 {
@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
                     for (int z = (wait16 * 5) >> 8; z > 0; z--) __builtin_amdgcn_s_sleep(1);               // (64 clocks each: a little short of the slot ...)
                     while ((int)(t_next16 - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 4)) > 0) { }    // (... the rest on the clock)
                 } else if (wait16 < -period16) t_next16 = now16 - (uint32_t)period16;                      // fell behind by more than a job: the debt is forgiven
-                t_next16 += (uint32_t)(period16 + (base + k < CW_HEAD_JOBS ? head_extra16 : 0));      // (TWO RATES, cw_render_pieces_kernel)
+                t_next16 += (uint32_t)(period16 + (base + k < CW_HEAD_JOBS ? head_extra16 : 0));      // (THE HEAD, cw_render_pieces_kernel)
             }
             // ---- the fill
             uint8_t *const job = dst_base + a0;
@@ -1428,17 +1428,18 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     }
 }
 template <int RASTER, int FPJ>
-__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int period16, int period16_busy, int chunk,
-                                                               int env_lo, int env_n)
+__global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int period16, int period16_head, int period16_busy,
+                                                               int chunk, int env_lo, int env_n)
 {
-    // TWO RATES.  On a step on which envs finished, the step kernel has just written their INIT_OBS / desired_goal frames (the steady state of a
-    // policy that finishes episodes: ~220 envs, 9 MB, on EVERY step), and for its first ~40 us the sweep that follows gets a notch less through the
-    // write path than on a quiet step: at 7.4 TB/s from its first job it reads 0.77-0.87 of the peak box by box, with its first CW_HEAD_JOBS jobs
-    // at 6.7 TB/s 0.86-0.88 (profiles/r04_clock.txt K, L).  The sweep of the observation array sees for itself what kind of step it follows: the
-    // engine's count of finished envs against what the last such sweep saw.  (chunk: bit 0 the step's first launch, bit 1 its last.)
+    // THE HEAD.  What the write path takes from a launch it does not take from its first microseconds: started at its full rate a 7.7-TB/s sweep
+    // falls into the saturated regime (0.78 of the peak) and stays there; with the first CW_HEAD_JOBS jobs of every wave (~40 us) a notch slower it
+    // holds 7.7 for the rest (0.89).  After a step on which envs finished -- the step kernel has just written their INIT_OBS / desired_goal frames:
+    // the steady state of a policy that finishes episodes, ~220 envs, 9 MB, on EVERY step -- the head has to be slower still (profiles/r04_clock.txt
+    // K-M).  The sweep of the observation array sees for itself what kind of step it follows: the engine's count of finished envs against what the
+    // last such sweep saw.  (chunk: bit 0 the step's first launch -- the others follow a sweep and need no head --, bit 1 its last.)
     const unsigned long long done_now = P.counters[1];
     const bool busy = src != CW_SRC_CURRENT || done_now - P.counters[4] >= CW_BUSY_FINISHED;
-    render_pieces<RASTER, FPJ>(P, frames, src, period16, __builtin_amdgcn_readfirstlane(busy && (chunk & 1) ? period16_busy - period16 : 0), env_lo, env_n);
+    render_pieces<RASTER, FPJ>(P, frames, src, period16, __builtin_amdgcn_readfirstlane((chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n);
     if (src == CW_SRC_CURRENT && (chunk & 2) && blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = done_now;      // (every wave has read it long ago)
 }
 // ------------------------------------------------------------------------------------ exports
@@ -1648,7 +1649,7 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
-typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int);
+typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int, int);
 static CwSweepKernel cw_sweep_kernel(int raster, int fpj)
 {
     if (raster == 1) return fpj <= 2 ? cw_render_pieces_kernel<1, 2> : fpj <= 4 ? cw_render_pieces_kernel<1, 4> : fpj <= 8 ? cw_render_pieces_kernel<1, 8> : cw_render_pieces_kernel<1, 16>;
@@ -1663,7 +1664,7 @@ static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *fram
     for (int c = 0; c < n_chunks; c++) {
         const int env_n = min(per, P.n_envs - c * per);
         const long long pieces = ((long long)env_n * P.frame_bytes + CW_PIECE - 1) / CW_PIECE;
-        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.period16, tn.period16_busy, (c == 0 ? 1 : 0) | (c == n_chunks - 1 ? 2 : 0), c * per, env_n);
+        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.period16, tn.period16_head, tn.period16_busy, (c == 0 ? 1 : 0) | (c == n_chunks - 1 ? 2 : 0), c * per, env_n);
     }
 }
 

@@ -43,8 +43,8 @@ struct CwMenuDev {
 struct CwTuning {
     int n_cu = 256;                 // compute units of the engine's device (hipDeviceProp_t::multiProcessorCount, set by cw_create)
     int period16 = 0;               // the sweep's CLOCK: a wave's jobs (4-KiB pieces) start one period apart; in 1/16 of a 10-ns tick of the 100-MHz clock (0: unclocked)
-    int period16_busy = 0;          // ... of a launch's first 64 jobs after a step on which envs finished (their frames were written just before the sweep:
-                                    // the write path takes a notch less for ~40 us)
+    int period16_head = 0;          // ... of a launch's first 64 jobs (the write path takes a notch less from a launch's first ~40 us) ...
+    int period16_busy = 0;          // ... and of those after a step on which envs finished (their frames were written just before the sweep)
     int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
                                     // 131 072 envs at 21x21 (0: one launch whatever the batch)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels

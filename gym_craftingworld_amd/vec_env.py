@@ -520,7 +520,7 @@ class CraftingWorldVecEnv:
 
     def tuner_state(self):
         """What the engine's tuning holds right now (full-frame mode; performance only): dict with `period16` (the period of the sweep's clock in
-        1/16 of a 10-ns tick, 0: unclocked; `period16_busy`: of a launch's first 64 jobs after a step on which envs finished), `lookahead` (1: the outcome of every env's next reset() is computed ahead of time), `resident` (1: the
+        1/16 of a 10-ns tick, 0: unclocked; `period16_head`: of a launch's first 64 jobs, `period16_busy`: of those after a step on which envs finished), `lookahead` (1: the outcome of every env's next reset() is computed ahead of time), `resident` (1: the
         N=1 doorbell stepper is available) and `guard_slowdowns` (how often the clock's guard has lowered the rate; -1: no guard)."""
         t = L.cw_tuner_state()
         L.check(self._lib.cw_tuner(self._h, C.byref(t)), 'cw_tuner', self._lib)

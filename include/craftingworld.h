@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, period16_busy, lookahead, resident, guard_slowdowns}; one painter, look-ahead records */
+#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, period16_head, period16_busy, lookahead, resident, guard_slowdowns}; one painter, look-ahead records */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -255,13 +255,13 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
 const char *cw_render_kernel_name(const cw_engine *e);
 
 /* What the engine's tuning holds (full-frame mode): the period of the sweep's clock -- a wave starts a 4-KiB piece every
- * period16 / 16 ticks of the 100-MHz clock, 0: unclocked; period16_busy: the period of a launch's first 64 jobs after a step on which envs
- * finished --, and whether the engine
+ * period16 / 16 ticks of the 100-MHz clock, 0: unclocked; period16_head: the period of a launch's first 64 jobs, period16_busy: of those after a
+ * step on which envs finished --, and whether the engine
  * keeps look-ahead records (cw_config.auto_reset, device-resident outputs); `resident`: 1 if cw_step_resident can be used on this engine;
  * guard_slowdowns: how often the clock's guard has lowered the rate because sweeps stopped keeping their schedule (-1: no guard).
  * Only performance depends on any of it. */
 typedef struct cw_tuner_state {
-    int32_t period16, period16_busy, lookahead, resident, guard_slowdowns;
+    int32_t period16, period16_head, period16_busy, lookahead, resident, guard_slowdowns;
 } cw_tuner_state;
 int cw_tuner(const cw_engine *e, cw_tuner_state *out);
 
