@@ -1438,8 +1438,12 @@ __global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8
     // K-M).  The sweep of the observation array sees for itself what kind of step it follows: the engine's count of finished envs against what the
     // last such sweep saw.  (chunk: bit 0 the step's first launch -- the others follow a sweep and need no head --, bit 1 its last.)
     const unsigned long long done_now = P.counters[1];
-    const bool busy = src != CW_SRC_CURRENT || done_now - P.counters[4] >= CW_BUSY_FINISHED;
-    render_pieces<RASTER, FPJ>(P, frames, src, period16, __builtin_amdgcn_readfirstlane((chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n);
+    const unsigned long long finished = src == CW_SRC_CURRENT ? done_now - P.counters[4] : (unsigned long long)P.n_envs;
+    const bool busy = finished >= CW_BUSY_FINISHED, storm = finished * 8ull >= (unsigned long long)P.n_envs;
+    // (after a step on which an eighth of the batch or more finished -- the all-env time-out step wrote two frames per env, 2.8 GB -- and for the
+    //  INIT_OBS / desired_goal arrays of a reset the whole launch runs at the busy head's rate: 7.7 TB/s right after that reads 0.34 ms, this 0.22)
+    render_pieces<RASTER, FPJ>(P, frames, src, __builtin_amdgcn_readfirstlane(storm ? period16_busy : period16),
+                               __builtin_amdgcn_readfirstlane(!storm && (chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n);
     if (src == CW_SRC_CURRENT && (chunk & 2) && blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = done_now;      // (every wave has read it long ago)
 }
 // ------------------------------------------------------------------------------------ exports
