@@ -101,7 +101,8 @@ struct cw_engine {
     bool guard_on = false, guard_pending = false;
     hipEvent_t guard_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned guard_step = 0;
-    int guard_late = 0, guard_slowdowns = 0, guard_period16 = 0;
+    int guard_late = 0, guard_good = 0, guard_slowdowns = 0, guard_period16 = 0;
+    double sweep_rate_top = 0;          // the rate cw_create chose: the guard never goes above it
     int prof_cap = 0, prof_n = 0;
 };
 // look-ahead refill: every la_period-th step.  A refill costs one reset's latency (~15 us) whatever the list holds, so rarely is cheap -- but an env
@@ -362,6 +363,7 @@ static int calibrate_sweep(cw_engine *e)
         if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; e->sweep_rate = rates[i]; }
     }
     set_sweep_rate(e, e->sweep_rate);
+    e->sweep_rate_top = e->sweep_rate;
     e->guard_on = rc == CW_OK && e->sweep_rate > 0 && e->auto_reset && !(getenv("CW_TUNE_GUARD") && atoi(getenv("CW_TUNE_GUARD")) == 0);
     if (e->guard_on)
         for (hipEvent_t &ev : e->guard_ev)
@@ -373,11 +375,13 @@ static int calibrate_sweep(cw_engine *e)
 }
 
 // The GUARD of the sweep's clock.  Every CW_GUARD_EVERY-th step's sweep is bracketed by two events on the caller's stream; when they have completed
-// (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + what a launch costs
-// beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 5-15 % and erratically; one that keeps up
-// by less than 1 %.  Three samples in a row more than 4 % late: the rate goes down by 0.2 TB/s for the rest of the process (never up again: the
-// point of a clock is that it does not hunt).  -> the event array for this step's launch, or null.
-enum { CW_GUARD_EVERY = 64 };
+// (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + the busy head + what
+// a launch costs beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 10-16 % launch after launch; at
+// the edge (7.7 TB/s) one launch in ten is 7-12 % late and the rest on time.  Three samples in a row more than 6 % late: the rate goes down by
+// 0.2 TB/s.  It comes back a notch after CW_GUARD_RECOVER samples in a row on time (~4 000 steps), never above what cw_create chose: a disturbance
+// that has passed -- another process on the card, a thermal excursion -- does not slow the engine for the rest of its life, and a clock that moves
+// once in thousands of steps does not hunt.  -> the event array for this step's launch, or null.
+enum { CW_GUARD_EVERY = 64, CW_GUARD_RECOVER = 64 };
 static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
 {
     if (++e->guard_step % CW_GUARD_EVERY) return nullptr;
@@ -390,7 +394,16 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
         if (hipEventElapsedTime(&ms, e->guard_ev[4], e->guard_ev[5]) == hipSuccess && ms > 0.f && e->guard_period16 == e->tune.period16) {
             const double scheduled = (e->sweep_jobs * (e->tune.period16 / 1.6) + CW_HEAD_JOBS_HOST * ((e->tune.period16_busy - e->tune.period16) / 1.6)) * 1e-6 +
                                      e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
-            e->guard_late = ms > 1.04 * scheduled ? e->guard_late + 1 : 0;
+            const bool late = ms > 1.06 * scheduled;
+            e->guard_late = late ? e->guard_late + 1 : 0;
+            e->guard_good = late ? 0 : e->guard_good + 1;
+            if (e->guard_good >= CW_GUARD_RECOVER && e->sweep_rate + 0.1 < e->sweep_rate_top) {
+                e->sweep_rate += 0.2;
+                set_sweep_rate(e, e->sweep_rate);
+                e->guard_good = 0;
+                if (getenv("CW_TUNE_VERBOSE"))
+                    fprintf(stderr, "[craftingworld] sweep clock: %d samples in a row on time -> back to %.1f TB/s (%.0f ns)\n", CW_GUARD_RECOVER, e->sweep_rate, e->tune.period16 / 1.6);
+            }
             if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {
                 e->sweep_rate -= 0.2;
                 set_sweep_rate(e, e->sweep_rate);

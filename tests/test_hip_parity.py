@@ -1214,7 +1214,7 @@ def test_full_frame_step_of_every_frame_size_equals_the_dirty_cell_engine(N, siz
 @pytest.mark.gpu
 def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
     """The sweep's clock sets the rate at which a launch writes; its guard (cw_engine.cpp: sweep_guard_tick) holds every 64th sweep against its
-    schedule and lowers the rate when three samples in a row are more than 4 % late.  Started at 9 TB/s -- more than the memory system takes --
+    schedule and lowers the rate when three samples in a row are more than 6 % late (and raises it again only after 64 samples on time).  Started at 9 TB/s -- more than the memory system takes --
     the guard must have stepped the rate down within 2 000 steps; at the default rate it must not move; the frames are the dirty-cell engine's
     either way."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
