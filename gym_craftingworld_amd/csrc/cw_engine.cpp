@@ -306,12 +306,13 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
 }
 
 // The sweep's CLOCK (cw_kernels.hip: render_pieces): the period between two jobs of a wave, i.e. the RATE at which a launch writes --
-// waves x 4 KiB per period.  In a row of back-to-back launches the memory system of an MI355X takes 7.2-7.4 TB/s of such a stream (65 536 envs,
-// 21x21, 1 024 waves: 582 ns 0.2049 ms per launch in step / 0.2054 with ~220 envs finishing on every step, 567 ns 0.2004 / 0.2032-0.2046: 0.86-0.88 of
-// the 8 TB/s peak) and falls into its slower, saturated regime just beyond (555 ns: 0.228 spread out; 131 072 envs spread out already at 567 ns: 0.435
-// against 0.406 at 582) -- profiles/r04_clock.txt K.  So cw_create tries 7.4, 7.2, 7.0, 6.8, 6.6 TB/s and the unclocked sweep on the engine's own
-// batch (20 launches each) and takes the best 90th percentile, and a GUARD keeps watching in cw_step (sweep_guard_tick): a sweep that does not keep
-// its schedule any more -- the steady state of a big batch at 7.4 -- is slowed down a notch.
+// waves x 4 KiB per period.  In a row of back-to-back launches the memory system of an MI355X takes up to 7.7 TB/s of such a stream (65 536 envs,
+// 21x21, 1 024 waves, 545 ns: 0.1988 ms per launch in step, 0.2004 with ~220 envs finishing on every step, 0.89 / 0.88 of the 8 TB/s peak) IF the
+// launch's first ~40 us run a notch slower (cw_render_pieces_kernel: the head), and falls into its slower, saturated regime just beyond (525 ns:
+// 0.20-0.24 whatever the head) or, box by box, already there (one launch in four 10-15 % late) -- profiles/r04_clock.txt K-M.  So cw_create tries 7.7,
+// 7.4, 7.2, 7.0, 6.8, 6.6 TB/s and the unclocked sweep on the engine's own batch (20 launches each, an idle kernel between them like a step's)
+// and takes the best 90th percentile -- a rate that is late one time in four loses to the next one -- and a GUARD keeps watching in cw_step
+// (sweep_guard_tick): a sweep that does not keep its schedule any more is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
 // the clock's three periods from one rate: a launch's first CW_HEAD_JOBS jobs run CW_HEAD_NOTCH slower, after a step on which envs finished
