@@ -22,24 +22,19 @@ for t in range(250):
 torch.cuda.synchronize()
 period = env.tuner_state()['period16'] / 16.0            # ticks of 10 ns
 buf = (C.c_ulonglong * (1024 * 8))()
-for rep in range(3):
-    for t in range(30):                                   # back to back: the LAST launch's stamps are read (an idle gap before a launch flatters it)
-        env.step_async(acts[300 + t]); env.step_wait()
+for rep in range(12):
+    for t in range(7):                                    # back to back: the LAST launch's stamps are read (an idle gap before a launch flatters it)
+        env.step_async(acts[300 + (7 * rep + t) % 90]); env.step_wait()
     torch.cuda.synchronize()
     assert env._lib.cwk_trace_read(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-    t_in, t_t0, t_issue, t_drain = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
-    n_forg, forg_sum, n_late, max_late = a[:, 4], a[:, 5] / 16.0, a[:, 6], a[:, 7] / 16.0
+    t_in, t_issue, t_drain, n_forg, first, last = a[:, 0], a[:, 2], a[:, 3], a[:, 4], a[:, 5], a[:, 6]
     z = t_in.min()
     frame_bytes = 48 * size * size
     jobs = -(-(n * frame_bytes) // 4096)
     q = -(-jobs // 1024)
-    print('launch %d: period %.1f ns, %d jobs per wave, schedule %.1f us' % (rep, period * 10, q, q * period / 100))
-    print('   entry   (after the first wave)    med %6.2f  max %6.2f us' % (np.median(t_in - z) / 100, (t_in - z).max() / 100))
-    if t_t0.any():                                        # (a build that stamps the end of the first batch's fetch)
-        print('   first batch prepared (clock t0)   med %6.2f  max %6.2f us' % (np.median(t_t0 - z) / 100, (t_t0 - z).max() / 100))
-    print('   last store issued                 med %6.2f  min %6.2f  max %6.2f us' % (np.median(t_issue - z) / 100, (t_issue - z).min() / 100, (t_issue - z).max() / 100))
-    print('   drained                           med %6.2f  max %6.2f us   (drain itself: med %5.2f max %5.2f us)' %
-          (np.median(t_drain - z) / 100, (t_drain - z).max() / 100, np.median(t_drain - t_issue) / 100, (t_drain - t_issue).max() / 100))
-    print('   forgiven: events per wave med %d max %d; time per wave med %.2f max %.2f us; late starts per wave med %d; worst lateness med %.2f max %.2f us' %
-          (np.median(n_forg), n_forg.max(), np.median(forg_sum) / 100, forg_sum.max() / 100, np.median(n_late), np.median(max_late) / 100, max_late.max() / 100))
+    had = first >= 0
+    print('launch %2d: period %.1f ns, %d jobs/wave, schedule %.1f us | last store issued med %6.2f max %6.2f us | debts forgiven per wave med %d max %d, waves with none %d; '
+          'first at job med %d (min %d), last at job med %d' %
+          (rep, period * 10, q, q * period / 100, np.median(t_issue - z) / 100, (t_issue - z).max() / 100, np.median(n_forg), n_forg.max(), (~had).sum(),
+           np.median(first[had]) if had.any() else -1, first[had].min() if had.any() else -1, np.median(last[had]) if had.any() else -1))
