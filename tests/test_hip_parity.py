@@ -1227,7 +1227,9 @@ def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
             monkeypatch.setenv('CW_TUNE_RATE_TBS', rate)
         e = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
         monkeypatch.delenv('CW_TUNE_RATE_TBS', raising=False)
-        p0 = e.tuner_state()['period16']
+        t0 = e.tuner_state()
+        p0 = t0['period16']
+        assert 0 < p0 < t0['period16_head'] < t0['period16_busy'], t0        # (a launch's head runs a notch slower, two after a busy step)
         e.reset()
         for t in range(T):                                   # (alone on the card: the guard times this engine's sweeps)
             e.step_async(acts[t % 64])
