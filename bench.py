@@ -9,15 +9,17 @@
 
 Workload = BASELINE.json configs[2] (the config the metric is quoted on): 65 536 envs per GPU,
 21x21 grid, full-frame 4x4-pixel-cell uint8 observation every step, auto-reset, uniform random
-actions, max_steps=300.  One "step" = one cw_step over the whole batch (step kernel, then ONE launch whose first
-workgroups render every frame and whose last ones reset the envs of the ballot-compacted done list).  Envs shard across
+actions, max_steps=300.  One "step" = one cw_step over the whole batch: cw_step_fused_kernel (every env's step; a finished env takes
+the look-ahead record of its next episode and its wave paints the two frames a reset changes), then cw_render_pieces_kernel, the clocked
+sweep that writes the whole observation array; every max_steps/4-th step cw_refill_kernel ahead of them.  Envs shard across
 ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
 are the timing barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt), with
-  roofline     -- dominant kernel (cw_render_pieces_step_kernel, or cw_render_step_kernel where cw_create measured that one faster) vs the HBM roof, from HIP events recorded by the
-                  library on the launch stream (cw_profile_begin/end) over a second, identical
-                  K-step region (the first region, without events, gives `value`);
+  roofline     -- dominant kernel (cw_render_pieces_kernel<raster, frames per job>: the sweep of the observation array) vs the HBM roof, from
+                  HIP events recorded by the library on the launch stream (cw_profile_begin/end) over a second, identical
+                  K-step region (the first region, without events, gives `value`); step_frac = the WHOLE step against the same roof;
+  policy_in_loop -- the same engine with a consumer between two steps that reads every observation byte and produces the next actions;
   cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) on this host's cores,
                   same workload shape, bounded sample; `value` is like for like with the headline (a full
                   render() per step), `dirty_cell_value` is the reference's own repaint strategy;
@@ -161,6 +163,51 @@ def single_env_latency(device, steps=200, repeats=5):
                      'measured in the build container (BASELINE.md §2)')
 
 
+def make_consumer(kind, n_envs, frame_shape, dev):
+    """A stand-in POLICY for the policy-in-the-loop measurement (SURVEY 8b's callers: "torch policies consuming device tensors without
+    host copies", docs/source/envs/gen_info.rst:62-82 with a network where the reference samples).  -> fn(obs uint8 [N, H, W, 3]) -> actions
+    uint8 [N]; torch kernels on the current stream, every observation byte read, the next actions a function of it.
+      reduce: obs.view(N, -1).sum(1) % 6 -- one pass over the frames, nothing else.
+      conv:   two strided convolutions (kernel = stride: 4x4 per cell -- or 3x3 for the AltObs tiles -- then 3x3 cells), bf16, as GEMMs over
+              the patches, ReLU between, mean over positions, a 6-way head, an action sampled from its softmax (Gumbel-max).  Weights are fixed random numbers (seed 0)."""
+    import torch
+    H, Wd, _ = frame_shape
+    if kind == 'reduce':
+        def policy(obs):
+            return torch.remainder(obs.view(n_envs, -1).sum(1, dtype=torch.int32), 6).to(torch.uint8)
+        policy.describe = 'obs.view(N,-1).sum(1) % 6 (torch reduction over every observation byte)'
+        return policy
+    if kind != 'conv':
+        raise ValueError('consumer must be reduce or conv')
+    p1 = 4 if H == Wd else 3                                   # one cell per patch (Ray 4x4 px, AltObs 3x3 px; its strip of 3 more rows is one more patch row)
+    g1h, g1w = H // p1, Wd // p1
+    p2 = 3
+    g2h, g2w = g1h // p2, g1w // p2
+    gen = torch.Generator(device=dev).manual_seed(0)
+    w1 = (torch.randn(p1 * p1 * 3, 16, device=dev, generator=gen) / 64.0).to(torch.bfloat16)
+    w2 = (torch.randn(p2 * p2 * 16, 32, device=dev, generator=gen) / 12.0).to(torch.bfloat16)
+    w3 = torch.randn(32, 6, device=dev, generator=gen).to(torch.bfloat16)
+    chunk = 8192                                               # envs per pass: the bf16 patches of a chunk stay a few hundred MB
+
+    def policy(obs):
+        out = torch.empty(n_envs, dtype=torch.uint8, device=dev)
+        for lo_ in range(0, n_envs, chunk):
+            o = obs[lo_:lo_ + chunk]
+            n = o.shape[0]
+            x = o[:, :g1h * p1, :g1w * p1].reshape(n, g1h, p1, g1w, p1, 3).permute(0, 1, 3, 2, 4, 5).reshape(n * g1h * g1w, p1 * p1 * 3)
+            h1 = torch.relu(x.to(torch.bfloat16) @ w1).view(n, g1h, g1w, 16)
+            y = h1[:, :g2h * p2, :g2w * p2].reshape(n, g2h, p2, g2w, p2, 16).permute(0, 1, 3, 2, 4, 5).reshape(n * g2h * g2w, p2 * p2 * 16)
+            h2 = torch.relu(y @ w2).view(n, g2h * g2w, 32).mean(1)
+            logits = (h2 @ w3).float()
+            logits = logits / (logits.abs().amax(1, keepdim=True) + 1.0)          # (fixed random weights: keep the head's temperature near 1)
+            u = torch.rand(logits.shape, device=dev, generator=gen).clamp_(1e-9, 1.0 - 1e-7)
+            out[lo_:lo_ + chunk] = (logits - torch.log(-torch.log(u))).argmax(1).to(torch.uint8)      # a SAMPLED action (Gumbel-max), as a stochastic policy takes it
+        return out
+    policy.describe = ('conv %dx%d/%d (3->16) + ReLU, conv 3x3/3 (16->32) + ReLU, mean, linear 32->6, sampled action; bf16 GEMMs over patches, %d envs per pass'
+                       % (p1, p1, p1, chunk))
+    return policy
+
+
 def frames_per_job(frame_bytes):
     """template parameter of cw_render_pieces_kernel as a kernel trace lists it: the most frames an aligned 4-KiB piece overlaps, as a power of two"""
     most, fpj = 4095 // frame_bytes + 2, 2
@@ -215,6 +262,11 @@ def main():
                          'slower; reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
+    ap.add_argument('--consumer', default='default', choices=['default', 'none', 'reduce', 'conv', 'both'],
+                    help='policy-in-the-loop measurement (pixel modes): between two steps a torch kernel that reads EVERY observation byte and '
+                         'produces the next actions from it, on the env\'s stream.  reduce: obs.view(N,-1).sum(1) %% 6; conv: two strided bf16 '
+                         'convolutions + a sampled action.  default: both, except with --quick (none); a named one also runs with --quick')
+    ap.add_argument('--consumer-steps', type=int, default=0, help='steps per pass of the policy-in-the-loop measurement (0: 2*max_steps)')
     ap.add_argument('--shard-check', type=int, default=0, metavar='T',
                     help='no timing: reset, take T steps with actions that depend only on (step, GLOBAL env index), write per-env CRC32s of '
                          'the final frames and the reward / done of every step of this rank\'s shard to --shard-out/rank<r>.npz and exit '
@@ -266,9 +318,9 @@ def main():
         # The default group is gloo (CPU, rendezvous over MASTER_ADDR:MASTER_PORT): it carries the control plane -- above all the agreement
         # on whether RCCL works.  RCCL (backend "nccl") is a second group for the two timing collectives; no data-path collective exists.
         # sharding.agree_on_rccl: every rank publishes its status over gloo after creating the group and again after one all-reduce on it --
-        # everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  (A rank whose all-reduce throws while its peers block in
-        # theirs: they wait out the 60-s group timeout; with torch's asynchronous error handling the watchdog would abort them instead of raising.)
-        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
+        # everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  The RCCL group waits in blocking mode
+        # (TORCH_NCCL_BLOCKING_WAIT=1, set there): a rank whose peers never arrive in the probe gets an exception after the group's 60-s timeout
+        # and joins the agreement; torch's asynchronous error handling keeps its default, so a collective that hangs later ends the rank non-zero.
         dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         backend_used = args.dist_backend
         if args.dist_backend == 'nccl':
@@ -480,6 +532,84 @@ def main():
                                  'then the window without events (value, max over ranks) and once more with the library\'s events '
                                  '(roofline, rank 0)' % KW_}
 
+    # POLICY IN THE LOOP (SURVEY 8b's callers: torch policies consuming device tensors without host copies; gen_info.rst:62-82 with a network
+    # where the reference samples its actions).  Every region above runs sweeps back to back with nothing else on the card -- the regime the
+    # sweep's clock, its head and the guard were tuned in.  Here a consumer that READS every byte of the 1.4 GB of frames runs between two steps
+    # and its output is the next step's actions: step -> sweep -> consumer -> step ..., all on one stream.
+    policy_blocks = None
+    kinds = {'default': () if args.quick else ('reduce', 'conv'), 'none': (), 'both': ('reduce', 'conv')}.get(args.consumer, (args.consumer,))
+    if kinds and args.obs_mode == 'pixels':
+        S_ = args.size
+        frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
+        sweep_bytes = float(N) * (S_ * S_ + frame_)
+        KC = args.consumer_steps if args.consumer_steps > 0 else 2 * args.max_steps
+        policy_blocks = {}
+        for kind in kinds:
+            policy = make_consumer(kind, N, env.frame_shape, dev)
+            obs_t = env._obs
+            a = actions[0].clone()
+            for _ in range(3):                           # (the consumer's own warm-up: GEMM heuristics, allocator)
+                a = policy(obs_t)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                a = policy(obs_t)
+            e1.record()
+            e1.synchronize()
+            consumer_alone_ms = e0.elapsed_time(e1) / 20
+            tuner0 = env.tuner_state()
+            for _ in range(64):
+                env.step_async(a)
+                a = policy(obs_t)
+            barrier()
+            ep0 = int(env.counters[1].item())
+            t0 = time.perf_counter()                     # pass A: no events at all (the guard watches every 64th sweep)
+            for _ in range(KC):
+                env.step_async(a)
+                a = policy(obs_t)
+            barrier()
+            wall = max_over_ranks(time.perf_counter() - t0, device=red_dev, group=timing_group)
+            finished = int(env.counters[1].item()) - ep0
+            tuner1 = env.tuner_state()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * KC)]
+            env.profile_begin(KC)                        # pass B: the library's events around the sweep, torch events around the consumer
+            barrier()
+            t0 = time.perf_counter()
+            for t in range(KC):
+                env.step_async(a)
+                evs[2 * t].record()
+                a = policy(obs_t)
+                evs[2 * t + 1].record()
+            barrier()
+            wall_b = time.perf_counter() - t0
+            pp = env.profile_end()
+            cons = sorted(evs[2 * t].elapsed_time(evs[2 * t + 1]) for t in range(KC))
+            cons_ms = sum(cons) / KC
+            ms_ = pp['ms_render_kernel']
+            step_ms = wall / KC * 1e3
+            policy_blocks[kind] = {
+                'consumer': policy.describe, 'steps': KC, 'episodes_finished_per_step': finished / KC,
+                'ms_per_step': step_ms, 'value': float(N) * world * KC / wall, 'unit': 'env-steps/s (consumer included)',
+                'consumer_ms': cons_ms, 'consumer_ms_median': cons[KC // 2], 'consumer_alone_ms': consumer_alone_ms,
+                'consumer_read_GBs': float(N) * frame_ / (cons_ms * 1e-3) / 1e9,
+                'env_ms_per_step': step_ms - cons_ms,    # the whole step minus the consumer: step kernel + sweep + gaps
+                'env_value': float(N) * world / ((step_ms - cons_ms) * 1e-3) if step_ms > cons_ms else None,
+                'sweep': {'kernel': render_kernel, 'avg_launch_ms': ms_, 'median_launch_ms': pp['ms_render_kernel_median'] or None,
+                          'launch_ms_min_max': [pp['ms_render_kernel_min'], pp['ms_render_kernel_max']],
+                          'achieved': sweep_bytes / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
+                          'frac': sweep_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None,
+                          'frac_at_median_launch': (sweep_bytes / (pp['ms_render_kernel_median'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                    if pp['ms_render_kernel_median'] > 0 else None)},
+                'step_frac': float(N) * (48 + S_ * S_ + frame_) / ((step_ms - cons_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > cons_ms else None,
+                'ms_per_step_with_events': wall_b / KC * 1e3,
+                'tuner_before': tuner0, 'tuner_after': tuner1,
+                'guard_moves': tuner1['guard_slowdowns'] - tuner0['guard_slowdowns'],
+                'note': 'step -> sweep -> consumer -> step on one stream; the consumer reads every observation byte and its output is the next '
+                        'step\'s action tensor.  ms_per_step / value: %d steps without events (guard on); sweep / consumer_ms: the same again with the '
+                        'library\'s events around the sweep and torch events around the consumer; episode phases as the regions above left '
+                        'them (%s)' % (KC, 'spread out' if (window_desync or args.desync) else 'in step')}
+
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
     # step (the reference's own render_edit strategy), state-only has no frames at all.  Both are launch-bound: `value` is the per-step
@@ -505,6 +635,7 @@ def main():
             rec = {'value': n_envs * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1, 'launch': 'eager, one cw_step per Python call',
                    'repeats': {'n': 3, 'value': [n_envs * k2 / x for x in dts], 'us_per_step': [x / k2 * 1e6 for x in dts]}}
             block = acts[:k2].contiguous()
+            kb = int(block.shape[0])                     # (the action pool holds `rows` rows: fewer than k2 when max_steps > 512)
             e2.step_many(block)
             torch.cuda.synchronize(dev)
             tt = time.perf_counter()
@@ -512,7 +643,7 @@ def main():
                 e2.step_many(block)
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - tt) / 3
-            rec['step_many'] = {'value': n_envs * k2 / dt, 'us_per_step': dt / k2 * 1e6, 'launch': 'cw_step_many: %d steps per library call' % k2}
+            rec['step_many'] = {'value': n_envs * kb / dt, 'us_per_step': dt / kb * 1e6, 'launch': 'cw_step_many: %d steps per library call' % kb}
             ring = acts[:64].clone()
             g = e2.capture_steps(ring)
             reps = max(1, k2 // 64)
@@ -532,7 +663,7 @@ def main():
                 e2.rollout(block, record=False)
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tt
-                rec['rollout'] = {'value': n_envs * k2 / dt, 'us_per_step': dt / k2 * 1e6, 'launch': 'cw_rollout: %d steps in one persistent kernel' % k2}
+                rec['rollout'] = {'value': n_envs * kb / dt, 'us_per_step': dt / kb * 1e6, 'launch': 'cw_rollout: %d steps in one persistent kernel' % kb}
             out_[mode] = rec
             e2.close()
         return out_
@@ -551,18 +682,17 @@ def main():
         S = args.size
         frame = 48 * S * S if args.raster == 'ray' else 27 * S * (S + 1)
         if args.obs_mode == 'pixels':
-            # A_pix = 48 + S*S (grid read) + frame write; the render kernel's share is
-            # S*S + frame bytes per env, and one launch paints N envs (+2 more frames for each env reset that step)
-            # (cw_render_step_kernel: + the 2 extra frames of every env reset inside the launch, see below)
+            # A_pix = 48 + S*S (grid read) + frame write; the sweep's share is S*S + frame bytes per env, and one sweep
+            # paints N envs.  (The INIT_OBS / desired_goal frames of envs that finished -- 2 x resets_in_prof frames in the profiled region --
+            # are painted inside cw_step_fused_kernel, BEFORE the sweep and outside the bracketed kernel: not counted here.)
             alg_bytes = plain_alg_bytes = float(N) * (S * S + frame)
-            # (the frames of envs that finished -- INIT_OBS and desired_goal, 2 x resets_in_prof frames in the profiled region -- are painted by
-            # cw_list_kernel after the sweep, outside the bracketed kernel: not counted here)
             dominant, ms = render_kernel, prof['ms_render_kernel']
         else:
             alg_bytes = plain_alg_bytes = float(N) * 48.0
             # state-only / dirty-cell: the whole auto-reset step is one launch (step + inline resets), latency-bound
             dominant, ms = 'cw_step_fused_kernel', prof['ms_step_kernel']
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        step_alg_bytes = float(N) * ((48.0 + S * S + frame) if args.obs_mode == 'pixels' else (48.0 + 96.0) if args.obs_mode == 'pixels_dirty' else 48.0)
         # HBM bytes per launch of the dominant kernel from the PMC passes (tools/profile_pmc.sh: separate
         # WRITE_SIZE / FETCH_SIZE runs, calibrated; the newest committed summary is quoted, null otherwise)
         traffic = traffic_source = None
@@ -617,6 +747,13 @@ def main():
                          'kernel_in_trace': (('%s<%d, %d>' % (dominant, 1 if args.raster == 'alt' else 0, frames_per_job(frame))) if dominant.startswith('cw_render_pieces') else dominant),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                         # the WHOLE step against the same roof: A x N / ms_per_step (A = SURVEY 8d's bytes per env-step: 48 + S*S + frame in the
+                         # full-frame mode) for `value` and for the two windows to quote
+                         'step_frac': step_alg_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+                         'step_frac_metric_window': step_alg_bytes / (window['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS if window else None,
+                         'step_frac_metric_window_desync': (step_alg_bytes / (window_desync['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                            if window_desync else None),
+                         'step_algorithmic_bytes': step_alg_bytes,
                          'fill_same_bytes_GBs': fill_gbs,   # plain fill of the same size on this box, for orientation
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms,
                          'launch_ms_min_max': [prof['ms_render_kernel_min'], prof['ms_render_kernel_max']],
@@ -642,6 +779,7 @@ def main():
             'dist_backend': backend_used,
             'other_obs_modes_1gpu': other,
             'config1_state_4096': config1,
+            'policy_in_loop': policy_blocks,
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (task contract)
             out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)

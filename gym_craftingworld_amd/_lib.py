@@ -15,7 +15,7 @@ def lib_path():
     """Which build to load: CW_LIB_PATH (any other build, A/B runs) or the product."""
     return os.environ.get('CW_LIB_PATH') or LIB_PATH
 
-CW_ABI_VERSION = 4
+CW_ABI_VERSION = 5
 CW_MT_N = 624
 CW_MAX_TASKS = 16
 CW_MAX_MENUS = 256
@@ -42,7 +42,7 @@ class cw_config(C.Structure):
 class cw_buffer_table(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('desired_goal', C.c_void_p), ('init_obs', C.c_void_p), ('terminal_obs', C.c_void_p),
                 ('reward', C.c_void_p), ('done', C.c_void_p), ('achieved', C.c_void_p),
-                ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('hdr', C.c_void_p),
+                ('desired', C.c_void_p), ('episode_length', C.c_void_p), ('episode_return', C.c_void_p), ('hdr', C.c_void_p),
                 ('slot_pos', C.c_void_p), ('counters', C.c_void_p), ('frame_bytes', C.c_size_t),
                 ('host_actions', C.c_void_p), ('host_onehot', C.c_void_p)]
 
@@ -74,6 +74,7 @@ ABI = {
     'cw_seed_int': (C.c_int, [_VP, _VP]),
     'cw_get_mt': (C.c_int, [_VP, _VP, _VP]),
     'cw_generate_fixed_states': (C.c_int, [_VP, _VP]),
+    'cw_get_fixed_states': (C.c_int, [_VP, _VP]),
     'cw_reset': (C.c_int, [_VP, _VP]),
     'cw_step': (C.c_int, [_VP, _VP, C.c_int, _VP]),
     'cw_step_many': (C.c_int, [_VP, _VP, C.c_int, C.c_int32, _VP]),

@@ -34,8 +34,9 @@ class GymnasiumVecAdapter:
         obs, reward, done, info = self.venv.step(actions)
         terminated = done & (reward == self.venv.MAX_STEPS)
         truncated = done & ~terminated
+        info = dict(info, _episode=done)                 # gymnasium.vector: which rows of info['episode'] ({'r', 'l'}) hold a finished episode
         if 'terminal_observation' in info:
-            info = dict(info, final_observation=info['terminal_observation'])
+            info['final_observation'] = info['terminal_observation']
         return obs, reward, terminated, truncated, info
 
     def close(self):

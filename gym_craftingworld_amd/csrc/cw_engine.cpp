@@ -104,7 +104,36 @@ struct cw_engine {
     int guard_late = 0, guard_good = 0, guard_slowdowns = 0, guard_period16 = 0;
     double sweep_rate_top = 0;          // the rate cw_create chose: the guard never goes above it
     int prof_cap = 0, prof_n = 0;
+    // the engine's OWN work: the streams it was handed since its last wait (at most 4 are remembered) and a private stream for the synchronous
+    // entry points' copies and kernels (cw_seed_*, cw_get_mt, cw_get/set_state, checkpoints): none of them waits for anybody else's work
+    hipStream_t aux = nullptr;
+    hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_work = 0;
+    bool work_overflow = false;        // more than 4 distinct streams since the last wait: a device-wide wait is the only safe one
 };
+// every entry point that ENQUEUES on a caller's stream notes it ...
+static inline void note_work(cw_engine *e, hipStream_t st)
+{
+    for (int i = 0; i < e->n_work; i++) if (e->work[i] == st) return;
+    if (e->n_work < 4) e->work[e->n_work++] = st; else e->work_overflow = true;
+}
+// ... and every synchronous one first waits for exactly that: the engine's own work, not the card's (two engines on one device, a learner beside
+// them: MultiDeviceVecEnv).  A stream the caller destroyed meanwhile (its work has then been waited for or abandoned by the caller) fails the
+// wait: then, and only then, the whole device is waited for.
+static hipError_t quiesce(cw_engine *e)
+{
+    bool all = e->work_overflow;
+    for (int i = 0; i < e->n_work && !all; i++)
+        if (hipStreamSynchronize(e->work[i]) != hipSuccess) { (void)hipGetLastError(); all = true; }
+    e->n_work = 0;
+    e->work_overflow = false;
+    if (all) return hipDeviceSynchronize();
+    return e->aux ? hipStreamSynchronize(e->aux) : hipSuccess;
+}
+static inline hipError_t aux_copy(cw_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    return bytes ? hipMemcpyAsync(dst, src, bytes, kind, e->aux) : hipSuccess;
+}
 // look-ahead refill: every la_period-th step.  A refill costs one reset's latency (~15 us) whatever the list holds, so rarely is cheap -- but an env
 // that finishes twice between two refills is reset the slow way: a quarter of the episode length, 8..64 steps
 static int la_period_for(int max_steps) { const int p = max_steps / 4; return p < 8 ? 8 : p > 64 ? 64 : p; }
@@ -291,9 +320,9 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     bool ok = true;
     for (hipEvent_t &ev : evs) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int rep = 0; rep < LAUNCHES && ok; rep++)
-        ok = hipEventRecord(evs[2 * rep], nullptr) == hipSuccess && cwk_launch_sweep_calib(&e->P, &e->tune, nullptr) == hipSuccess &&
-             hipEventRecord(evs[2 * rep + 1], nullptr) == hipSuccess && cwk_launch_idle(nullptr) == hipSuccess;
-    ok = ok && hipDeviceSynchronize() == hipSuccess;
+        ok = hipEventRecord(evs[2 * rep], e->aux) == hipSuccess && cwk_launch_sweep_calib(&e->P, &e->tune, e->aux) == hipSuccess &&
+             hipEventRecord(evs[2 * rep + 1], e->aux) == hipSuccess && cwk_launch_idle(e->aux) == hipSuccess;
+    ok = ok && hipStreamSynchronize(e->aux) == hipSuccess;
     float ms[LAUNCHES];
     for (int rep = 0; rep < LAUNCHES && ok; rep++) ok = hipEventElapsedTime(&ms[rep], evs[2 * rep], evs[2 * rep + 1]) == hipSuccess;
     for (hipEvent_t &ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -528,7 +557,9 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(achieved_out, N);
     ALLOC_OUT(desired_out, N);
     ALLOC_OUT(episode_length, N);
+    ALLOC_OUT(episode_return, N);
     ALLOC(counters, 8);
+    if (rc == CW_OK && hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: no private stream");
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
         ALLOC_OUT(desired_img, N * P.frame_bytes);
@@ -562,6 +593,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
             rc = fail(CW_ERR_HIP, "cw_create: header upload failed");
     }
     if (rc != CW_OK) {
+        if (e->aux) (void)hipStreamDestroy(e->aux);
         for (void *p : e->allocs) (void)hipFree(p);
         for (void *p : e->host_allocs) (void)hipHostFree(p);
         delete e;
@@ -606,8 +638,9 @@ int cw_destroy(cw_engine *e)
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     (void)resident_park(e);
-    (void)hipDeviceSynchronize();
+    (void)quiesce(e);
     prof_free(e);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
     if (e->last_work) (void)hipEventDestroy(e->last_work);
     for (hipEvent_t ev : e->guard_ev) if (ev) (void)hipEventDestroy(ev);
@@ -621,8 +654,8 @@ int cw_destroy(cw_engine *e)
 static hipError_t lookahead_drop(cw_engine *e)
 {
     if (!e->P.lookahead) return hipSuccess;
-    hipError_t rc = hipMemsetAsync(e->P.nx_misc, 0, (size_t)e->n * sizeof(uint4), nullptr);
-    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.refill_count, 0, 2 * sizeof(int32_t), nullptr);
+    hipError_t rc = hipMemsetAsync(e->P.nx_misc, 0, (size_t)e->n * sizeof(uint4), e->aux);
+    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.refill_count, 0, 2 * sizeof(int32_t), e->aux);
     e->la_refill_all = true;
     return rc;
 }
@@ -638,12 +671,12 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
     const size_t N = (size_t)e->n;
     for (size_t i = 0; i < N; i++)
         if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(e->P.mt, keys, N * CW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->P.mt_idx, pos, N * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(cwk_launch_seed(&e->P, nullptr, nullptr));
+    HIP_TRY(quiesce(e));                              // (the engine's own work, not the card's)
+    HIP_TRY(aux_copy(e, e->P.mt, keys, N * CW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(aux_copy(e, e->P.mt_idx, pos, N * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(cwk_launch_seed(&e->P, nullptr, e->aux));
     HIP_TRY(lookahead_drop(e));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 
@@ -653,11 +686,11 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, nullptr));
+    HIP_TRY(quiesce(e));
+    HIP_TRY(aux_copy(e, e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, e->aux));
     HIP_TRY(lookahead_drop(e));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 
@@ -669,13 +702,14 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     PARK(e);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> misc(e->P.lookahead ? N * 4 : 0);
+    HIP_TRY(quiesce(e));
+    HIP_TRY(aux_copy(e, words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (e->P.lookahead) HIP_TRY(aux_copy(e, misc.data(), e->P.nx_misc, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(e->aux));
     for (size_t i = 0; i < N; i++) cwh_mt_to_numpy(&words[i * CW_MT_N], pos[i], keys + i * CW_MT_N);
     if (e->P.lookahead) {                            // the engine's streams are one reset ahead where a record waits: report the position BEFORE it
-        std::vector<uint32_t> misc(N * 4);
-        HIP_TRY(hipMemcpy(misc.data(), e->P.nx_misc, N * 16, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; i++)
             if (misc[i * 4 + 2] >> 31) cwh_mt_rewind(keys + i * CW_MT_N, &pos[i], misc[i * 4 + 3]);
     }
@@ -708,6 +742,7 @@ int cw_reset(cw_engine *e, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_reset_all(&e->P, &e->tune, e->obs_mode, (hipStream_t)stream));
     if (e->P.lookahead) {                            // every env's NEXT episode, ahead of time (cw_refill_kernel)
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, 1, (hipStream_t)stream));
@@ -727,6 +762,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    if (e->n_work != 1 || e->work[0] != (hipStream_t)stream) note_work(e, (hipStream_t)stream);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     const bool profiled = ev != nullptr;
     if (e->guard_on && !ev) ev = sweep_guard_tick(e, (hipStream_t)stream);
@@ -842,6 +878,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     if (e->P.lookahead) {
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -858,6 +895,7 @@ int cw_render(cw_engine *e, uint8_t *out_frames, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
@@ -869,6 +907,7 @@ int cw_render_onehot(cw_engine *e, const uint8_t *onehot, int32_t n_states, uint
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_render_onehot(&e->P, onehot, n_states, out_frames, (hipStream_t)stream));
     return CW_OK;
 }
@@ -879,6 +918,7 @@ int cw_export_grid(cw_engine *e, uint8_t *out, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 0, 0, (hipStream_t)stream));
     return CW_OK;
 }
@@ -889,6 +929,7 @@ int cw_export_onehot(cw_engine *e, uint8_t *out, cw_stream_t stream)
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, 0, (hipStream_t)stream));
     return CW_OK;
 }
@@ -901,6 +942,7 @@ int cw_export_onehot_of(cw_engine *e, int which, uint8_t *out, cw_stream_t strea
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
+    note_work(e, (hipStream_t)stream);
     HIP_TRY(cwk_launch_export(&e->P, &e->tune, out, 1, which, (hipStream_t)stream));
     return CW_OK;
 }
@@ -987,6 +1029,7 @@ int cw_buffers(cw_engine *e, cw_buffer_table *out)
     out->achieved = P.achieved_out;
     out->desired = P.desired_out;
     out->episode_length = P.episode_length;
+    out->episode_return = P.episode_return;
     out->hdr = (uint8_t *)P.hdr;
     out->slot_pos = (uint16_t *)P.pos;
     out->counters = (uint64_t *)P.counters;
@@ -1003,6 +1046,23 @@ int cw_synchronize(cw_engine *e, cw_stream_t stream)
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < e->n_work; i++)               // (that stream's share of the engine's work is done: the caller may destroy it now)
+        if (e->work[i] == (hipStream_t)stream) { e->work[i] = e->work[--e->n_work]; break; }
+    return CW_OK;
+}
+
+// generate_fixed_states' result (ray.py:116-118: fixed_state_list): the K pooled placements of every env as cell indices, [N][K][9] uint16 =
+// objects 0..7 (OBJECTS order, ray.py:21) then the agent.  Synchronous host call.
+int cw_get_fixed_states(cw_engine *e, uint16_t *out)
+{
+    if (!e || !out) return fail(CW_ERR_INVALID, "cw_get_fixed_states: null argument");
+    if (e->K == 0) return fail(CW_ERR_INVALID, "cw_get_fixed_states: the engine was created with fixed_init_state = 0");
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    PARK(e);
+    HIP_TRY(quiesce(e));
+    HIP_TRY(aux_copy(e, out, e->P.pool, (size_t)e->n * e->K * 9 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 
@@ -1025,15 +1085,16 @@ int cw_get_state(cw_engine *e, cw_state_view *v)
     std::vector<uint32_t> hdr(N * 4), goal_codes(N);
     std::vector<uint16_t> pos(N * 8), ipos(N * 8), gpos(N * 8), iagent(N), gagent(N);
     std::vector<int32_t> epno(N);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(goal_codes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(quiesce(e));                              // (the engine's own work; copies on its private stream)
+    HIP_TRY(aux_copy(e, hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, goal_codes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(e->aux));
     for (size_t i = 0; i < N; i++) {
         const uint32_t *h = &hdr[i * 4];
         if (v->grid) slots_to_grid(&pos[i * 8], h[3], nc, v->grid + i * nc);
@@ -1065,18 +1126,19 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     std::vector<uint32_t> gcodes;
     std::vector<int32_t> epno(N);
     const bool restore_episode = v->goal_grid || v->goal_agent_rc || v->init_agent_rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(quiesce(e));
     if (restore_episode) {                           // the episode records: goal state (imagine_obs' result) and the agent's start cell
         gpos.resize(N * 8); gagent.resize(N); iagent.resize(N); gcodes.resize(N);
-        HIP_TRY(hipMemcpy(gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(gcodes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(aux_copy(e, gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(aux_copy(e, gcodes.data(), e->P.goal_codes, N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(aux_copy(e, gagent.data(), e->P.goal_agent, N * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(aux_copy(e, iagent.data(), e->P.init_agent, N * 2, hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipMemcpy(hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(aux_copy(e, epno.data(), e->P.ep_no, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(e->aux));
     for (size_t i = 0; i < N; i++) {
         uint32_t *h = &hdr[i * 4];
         uint32_t hold = (h[0] >> 16) & 0xFF;
@@ -1154,21 +1216,21 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
         }
         if (v->ep_no) epno[i] = v->ep_no[i];
     }
-    HIP_TRY(hipMemcpy(e->P.hdr, hdr.data(), N * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->P.pos, pos.data(), N * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->P.init_pos, ipos.data(), N * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->P.ep_no, epno.data(), N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(aux_copy(e, e->P.hdr, hdr.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(aux_copy(e, e->P.pos, pos.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(aux_copy(e, e->P.init_pos, ipos.data(), N * 16, hipMemcpyHostToDevice));
+    HIP_TRY(aux_copy(e, e->P.ep_no, epno.data(), N * 4, hipMemcpyHostToDevice));
     if (restore_episode) {
-        HIP_TRY(hipMemcpy(e->P.goal_pos, gpos.data(), N * 16, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->P.goal_codes, gcodes.data(), N * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->P.goal_agent, gagent.data(), N * 2, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->P.init_agent, iagent.data(), N * 2, hipMemcpyHostToDevice));
+        HIP_TRY(aux_copy(e, e->P.goal_pos, gpos.data(), N * 16, hipMemcpyHostToDevice));
+        HIP_TRY(aux_copy(e, e->P.goal_codes, gcodes.data(), N * 4, hipMemcpyHostToDevice));
+        HIP_TRY(aux_copy(e, e->P.goal_agent, gagent.data(), N * 2, hipMemcpyHostToDevice));
+        HIP_TRY(aux_copy(e, e->P.init_agent, iagent.data(), N * 2, hipMemcpyHostToDevice));
     }
     if (e->obs_mode != CW_OBS_STATE) {   // the persistent frames must follow the injected state
-        if (restore_episode) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));
-        else HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, nullptr));
+        if (restore_episode) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, e->aux));
+        else HIP_TRY(cwk_launch_render_ext(&e->P, &e->tune, e->P.obs, e->aux));
     }
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 
@@ -1188,6 +1250,7 @@ struct CwCkptHeader {
     uint64_t menus_hash, total_bytes;
 };
 static const char CW_CKPT_MAGIC[8] = {'C', 'W', 'C', 'K', 'P', 'T', 0, 1};
+enum { CW_CKPT_VERSION = 3 };      // 2: look-ahead records; 3: episode_return, the sweep's private counter word, the QUEUED bit of nx_misc
 
 struct CkptSection { void *dev; size_t bytes; };
 static std::vector<CkptSection> ckpt_sections(cw_engine *e)
@@ -1197,7 +1260,8 @@ static std::vector<CkptSection> ckpt_sections(cw_engine *e)
     return {{P.hdr, N * 16}, {P.pos, N * 16}, {P.init_pos, N * 16}, {P.goal_pos, N * 16}, {P.goal_codes, N * 4},
             {P.init_agent, N * 2}, {P.goal_agent, N * 2}, {P.ep_no, N * 4}, {P.mt, N * CW_MT_N * 4}, {P.mt_idx, N * 4},
             {P.pool, N * (size_t)e->K * 9 * 2}, {P.reward, N * 4}, {P.done, N}, {P.achieved_out, N * 2}, {P.desired_out, N * 2},
-            {P.episode_length, N * 4}, {P.counters, 4 * 8},
+            {P.episode_length, N * 4}, {P.episode_return, N * 4},
+            {P.counters, 5 * 8},     // (the four public counters and the sweep's private word: a resumed engine's first sweep sees what it would have seen)
             // the look-ahead records, verbatim (the RNG streams above are one reset ahead wherever one waits)
             {P.nx_init_pos, P.lookahead ? N * 16 : 0}, {P.nx_goal_pos, P.lookahead ? N * 16 : 0}, {P.nx_misc, P.lookahead ? N * 16 : 0},
             {P.refill_list, P.lookahead ? N * 4 : 0}, {P.refill_count, P.lookahead ? (size_t)8 : 0}};
@@ -1213,7 +1277,7 @@ static CwCkptHeader ckpt_header(cw_engine *e)
 {
     CwCkptHeader h{};
     memcpy(h.magic, CW_CKPT_MAGIC, 8);
-    h.version = 2;                                   // 2: look-ahead records
+    h.version = CW_CKPT_VERSION;
     h.header_bytes = (uint32_t)sizeof(CwCkptHeader);
     h.n_envs = e->n; h.size = e->S; h.max_steps = e->P.max_steps; h.pool_k = e->K;
     h.task_mask = e->P.task_mask; h.n_menus = (uint32_t)e->menus.size();
@@ -1237,14 +1301,15 @@ int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity)
     PARK(e);
     const CwCkptHeader h = ckpt_header(e);
     if (capacity < h.total_bytes) return fail(CW_ERR_INVALID, "cw_checkpoint_save: buffer of %zu bytes, %llu needed", capacity, (unsigned long long)h.total_bytes);
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(quiesce(e));
     unsigned char *p = (unsigned char *)buf;
     memcpy(p, &h, sizeof(h));
     p += sizeof(h);
     for (const CkptSection &sec : ckpt_sections(e)) {
-        if (sec.bytes) HIP_TRY(hipMemcpy(p, sec.dev, sec.bytes, hipMemcpyDefault));
+        if (sec.bytes) HIP_TRY(aux_copy(e, p, sec.dev, sec.bytes, hipMemcpyDefault));
         p += sec.bytes;
     }
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 
@@ -1258,8 +1323,9 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (length < sizeof(h)) return fail(CW_ERR_INVALID, "cw_checkpoint_load: %zu bytes is not a checkpoint", length);
     memcpy(&h, buf, sizeof(h));
     const CwCkptHeader mine = ckpt_header(e);
-    if (memcmp(h.magic, CW_CKPT_MAGIC, 8) != 0 || h.version != 2 || h.header_bytes != sizeof(CwCkptHeader))
-        return fail(CW_ERR_INVALID, "cw_checkpoint_load: not a CraftingWorld checkpoint (or another version)");
+    if (memcmp(h.magic, CW_CKPT_MAGIC, 8) != 0) return fail(CW_ERR_INVALID, "cw_checkpoint_load: not a CraftingWorld checkpoint");
+    if (h.version != CW_CKPT_VERSION || h.header_bytes != sizeof(CwCkptHeader))
+        return fail(CW_ERR_INVALID, "cw_checkpoint_load: checkpoint version %u, this library reads version %d", h.version, (int)CW_CKPT_VERSION);
     if (h.n_envs != mine.n_envs || h.size != mine.size || h.max_steps != mine.max_steps || h.pool_k != mine.pool_k ||
         h.task_mask != mine.task_mask)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: checkpoint of %d envs, size %d, max_steps %d, fixed_init_state %d, task mask %#x; "
@@ -1273,16 +1339,16 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
                     h.lookahead ? "with" : "without", mine.lookahead ? "with" : "without");
     if (h.total_bytes != mine.total_bytes || length < h.total_bytes)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(quiesce(e));
     const unsigned char *p = (const unsigned char *)buf + sizeof(h);
     for (const CkptSection &sec : ckpt_sections(e)) {
-        if (sec.bytes) HIP_TRY(hipMemcpy(sec.dev, p, sec.bytes, hipMemcpyDefault));
+        if (sec.bytes) HIP_TRY(aux_copy(e, sec.dev, p, sec.bytes, hipMemcpyDefault));
         p += sec.bytes;
     }
     e->has_reset = true;
     e->la_refill_all = e->P.lookahead != 0;          // (harmless: envs that hold a record are skipped)
-    if (e->obs_mode != CW_OBS_STATE) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, nullptr));   // frames follow the records
-    HIP_TRY(hipDeviceSynchronize());
+    if (e->obs_mode != CW_OBS_STATE) HIP_TRY(cwk_launch_render_restore(&e->P, &e->tune, e->aux));   // frames follow the records
+    HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
 }
 

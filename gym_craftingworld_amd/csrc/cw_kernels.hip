@@ -232,8 +232,9 @@ __device__ __forceinline__ void render_frame_alt(uint8_t *__restrict__ dst0, uin
 // One wavefront paints one frame, 64 cells per iteration: lane = one cell (row-major), whose colour
 // is an 8-compare chain against the wave-uniform slot positions (SGPRs), computed ONCE and stored
 // to the cell's 4 pixel rows as 4 x 12 B (global_store_dwordx3).  This is the painter of single frames
-// -- the frames of the done list (cw_list_kernel), of resets inlined in the dirty-cell step, of cw_render
-// into an array the sweep's 16-byte stores cannot take; every whole ARRAY is swept (render_pieces below).
+// -- the INIT_OBS / desired_goal frames of finished envs and their terminal frames (cw_step_fused_kernel), all three frames of an env
+// reset inside the dirty-cell step, cw_render into an array the sweep's 16-byte stores cannot take (cw_render_frames_kernel); every
+// whole ARRAY is swept (render_pieces below).
 // Plain stores: nontemporal ones measured 25 % slower in this shape (tools/microbench).
 __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t *__restrict__ dst1,
                                              int S, int ncell, uint32_t div_magic, const uint32_t sp[8],
@@ -318,6 +319,13 @@ struct CwStepOut {
     bool mark0, mark1;             // only the agent's mark came or went in that cell (a move that left the cell's object as it was): pixel rows 1, 2 suffice
     uint32_t step_num, achieved, desired;
 };
+
+// The finished episode's RETURN as the reference's loop sums it (ray.py:361-367: every step returns -1 except a successful last one, which
+// returns MAX_STEPS and ends the episode): MAX_STEPS - (step_num - 1) after a success, -step_num after a time-out.
+__device__ __forceinline__ int32_t episode_return_of(const CwParams &P, const CwStepOut &o)
+{
+    return o.success ? P.max_steps - (int32_t)o.step_num + 1 : -(int32_t)o.step_num;
+}
 
 template <typename InitPosFn>
 __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint32_t sp[8], int a, InitPosFn load_init_pos)
@@ -477,7 +485,7 @@ __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uin
     P.init_agent[env] = (uint16_t)(m.x & 0xFFFFu);
     P.goal_agent[env] = (uint16_t)(m.x >> 16);
     if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
-    ((uint32_t *)(P.nx_misc + env))[2] = m.z & 0x7FFFFFFFu;       // taken
+    ((uint32_t *)(P.nx_misc + env))[2] = (m.z & 0x7FFFFFFFu) | CW_NX_QUEUED;   // taken; the caller puts the env on the refill list
     const uint32_t ia = m.x & 0xFFFFu;
     const uint32_t ar = __umulhi(ia, P.div_magic), ac = ia - ar * P.size;
     h.x = ar | (ac << 8) | (h.x & 0xFF000000u);                   // (the menu id stays)
@@ -486,6 +494,19 @@ __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uin
     h.w = CW_CODES_INITIAL;
     unpack_pos(ipos, sp);
     return true;
+}
+
+// An env reset the SLOW way holds no record for its next episode.  Unless it is on the refill list already (it took its record earlier in this
+// refill period), it goes there now -- otherwise an engine whose host never asks for a whole-batch refill again (a captured graph replayed after a
+// re-seed dropped every record: cw_refill_kernel with all_envs = 0 baked in) would reset the slow way for the rest of its life.  One lane.
+__device__ __forceinline__ void queue_for_refill(const CwParams &P, int env)
+{
+    uint32_t *z = (uint32_t *)(P.nx_misc + env) + 2;
+    const uint32_t v = *z;
+    atomicAdd(&P.counters[5], 1ull);                  // (private word: resets taken the slow way)
+    if (v & (CW_NX_QUEUED | 0x80000000u)) return;
+    *z = v | CW_NX_QUEUED;
+    P.refill_list[atomicAdd(&P.refill_count[0], 1)] = env;
 }
 
 // step() for engines WITHOUT auto-reset (the single-env loop's launch path, fixture replays): one lane per env, finished envs keep
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         P.done[i] = done ? 1 : 0;
         P.achieved_out[i] = (uint16_t)o.achieved;
         P.desired_out[i] = (uint16_t)o.desired;
-        if (done) P.episode_length[i] = (int32_t)o.step_num;
+        if (done) { P.episode_length[i] = (int32_t)o.step_num; P.episode_return[i] = episode_return_of(P, o); }
         if (paint_dirty && o.changed) paint_changed_cells(P, i, h, sp, o);   // render_edit, :358
     }
     const unsigned long long m_done = CW_BALLOT(done), m_succ = CW_BALLOT(success), m_inv = CW_BALLOT(invalid);
@@ -962,7 +983,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
         n_done += __popcll(m_all);
         n_succ += __popcll(CW_BALLOT(live && o.success));
         n_inv += __popcll(CW_BALLOT(live && o.invalid));
-        if (m_all && t + 1 == T && live && o.done) P.episode_length[env] = (int32_t)o.step_num;
+        if (m_all && live && o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
         bool popped = false;                         // auto-reset: the look-ahead record if there is one ...
         if (live && o.done && P.lookahead) {
             popped = pop_next_episode(P, env, h, sp, true);
@@ -982,7 +1003,10 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
             const int env_l = env0 + l;
             const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
             const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
-            if (lane == 0) store_episode_records(P, env_l, r, true);   // step_num >= 1 here
+            if (lane == 0) {
+                store_episode_records(P, env_l, r, true);              // step_num >= 1 here
+                if (P.lookahead) queue_for_refill(P, env_l);
+            }
             if (lane == l) {
                 h = reset_header(P, r, menu_id);
                 unpack_pos(r.init_pos, sp);
@@ -1042,7 +1066,7 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
                 P.done[0] = o.done ? 1 : 0;
                 P.achieved_out[0] = (uint16_t)o.achieved;
                 P.desired_out[0] = (uint16_t)o.desired;
-                if (o.done) P.episode_length[0] = (int32_t)o.step_num;
+                if (o.done) { P.episode_length[0] = (int32_t)o.step_num; P.episode_return[0] = episode_return_of(P, o); }
                 if (paint_dirty && o.changed) {                                  // render_edit, ray.py:522-557 (as in cw_step_kernel)
                     uint8_t *frame = P.obs;
                     const uint32_t hold = (h.x >> 16) & 0xFFu;
@@ -1132,7 +1156,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         P.done[env] = o.done ? 1 : 0;
         P.achieved_out[env] = (uint16_t)o.achieved;
         P.desired_out[env] = (uint16_t)o.desired;
-        if (o.done) P.episode_length[env] = (int32_t)o.step_num;
+        if (o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
         if (paint == 1 && o.changed && !o.done) paint_changed_cells(P, env, h, sp, o);      // render_edit, :358 (a finished env is repainted whole below)
     }
     // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
@@ -1177,7 +1201,10 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         }
         const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
         const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
-        if (lane == 0) store_episode_records(P, env_l, r, true);           // step_num >= 1 here
+        if (lane == 0) {
+            store_episode_records(P, env_l, r, true);                       // step_num >= 1 here
+            if (P.lookahead) queue_for_refill(P, env_l);
+        }
         if (lane == l) {
             h = reset_header(P, r, menu_id);
             unpack_pos(r.init_pos, sp);

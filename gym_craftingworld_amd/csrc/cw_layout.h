@@ -28,6 +28,7 @@
 // Slot k initially holds object k (code k+1) -- OBJECTS order, ray.py:21.
 
 #define CW_CODES_INITIAL 0x87654321u  // slot k has code k+1
+#define CW_NX_QUEUED 0x40000000u      // nx_misc.z: the env is on the refill list (its record was taken, or it was reset the slow way)
 
 // One ordered selected_tasks list, device form (cw_task_menu packed): selected_bits as nibbles.
 struct CwMenuDev {
@@ -83,6 +84,7 @@ struct CwParams {
     uint16_t *achieved_out;  // [N]
     uint16_t *desired_out;   // [N]
     int32_t *episode_length; // [N]
+    int32_t *episode_return; // [N] sum of the finished episode's rewards (ray.py:361-367), written where done
     uint8_t *obs;            // [N][P][P][3] or null
     uint8_t *desired_img;
     uint8_t *init_img;
@@ -93,12 +95,15 @@ struct CwParams {
     // that finishes again before the next refill finds no record and is reset the slow way, on the spot, from the same stream position.
     uint4 *nx_init_pos;      // [N] sample_state placement of the next episode
     uint4 *nx_goal_pos;      // [N] its imagine_obs final state
-    uint4 *nx_misc;          // [N] x = init_agent | goal_agent << 16, y = goal_codes, z = desired | subset << 16 | VALID << 31,
-                             //     w = raw 32-bit draws the record consumed (cw_get_mt rewinds the exported stream by them)
+    uint4 *nx_misc;          // [N] x = init_agent | goal_agent << 16, y = goal_codes, z = desired | subset << 16 | QUEUED << 30 | VALID << 31
+                             //     (QUEUED: the env is on the refill list), w = raw 32-bit draws the record consumed (cw_get_mt rewinds the
+                             //     exported stream by them)
     int32_t *refill_list;    // [N] envs whose record was taken since the last refill (each at most once)
     int32_t *refill_count;   // [2] entries, release ticket
     int32_t lookahead;       // 0: no records are kept (engines without auto-reset, host-mapped engines, CW_TUNE_LOOKAHEAD=0)
-    unsigned long long *counters; // [4] steps, finished, successes, invalid actions (+ [4]: the finished count the last sweep of the observation array saw)
+    unsigned long long *counters; // [4] public: steps, finished, successes, invalid actions; [4] PRIVATE: the finished count the last sweep of the
+                                  // observation array saw (cw_render_pieces_kernel: what kind of step does it follow?), [5] PRIVATE: resets of
+                                  // look-ahead engines that found no record and were taken the slow way; 8 words allocated
     const CwMenuDev *menus;
     // constants
     int32_t n_envs;

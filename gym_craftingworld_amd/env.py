@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import seeding
+from .coord import GridPos
 from .spaces import Box, Dict, Discrete
 from .vec_env import ACTION_NAMES, TASK_LIST, CraftingWorldVecEnv
 
@@ -55,9 +56,13 @@ class CraftingWorldEnv:
                                            init_observation=img()))                # ray.py:85-92
         self.observation_vector_space = v.observation_vector_space                # ray.py:94-110
         self.action_space = Discrete(len(ACTION_NAMES))                            # ray.py:133
-        self.ACTIONS = list(ACTION_NAMES)
+        # ray.py:130-131: the four moves are Coord offsets carrying their name, pickup / drop plain strings
+        self.ACTIONS = [GridPos(-1, 0, name='up'), GridPos(0, 1, name='right'), GridPos(1, 0, name='down'), GridPos(0, -1, name='left'),
+                        'pickup', 'drop']
+        assert [getattr(a, 'name', a) for a in self.ACTIONS] == list(ACTION_NAMES)
         self.ep_no = 0
         self.step_num = 0
+        self._has_reset = False                     # (ray.py:119-124: obs_one_hot, agent_pos, INIT_OBS_VECTOR, observation_vector are None until reset())
         # the engine's host-mapped buffers (row 0 of the batch of one)
         self._h_obs, self._h_goal, self._h_init = (t[0].numpy() for t in (v._obs, v._desired_img, v._init_img))
         self._h_reward, self._h_done = v.reward.numpy(), v._done_u8.numpy()
@@ -105,6 +110,9 @@ class CraftingWorldEnv:
             os.makedirs('renders/env{}'.format(self.env_id), exist_ok=False)
             self._gif_frames = []
 
+    def _gif_wanted(self):
+        return True                                 # (hook: the Flat class saves only some episodes)
+
     def _gif_frame(self):
         a, b = np.asarray(self.obs_image, np.uint8), np.asarray(self.desired_goal, np.uint8)
         if a.shape != b.shape:
@@ -123,20 +131,63 @@ class CraftingWorldEnv:
     # -- reference attributes derived from the device state on demand --------------------
     @property
     def obs_one_hot(self):
+        if not self._has_reset:
+            return None
         return self._vec.one_hot()[0].cpu().numpy().astype(int)
 
     @property
     def agent_pos(self):
+        """ray.py:624-626: Coord(row, col, max_row=STATE_W - 1, max_col=STATE_H - 1) -- here a GridPos (coord.py: .row, .col, .tuple(),
+        clamped + and -, and it still compares equal to / unpacks like the (row, col) pair this attribute used to be)."""
+        if not self._has_reset:
+            return None
         r, c = self._vec.agent_rc[0].cpu().tolist()
-        return (r, c)
+        return GridPos(r, c, self.STATE_W - 1, self.STATE_H - 1)
 
     @property
     def INIT_OBS_VECTOR(self):
+        if not self._has_reset:
+            return None
         st = self._vec.get_state()
         return _one_hot_from(st['init_grid'][0], st['init_agent_rc'][0], 0)
 
+    @property
+    def observation_vector(self):
+        """ray.py:185-187, 354-356: the state-vector counterpart of `observation` -- obs_one_hot, the two goal vectors (the live (1, T) arrays
+        that info carries) and INIT_OBS_VECTOR.  Built from the device state when read (None before the first reset(), ray.py:124)."""
+        if not self._has_reset:
+            return None
+        return {'observation': self.obs_one_hot, 'desired_goal': self.desired_goal_vector, 'achieved_goal': self.achieved_goal_vector,
+                'init_observation': self.INIT_OBS_VECTOR}
+
+    @property
+    def fixed_state_list(self):
+        """ray.py:116-118: the fixed_init_state one-hot placements generate_fixed_states drew at construction (AttributeError when
+        fixed_init_state == 0: the reference never sets the attribute then)."""
+        if not self.fixed_init_state:
+            raise AttributeError("%r object has no attribute 'fixed_state_list'" % type(self).__name__)
+        S, out = self.STATE_W, []
+        for cells in self._vec.fixed_states()[0]:
+            oh = np.zeros((S, S, 12), dtype=int)
+            for k in range(9):                      # channels 0-7 the objects, 8 the agent (ray.py:605-608)
+                oh[cells[k] // S, cells[k] % S, k] = 1
+            out.append(oh)
+        return out
+
     def seed(self, seed=None):
         return self._vec.seed(seed)                                               # ray.py:145-147
+
+    def generate_fixed_states(self, num_states=None):
+        """ray.py:149-154: draw the fixed_init_state placements again from the env's CURRENT stream position (the constructor did it once,
+        ray.py:116-118; a caller who pins the stream afterwards -- `env.np_random = RandomState(...)` -- redraws the pool here, as assigning
+        `env.fixed_state_list = env.generate_fixed_states(k)` does in the reference).  The pool's size is fixed at construction."""
+        if not self.fixed_init_state:
+            raise ValueError('the env was built with fixed_init_state=0')
+        if num_states is not None and int(num_states) != self.fixed_init_state:
+            raise ValueError('the pool holds fixed_init_state=%d placements' % self.fixed_init_state)
+        from . import _lib as L
+        L.check(self._lib.cw_generate_fixed_states(self._eng, self._stream), 'cw_generate_fixed_states', self._lib)
+        return self.fixed_state_list
 
     @property
     def np_random(self):
@@ -182,12 +233,13 @@ class CraftingWorldEnv:
         return self.observation
 
     def reset(self, render_next=False):
-        if self.store_gif is True and self.step_num != 0 and self.ep_no % self.render_save_rate == 0 and self._gif_frames:
+        if self.store_gif is True and self.step_num != 0 and self.ep_no % self.render_save_rate == 0 and self._gif_frames and self._gif_wanted():
             self._gif_save()                                                      # ray.py:160-167
         if self.step_num != 0:                                                    # ray.py:200-201
             self.ep_no += 1
         self.step_num = 0
         self._vec.reset()                                                          # returns after the stream sync
+        self._has_reset = True
         if not self._live:
             self.obs_image[...] = self._h_obs
             self.desired_goal[...] = self._h_goal
@@ -207,6 +259,13 @@ class CraftingWorldEnv:
         a = int(action)
         if not 0 <= a < 6:
             raise IndexError('list index out of range')                           # ACTIONS[action], ray.py:308
+        if not self._has_reset:
+            # the reference's own failure for a step() before the first reset(): step_num has been counted (ray.py:309), then agent_pos is None --
+            # `None + Coord` for a move (ray.py:393), `None.tuple()` for pickup / drop (ray.py:315, :330)
+            self.step_num += 1
+            if a < 4:
+                raise TypeError("unsupported operand type(s) for +: 'NoneType' and 'Coord'")
+            raise AttributeError("'NoneType' object has no attribute 'tuple'")
         if self._resident:
             rc = self._step_resident(self._eng, a, self._want_onehot)               # doorbell + spin: no launch, no stream sync
         else:
@@ -273,6 +332,10 @@ class CraftingWorldEnvFlat(CraftingWorldEnv):
                          stacking=stacking, reward_style=reward_style, **kw)
         P = 4 * self.STATE_W
         self.observation_space = Box(low=0, high=255, shape=(P, P, 3), dtype=self._dtype)   # flat.py:57
+
+    def _gif_wanted(self):
+        # craftingworld_flat.py:64-71: the finished episode's GIF is written only if it achieved something or every 30th episode
+        return bool((self.achieved_goal_vector[0] == 1).any()) or self.ep_no % 30 == 0
 
     def reset(self, render_next=False):
         super().reset()

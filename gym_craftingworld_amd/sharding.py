@@ -52,8 +52,14 @@ def agree_on_rccl(device, timeout_s=60, new_group=None, log=None):
     on EVERY rank, over gloo otherwise: either everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  Two rounds, each closed
     by a MIN-reduce of the ranks' "ok" flags over gloo BEFORE anybody depends on the other ranks having got as far: (1) creating the group (nothing is
     sent yet: a rank that fails here keeps its peers out of RCCL's first collective, where they would otherwise wait out the group's timeout);
-    (2) one all-reduce on it.  A group that failed is destroyed.  -> (group or None, None or the reason as text).  Needs the default (gloo) group."""
+    (2) one all-reduce on it.  A group that failed is destroyed.  -> (group or None, None or the reason as text).  Needs the default (gloo) group.
+    The group is created with TORCH_NCCL_BLOCKING_WAIT=1 (unless the caller's environment says otherwise): a rank whose peers never arrive in the
+    probe -- theirs threw -- gets an exception after `timeout_s` instead of a kernel that spins until somebody kills the job, reaches the second
+    round and lands on gloo with everybody else.  torch's asynchronous error handling stays at its default: should a later timing collective
+    hang, the watchdog ends the rank (non-zero) after the group's timeout and launch.py stops the others."""
     import datetime
+    import os
+    os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')      # (read when the group is created)
     new_group = new_group or dist.new_group
     world = dist.get_world_size()
 

@@ -180,9 +180,11 @@ class CraftingWorldVecEnv:
         self.achieved_mask = v(tab.achieved, (N,), torch.int16)      # bit i = task_list[i] (bit pattern of a u16)
         self.desired_mask = v(tab.desired, (N,), torch.int16)
         self.episode_length = v(tab.episode_length, (N,), torch.int32)
+        self.episode_return = v(tab.episode_return, (N,), torch.int32)   # sum of the finished episode's rewards (ray.py:361-367), valid where done
         self.hdr = dv(tab.hdr, (N, 16), torch.uint8)                 # packed current state, layout in craftingworld.h
         self.slot_pos = dv(tab.slot_pos, (N, 8), torch.int16)
         self.counters = dv(tab.counters, (4,), torch.int64)
+        self._counters_raw = dv(tab.counters, (8,), torch.int64)     # (+ the engine's private words, craftingworld.h: tests only)
         self.agent_rc = self.hdr[:, 0:2]
         self.hold = self.hdr[:, 2]
 
@@ -263,6 +265,7 @@ class CraftingWorldVecEnv:
             self.set_rng_states(keys, pos)
         else:
             arr = np.array([s & 0xFFFFFFFF for s in seeds], dtype=np.uint32)
+            self._settle()
             L.check(self._lib.cw_seed_int(self._h, arr.ctypes.data_as(C.c_void_p)), 'cw_seed_int', self._lib)
         return seeds
 
@@ -272,12 +275,14 @@ class CraftingWorldVecEnv:
         pos = np.ascontiguousarray(pos, dtype=np.int32)
         if keys.shape != (self.num_envs, L.CW_MT_N) or pos.shape != (self.num_envs,):
             raise ValueError('keys must be [N,624] and pos [N]')
+        self._settle()
         L.check(self._lib.cw_seed_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_seed_mt', self._lib)
 
     def get_rng_states(self):
         """-> (keys uint32 [N,624], pos int32 [N]) accepted by RandomState.set_state, same stream."""
         keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
         pos = np.empty(self.num_envs, dtype=np.int32)
+        self._settle()
         L.check(self._lib.cw_get_mt(self._h, keys.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p)), 'cw_get_mt', self._lib)
         return keys, pos
 
@@ -290,6 +295,12 @@ class CraftingWorldVecEnv:
 
     def _sync(self):
         L.check(self._lib.cw_synchronize(self._h, self._stream()), 'cw_synchronize', self._lib)
+
+    def _settle(self):
+        """Ahead of a synchronous library call (seeding, state get/set, checkpoints): wait for torch's CURRENT stream.  The library waits for the
+        streams the engine was handed by itself -- but a replayed HIP graph runs wherever torch replays it, which the engine never sees."""
+        if getattr(self, '_h', None):
+            self._lib.cw_synchronize(self._h, self._stream())
 
     def synchronize(self):
         """Block until everything this env enqueued on the current stream (and on its own side stream) has finished."""
@@ -352,8 +363,11 @@ class CraftingWorldVecEnv:
         self._pending = False
         if self.host_outputs:
             self._sync()
+        # 'episode': the finished episode's statistics the way gym's RecordEpisodeStatistics reports them (r: return = the sum of its rewards,
+        # ray.py:361-367; l: length), as device tensors, rows valid where done (SURVEY 5 "metrics")
         info = {'task_success': self.achieved_mask, 'desired_goal': self.desired_mask,
-                'achieved_goal': self.achieved_mask, 'episode_length': self.episode_length}
+                'achieved_goal': self.achieved_mask, 'episode_length': self.episode_length,
+                'episode': {'r': self.episode_return, 'l': self.episode_length}}
         if self.terminal_observation is not None:
             info['terminal_observation'] = self.terminal_observation     # rows valid where done
         return self._observation(), self.reward, self.done, info
@@ -380,12 +394,9 @@ class CraftingWorldVecEnv:
         """-> a torch.cuda.CUDAGraph that takes K = actions.shape[0] steps per replay(), reading row t of the device tensor `actions` [K, N] on
         step t: fill the tensor IN PLACE (the ring a policy or an action sampler writes into), call graph.replay(), read the views.  One graph
         launch per K steps instead of K library calls: the way to run the launch-bound modes (state-only, dirty-cell frames) at the card's pace
-        rather than the host's.  The envs' episode bookkeeping needs nothing from the host, so replays can be queued back to back."""
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):                    # torch's capture warm-up protocol: the same calls once, eagerly, on a side stream
-            self.step_many(actions)
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        rather than the host's.  The envs' episode bookkeeping needs nothing from the host, so replays can be queued back to back.
+        Capturing takes NO step: nothing runs until the first replay() (cw_step_many allocates nothing and launches nothing lazily, so torch's
+        eager warm-up pass is not needed -- it would advance every env by K steps on whatever the tensor holds at that moment)."""
         self.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -454,6 +465,14 @@ class CraftingWorldVecEnv:
         bits = torch.arange(len(self.task_list), device=mask.device, dtype=torch.int32)
         return ((mask.to(torch.int32).unsqueeze(1) >> bits) & 1).to(torch.uint8)
 
+    def fixed_states(self):
+        """generate_fixed_states' pool (ray.py:116-118, 149-154: fixed_state_list) as cell indices: uint16 [N, K, 9] = the cells (row * S + col)
+        of objects 0..7 (OBJECTS order) and of the agent in each of the K pooled placements of every env.  ValueError when fixed_init_state == 0."""
+        out = np.empty((self.num_envs, max(self.fixed_init_state, 1), 9), dtype=np.uint16)
+        self._settle()
+        L.check(self._lib.cw_get_fixed_states(self._h, out.ctypes.data_as(C.c_void_p)), 'cw_get_fixed_states', self._lib)
+        return out
+
     def get_state(self):
         """Host snapshot (numpy) of every env: the de-facto checkpoint."""
         N, S = self.num_envs, self.size
@@ -463,6 +482,7 @@ class CraftingWorldVecEnv:
                    hold=np.empty(N, np.uint8), achieved=np.empty(N, np.uint16), desired=np.empty(N, np.uint16),
                    step_num=np.empty(N, np.int32), ep_no=np.empty(N, np.int32))
         view = L.cw_state_view(**{k: a.ctypes.data_as(C.c_void_p) for k, a in out.items()})
+        self._settle()
         L.check(self._lib.cw_get_state(self._h, C.byref(view)), 'cw_get_state', self._lib)
         return out
 
@@ -482,6 +502,7 @@ class CraftingWorldVecEnv:
             if keep[k].shape[0] != self.num_envs:
                 raise ValueError('%s must have num_envs rows' % k)
             setattr(view, k, keep[k].ctypes.data_as(C.c_void_p))
+        self._settle()
         L.check(self._lib.cw_set_state(self._h, C.byref(view)), 'cw_set_state', self._lib)
 
     # ------------------------------------------------------------------ checkpoint / resume
@@ -491,6 +512,7 @@ class CraftingWorldVecEnv:
         step's outputs, counters) behind a header that pins the configuration (cw_checkpoint_save; synchronises)."""
         n = int(self._lib.cw_checkpoint_bytes(self._h))
         buf = np.empty(n, dtype=np.uint8)
+        self._settle()
         L.check(self._lib.cw_checkpoint_save(self._h, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_save', self._lib)
         with open(path, 'wb') as f:
             buf.tofile(f)
@@ -501,6 +523,7 @@ class CraftingWorldVecEnv:
         the state-mode observation tensors (hdr, slot_pos) equal the uninterrupted run's too; frames are repainted.  Per-env
         menu ids, reward rules, pools and counters come from the file."""
         buf = np.fromfile(path, dtype=np.uint8)
+        self._settle()
         L.check(self._lib.cw_checkpoint_load(self._h, buf.ctypes.data_as(C.c_void_p), buf.size), 'cw_checkpoint_load', self._lib)
         self._has_reset = True
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 4   /* 4: cw_tuner_state = {period16, period16_head, period16_busy, lookahead, resident, guard_slowdowns}; one painter, look-ahead records */
+#define CW_ABI_VERSION 5   /* 5: cw_buffer_table.episode_return, cw_get_fixed_states; 4: cw_tuner_state, one painter, look-ahead records */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
@@ -107,13 +107,19 @@ typedef struct cw_buffer_table {
     uint16_t *achieved;      /* [N]  achieved_goal_vector as a bit mask AFTER the step, BEFORE auto-reset */
     uint16_t *desired;       /* [N]  desired_goal_vector of the episode the step belonged to       */
     int32_t *episode_length; /* [N]  step_num at done (valid where done==1)                        */
+    int32_t *episode_return; /* [N]  sum of the rewards of the episode that just ended (valid where done==1), as the reference's loop sums
+                              *      them (ray.py:361-367: -1 per step, MAX_STEPS on a successful last step): max_steps - (length - 1)
+                              *      after a success, -length after a time-out                         */
     uint8_t *hdr;            /* [N][16] packed per-env header of the CURRENT state (after auto-reset):
                               *   byte 0 agent row, 1 agent col, 2 hold (0 none,1 sticks,2 axe,3 hammer), 3 menu id,
                               *   bytes 4-5 achieved mask (LE u16), 6-7 desired mask, 8-9 step_num, 10-11 flags (bit 0: no step
                               *   taken yet in this episode, bit 1: subset reward rule),
                               *   bytes 12-15 the 8 object slots' codes, 4 bits each (slot k in bits 4k..4k+3)      */
     uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
-    uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions} */
+    uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions}; the allocation holds
+                              *      8 words: [4] is the engine's own (the finished count the last sweep of the observation array saw --
+                              *      the sweep paces its first jobs by what the step before it did), [5] counts resets of a look-ahead engine that
+                              *      found no record waiting (performance diagnostics), [6..7] unused.  Read-only for callers. */
     size_t frame_bytes;      /* P*P*3 (CW_RASTER_RAY) or (3S+3)*3S*3 (CW_RASTER_ALT) */
     int32_t *host_actions;   /* [N]  cw_config.host_outputs only (else NULL): mapped host buffer usable as cw_step's actions (CW_ACT_I32) */
     uint8_t *host_onehot;    /* [S][S][12] engines that can run cw_step_resident only (else NULL): obs_one_hot (ray.py:119) of the env in pinned host
@@ -144,7 +150,13 @@ int cw_destroy(cw_engine *e);
  * cw_seed_mt injects numpy RandomState states: keys[N][624], pos[N] (RandomState.get_state()[1:3]).
  * cw_seed_int seeds env i like numpy RandomState(seeds[i]) (init_genrand).  Both are synchronous
  * host calls; the conversion itself runs on the device, one lane per env.  cw_get_mt returns states a numpy RandomState accepts via set_state and that
- * continue the identical stream. */
+ * continue the identical stream.
+ * These and the other synchronous entry points (cw_get_state, cw_set_state, cw_get_fixed_states, cw_checkpoint_*) wait for THIS ENGINE'S
+ * work only -- whatever it enqueued on the streams it was handed since the last wait -- and do their copies on a stream of the engine's
+ * own: another engine on the same device, or a learner, is not stalled (no device-wide synchronisation).  A stream handed to an enqueueing
+ * call should stay alive until cw_synchronize on it (or one of these calls) has returned; if it was destroyed earlier the engine falls
+ * back to one device-wide wait.  Work the engine cannot know of -- replays of a HIP graph its calls were captured into run on whatever
+ * stream the graph is launched on -- is the caller's to wait for (cw_synchronize on that stream) before a synchronous call. */
 int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos);
 int cw_seed_int(cw_engine *e, const uint32_t *seeds);
 int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos);
@@ -152,6 +164,9 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos);
 /* generate_fixed_states (ray.py:149-154): draw fixed_init_state placements per env from the
  * env's current RNG stream.  No-op when fixed_init_state == 0.  Returns after the pool is complete (one-time cost). */
 int cw_generate_fixed_states(cw_engine *e, cw_stream_t stream);
+/* fixed_state_list (ray.py:116-118): the pool as cell indices, HOST array out[N][K][9] uint16 = the cells (row*S+col) of objects 0..7
+ * (OBJECTS order, ray.py:21) and of the agent in each of the K placements of every env.  Synchronous; CW_ERR_INVALID when K == 0. */
+int cw_get_fixed_states(cw_engine *e, uint16_t *out);
 
 /* --- reset() for every env (ray.py:156-218): task draw, placement, imagine_obs, render ------ */
 int cw_reset(cw_engine *e, cw_stream_t stream);
@@ -230,28 +245,28 @@ int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity);
 int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length);
 
 /* --- per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg) -----
- * cw_profile_begin: from now on cw_step brackets each of its kernels with hipEventRecord on the
- * stream it launches on (at most max_steps steps are kept).  cw_profile_end: synchronises the
- * events, returns average durations in milliseconds and stops recording. */
+ * cw_profile_begin: from now on cw_step brackets its kernels with hipEventRecord on the stream it launches on (at most max_steps
+ * steps are kept).  cw_profile_end: synchronises the events, returns durations in milliseconds and stops recording.
+ * What is bracketed: in CW_OBS_PIXELS_FULL only the sweep of the observation array (cw_render_pieces_kernel; all chunk launches of a large
+ * batch together) -- every event record costs the stream a pipeline bubble, and the step kernel in front of the sweep is short; in the
+ * other two modes the step kernel (cw_step_fused_kernel / cw_step_kernel), which is the whole step there.  The look-ahead refill
+ * (cw_refill_kernel, every max_steps/4-th step) is never bracketed. */
 typedef struct cw_profile {
     int32_t steps;           /* cw_step calls recorded */
-    float ms_step_kernel;    /* average per launch (0 where not bracketed, see ms_reset_kernel) */
-    float ms_reset_kernel;   /* in the overlapped full-pixel step only the render kernel is bracketed unless
-                              * CW_PROFILE_SIDE_STREAM=1: every event record costs a pipeline bubble and side-stream
-                              * events perturb the overlap they measure */
-    float ms_render_kernel;  /* 0 in CW_OBS_STATE */
+    float ms_step_kernel;    /* average per launch; 0 in CW_OBS_PIXELS_FULL (not bracketed there) */
+    float ms_reset_kernel;   /* always 0 since ABI 4: no reset kernel runs inside a step (finished envs take look-ahead records in the step kernel) */
+    float ms_render_kernel;  /* the sweep, average per step; 0 in CW_OBS_STATE and CW_OBS_PIXELS_DIRTY */
     float ms_render_kernel_max;
     float ms_render_kernel_min;
-    float ms_render_kernel_median;   /* (the one-launch step's average includes the launches on which every env is reset) */
+    float ms_render_kernel_median;
 } cw_profile;
 int cw_profile_begin(cw_engine *e, int max_steps);
 int cw_profile_end(cw_engine *e, cw_profile *out);
-/* Name of the kernel that ms_render_kernel brackets for this engine (what a rocprofv3 kernel trace of the same run lists it as):
- * "cw_render_pieces_step_kernel" / "cw_render_step_kernel" / "cw_render_frames_step_kernel" (full-frame render + the auto-resets beside it, one
- * launch: the sweep of aligned 4-KiB pieces -- a trace lists it as cw_render_pieces_step_kernel<0> (Ray raster) or <1> (AltObs) --, the sweep of
- * cell rows -- its eight placements are cw_render_step_kernel<0> .. <7>, cw_step measures which one to launch -- or frame per wave; cw_create
- * times the painters on the engine's batch and keeps the fastest), "cw_render_pieces_kernel" / "cw_render_kernel" / "cw_render_frames_kernel"
- * (the render alone), the step kernel's name in CW_OBS_PIXELS_DIRTY, or "" (CW_OBS_STATE: no render kernel).  A static string. */
+/* Name of the kernel that paints this engine's frames, as a rocprofv3 kernel trace of the same run lists it (without template arguments):
+ * CW_OBS_PIXELS_FULL: "cw_render_pieces_kernel" -- the one painter of whole frame arrays, a clocked sweep of aligned 4-KiB pieces; a trace
+ * shows cw_render_pieces_kernel<raster, frames per job> (<0, 2> for Ray frames of 4 KiB and more, <1, 2> AltObs; 4 / 8 / 16 frames per job for
+ * smaller frames); this is what ms_render_kernel brackets.  CW_OBS_PIXELS_DIRTY: the step kernel itself, which repaints the <= 2 changed cells
+ * ("cw_step_fused_kernel" with auto_reset, else "cw_step_kernel").  CW_OBS_STATE: "" (nothing is painted).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 
 /* What the engine's tuning holds (full-frame mode): the period of the sweep's clock -- a wave starts a 4-KiB piece every

@@ -137,6 +137,7 @@ def test_random_batch_vs_oracle(case, obs_mode):
     acts = np.random.RandomState(5).randint(0, 6, size=(T, N)).astype(np.int64)
     dacts = torch.as_tensor(acts, device=env.device)
     n_done = 0
+    ret, length = np.zeros(N, np.int64), np.zeros(N, np.int64)         # the oracle's running episode return / length (ray.py:361-367 summed by the loop)
     for t in range(T):
         obs, rew, done, info = env.step(dacts[t])
         # terminal masks must be read before the oracle resets
@@ -151,6 +152,14 @@ def test_random_batch_vs_oracle(case, obs_mode):
         assert np.array_equal(rew.cpu().numpy(), o_rew), ('reward', t)
         assert np.array_equal(done.cpu().numpy(), o_done), ('done', t)
         assert np.array_equal(info['achieved_goal'].cpu().numpy().astype(np.int64) & 0xFFFF, o_ach), ('achieved', t)
+        ret += o_rew
+        length += 1
+        if o_done.any():                                 # info['episode'] = {'r', 'l'}: device tensors, rows valid where done
+            assert np.array_equal(info['episode']['r'].cpu().numpy()[o_done], ret[o_done]), ('episode return', t)
+            assert np.array_equal(info['episode']['l'].cpu().numpy()[o_done], length[o_done]), ('episode length', t)
+            assert info['episode']['l'] is info['episode_length'] and info['episode']['r'] is env.episode_return
+            ret[o_done] = 0
+            length[o_done] = 0
         n_done += int(o_done.sum())
         if t % 37 == 0 or t == T - 1:
             _compare_full(env, ora, obs_mode, t)
@@ -474,11 +483,8 @@ def test_step_many_and_captured_graphs_equal_stepping(obs_mode, K):
     eager, many, graphed = envs
     gen = torch.Generator(device='cuda').manual_seed(8)
     ring = torch.zeros((K, N), dtype=torch.uint8, device='cuda')
-    graph = graphed.capture_steps(ring)                      # (the warm-up pass inside stepped `graphed` K times with zeros ...)
-    zeros = torch.zeros((K, N), dtype=torch.uint8, device='cuda')
-    many.step_many(zeros)                                    # (... so the twins take the same K steps)
-    for t in range(K):
-        eager.step(zeros[t])
+    graph = graphed.capture_steps(ring)                      # (capturing takes no step: the twins start level)
+    assert int(graphed.counters[0]) == 0
     for r_ in range(rounds):
         acts = torch.randint(0, 6, (K, N), device='cuda', dtype=torch.uint8, generator=gen)
         ring.copy_(acts)
@@ -1610,6 +1616,12 @@ def test_checkpoint_resume_is_bit_identical(obs_mode, raster, pool, tmp_path):
             b.step(acts[90 + t])
     b.load_checkpoint(path)                           # pool > 0: straight into an engine that was never reset
     assert torch.equal(a.hdr, b.hdr) and torch.equal(a.slot_pos, b.slot_pos) and torch.equal(a.counters, b.counters)
+    # the engine's private word -- the finished count the last sweep of the observation array saw -- travels too: the resumed engine's first sweep
+    # sees the step it follows as the uninterrupted run's would (round 4 restored 4 of the 5 words: `finished` = counters[1] - 0, a storm launch)
+    assert int(b._counters_raw[4]) == int(a._counters_raw[4]) and int(b._counters_raw[4]) <= int(b.counters[1])
+    if obs_mode == 'pixels':
+        assert int(b._counters_raw[4]) == int(b.counters[1])
+    assert torch.equal(a.episode_return, b.episode_return) and torch.equal(a.episode_length, b.episode_length)
     if obs_mode != 'state':
         oa, ob = a._observation(), b._observation()
         for k in oa:
@@ -2002,3 +2014,193 @@ def test_render_of_arbitrary_one_hot_states():
     with pytest.raises(ValueError):
         exact.render(state=np.zeros((S + 1, S, 12), int))
     exact.close(); wrap.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode,consumer', [('pixels', 'reduce'), ('pixels_dirty', 'reduce'), ('pixels', 'conv')])
+def test_policy_in_the_loop_actions_replay_through_the_oracle(obs_mode, consumer):
+    """SURVEY 8b's callers: a torch policy consuming the device tensors without host copies (docs/source/envs/gen_info.rst:62-82 with a network where
+    the reference samples; ray.py:376-378 hands the observation back).  Between two steps a consumer reads EVERY observation byte and produces the
+    next actions from it (bench.py's --consumer), all on the env's stream, no host synchronisation inside the loop: 200 steps of 4 096 envs.  Then
+    the RECORDED actions go through the oracle: rewards, dones and frames must be the oracle's, and -- `reduce`, whose policy a host can restate
+    exactly -- every recorded action must be what the policy computes from the ORACLE's frame of that step: a consumer that read a frame before the
+    sweep (or the step kernel's repaint) had written it would have taken another action."""
+    import bench
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T = 4096, 200
+    kw = dict(size=(21, 21), max_steps=37)                # (episodes end inside the run, at spread-out steps once some succeed)
+    keys, pos = _np_states(N, 52000)
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, **kw)
+    env.set_rng_states(keys, pos)
+    policy = bench.make_consumer(consumer, N, env.frame_shape, env.device)
+    obs = env.reset()
+    # spread the episode phases out: envs finish on every step, so frames of freshly reset envs are consumed on every step too
+    env.set_state(step_num=(np.arange(N) % 30).astype(np.int32))
+    rec_a = torch.empty((T, N), dtype=torch.uint8, device=env.device)
+    rec_r = torch.empty((T, N), dtype=torch.int32, device=env.device)
+    rec_d = torch.empty((T, N), dtype=torch.bool, device=env.device)
+    a = policy(obs['observation'])
+    for t in range(T):                                     # nothing in this loop waits for the card
+        rec_a[t] = a
+        obs, r, d, _ = env.step(a)
+        rec_r[t] = r
+        rec_d[t] = d
+        a = policy(obs['observation'])
+    torch.cuda.synchronize()
+    acts, rews, dones = rec_a.cpu().numpy(), rec_r.cpu().numpy(), rec_d.cpu().numpy()
+    final = obs['observation'].cpu().numpy()
+    goal = obs['desired_goal'].cpu().numpy()
+    ora = OracleBatch(N, rng_states=list(zip(keys, pos)), **kw)
+    ora.reset()
+    for i, e in enumerate(ora.envs):                       # the same phase spread (step_num only)
+        s = e.state()
+        e.set_state(s['grid'], s['init_grid'], s['agent'], s['hold'], s['achieved'], s['desired'], i % 30)
+    ish = ora.envs[0].img_shape
+    n_done = 0
+    for t in range(T):
+        if consumer == 'reduce':
+            want = np.array([int(np.ctypeslib.as_array(e.view().obs, shape=ish).sum(dtype=np.int64)) % 6 for e in ora.envs], dtype=np.uint8)
+            bad = np.nonzero(want != acts[t])[0]
+            assert bad.size == 0, ('step', t, 'envs whose action was not computed from the finished frame', bad[:8], acts[t][bad[:8]], want[bad[:8]])
+        o_rew, o_done = ora.step(acts[t])
+        assert np.array_equal(rews[t], o_rew), ('reward', t)
+        assert np.array_equal(dones[t], o_done), ('done', t)
+        n_done += int(o_done.sum())
+    assert n_done > 2 * N                                  # every env was reset several times on the way
+    for i in list(range(0, N, 61)) + [N - 1]:
+        s = ora.envs[i].state()
+        assert np.array_equal(final[i], s['obs']) and np.array_equal(goal[i], s['desired_img']), i
+    assert int(env.counters[1].item()) == n_done
+    env.close()
+
+
+@pytest.mark.gpu
+def test_facade_reference_attributes_live():
+    """The attributes reference users read off CraftingWorldEnvRay (ray.py:119-141, 185-187, 624-626): None before the first reset()
+    and the reference's own exceptions for a step() before it; afterwards agent_pos is a Coord-like value (.row / .col / .tuple(), == tuples),
+    observation_vector holds the one-hot state and the live goal vectors, fixed_state_list the pooled placements -- those against the fixture
+    the reference class itself produced with fixed_init_state=3 (every reset state of the fixture is one of the three)."""
+    import gym_craftingworld_amd as cw
+    from gym_craftingworld_amd.coord import GridPos
+    meta, kw, g = load('ray6_fixedinit')
+    env = cw.CraftingWorldEnv(**kw)
+    assert env.agent_pos is None and env.obs_one_hot is None and env.INIT_OBS_VECTOR is None and env.observation_vector is None and env.observation is None
+    with pytest.raises(TypeError):
+        env.step(0)                                        # None + Coord, ray.py:393
+    with pytest.raises(AttributeError):
+        env.step(4)                                        # None.tuple(), ray.py:315
+    assert env.step_num == 2                               # (counted before the failure, ray.py:309)
+    env.step_num = 0
+    with pytest.raises(IndexError):
+        env.step(6)
+    assert [getattr(a, 'name', a) for a in env.ACTIONS] == ['up', 'right', 'down', 'left', 'pickup', 'drop'] and env.ACTIONS[0].tuple() == (-1, 0)
+    env.set_rng_state(g['key0'], int(g['pos0']))
+    pool = env.generate_fixed_states(3)                    # the constructor's draw, redone on the injected stream (ray.py:116-118)
+    assert len(pool) == 3 and all(p.shape == (6, 6, 12) and p.sum() == 9 and p[:, :, 9:].sum() == 0 for p in pool)
+    with pytest.raises(ValueError):
+        env.generate_fixed_states(4)
+
+    def key_of(grid, agent):
+        return (np.asarray(grid, np.uint8).tobytes(), tuple(int(x) for x in agent))
+    mine = {key_of((p[:, :, :8] * np.arange(1, 9)).sum(2), np.argwhere(p[:, :, 8] == 1)[0]) for p in env.fixed_state_list}
+    theirs = {key_of(g['r_grid'][i], g['r_agent'][i]) for i in range(len(g['r_grid']))}
+    assert len(mine) == 3 and theirs <= mine and len(theirs) >= 2
+    obs = env.reset()
+    ap = env.agent_pos
+    assert isinstance(ap, GridPos) and ap.tuple() == tuple(g['r_agent'][0]) and ap == tuple(g['r_agent'][0]) and (ap.row, ap.col) == tuple(g['r_agent'][0])
+    assert ap.max_row == 5 and ap.max_col == 5 and (ap + env.ACTIONS[0]).row == max(ap.row - 1, 0)
+    r, c = ap
+    ov = env.observation_vector
+    assert set(ov) == {'observation', 'desired_goal', 'achieved_goal', 'init_observation'}
+    assert ov['observation'].shape == (6, 6, 12) and ov['observation'][r, c, 8] == 1 and np.array_equal(ov['observation'], ov['init_observation'])
+    assert ov['desired_goal'] is env.desired_goal_vector and ov['achieved_goal'] is env.achieved_goal_vector and ov['desired_goal'].shape == (1, 9)
+    assert np.array_equal((ov['observation'][:, :, :8] * np.arange(1, 9)).sum(2), g['r_grid'][0])
+    for t in range(60):
+        o, rew, d, info = env.step(int(g['action'][t]))
+        assert rew == g['reward'][t] and env.agent_pos == tuple(g['agent'][t]), t
+        if d:
+            env.reset()
+    no_pool = cw.CraftingWorldEnv(size=(5, 5))
+    with pytest.raises(AttributeError):
+        no_pool.fixed_state_list
+    no_pool.close()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_synchronous_calls_wait_for_the_engines_own_streams_only():
+    """cw_seed_* / cw_get_mt / cw_get_state / checkpoints no longer synchronise the DEVICE (round 4: hipDeviceSynchronize stalled every other engine
+    and any learner on the card): they wait for the streams this engine was handed, and copy on a stream of their own.  Work enqueued on a torch
+    SIDE stream (non-blocking: the null stream does not wait for it) must be complete in what they return, with no synchronisation by the caller."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, T = 20000, 120
+    kw = dict(size=(21, 21), max_steps=25, obs_mode='pixels')
+    a, b = CraftingWorldVecEnv(N, seed=4, **kw), CraftingWorldVecEnv(N, seed=4, **kw)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    acts = torch.randint(0, 6, (T, N), device='cuda', dtype=torch.uint8, generator=gen)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a._settle = lambda: None                             # (the Python layer's own wait for torch's current stream: off, this is about the library's)
+    with torch.cuda.stream(side):
+        a.reset()
+        for t in range(T):
+            a.step_async(acts[t])
+        sa = a.get_state()                               # no wait in between: T sweeps are still queued on `side`
+        ka, pa = a.get_rng_states()
+    b.reset()
+    for t in range(T):
+        b.step_async(acts[t])
+    torch.cuda.synchronize()
+    sb = b.get_state()
+    kb, pb = b.get_rng_states()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(pa, pb) and np.array_equal(ka[:, 1:], kb[:, 1:])
+    with torch.cuda.stream(side):                        # ... and a re-seed issued behind queued work takes effect after it, not in the middle of it
+        for t in range(30):
+            a.step_async(acts[t])
+        a.seed(77)
+        a.reset()
+    for t in range(30):
+        b.step_async(acts[t])
+    b.seed(77)
+    b.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(a.hdr, b.hdr) and torch.equal(a._obs, b._obs) and torch.equal(a.counters, b.counters)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode', ['state', 'pixels_dirty'])
+def test_replayed_graph_gets_its_records_back_after_a_reseed(obs_mode):
+    """A captured graph bakes cw_refill_kernel in with all_envs = 0: it refills the LIST.  A re-seed drops every look-ahead record (they were computed from
+    the old streams) and empties the list; finished envs then reset the slow way -- and (round 5) put themselves on the list, so the next replay's refill
+    gives them records again.  Round 4 never did: every later episode of such an engine was reset the slow way, equal results at a permanent cost.
+    counters[5] (engine-private) counts slow resets: it must stop growing once the first episodes after the re-seed are over.  Results equal an
+    engine stepped eagerly all along."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, K = 6000, 6
+    kw = dict(size=(9, 9), max_steps=11, obs_mode=obs_mode, seed=5)
+    g_env, e_env = CraftingWorldVecEnv(N, **kw), CraftingWorldVecEnv(N, **kw)
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    ring = torch.randint(0, 6, (K, N), device='cuda', dtype=torch.uint8, generator=gen)
+    g_env.reset(); e_env.reset()
+    graph = g_env.capture_steps(ring)
+    assert int(g_env.counters[0]) == 0                   # capturing took no step (round 4's eager warm-up advanced every env by K steps)
+    for _ in range(4):
+        graph.replay()
+        e_env.step_many(ring)
+    g_env.seed(123); e_env.seed(123)                     # every record dropped on both
+    slow = []
+    for rep in range(14):
+        graph.replay()
+        e_env.step_many(ring)
+        torch.cuda.synchronize()
+        slow.append(int(g_env._counters_raw[5]))
+    assert slow[1] > 0                                   # the first episodes after the re-seed ended without a record ...
+    assert slow[-1] == slow[5], slow                     # ... and from then on every finished env finds one again
+    assert torch.equal(g_env.hdr, e_env.hdr) and torch.equal(g_env.slot_pos, e_env.slot_pos) and torch.equal(g_env.counters, e_env.counters)
+    ka, pa = g_env.get_rng_states(); kb, pb = e_env.get_rng_states()
+    assert np.array_equal(pa, pb) and np.array_equal(ka[:, 1:], kb[:, 1:])
+    g_env.close(); e_env.close()

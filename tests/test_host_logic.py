@@ -28,7 +28,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.ABI), (declared ^ set(_lib.ABI))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 4
+    assert lib.cw_abi_version() == _lib.CW_ABI_VERSION == 5
 
 
 def test_struct_layouts_match_header(lib, tmp_path):
@@ -270,3 +270,59 @@ def test_batch_space_adds_a_leading_axis():
     assert batch_space(Discrete(6), 5).nvec.tolist() == [6] * 5
 
 
+
+
+def test_gridpos_keeps_the_reference_coord_contract():
+    """agent_pos / ACTIONS of the N=1 classes are GridPos values (gym_craftingworld_amd/coord.py), the counterpart of the reference's Coord
+    (coordinates.py:6-42): row / col / max_row / max_col / name, + and - clamped to the grid (coordinates.py:22-30), tuple(), str() -- and, beyond the
+    reference, equality with a plain (row, col) pair and unpacking like one (what this attribute was in earlier rounds)."""
+    from gym_craftingworld_amd.coord import Coord, GridPos
+    assert Coord is GridPos
+    p = GridPos(3, 0, 20, 20)
+    assert (p.row, p.col, p.max_row, p.max_col, p.name) == (3, 0, 20, 20, None)
+    up, right, down, left = GridPos(-1, 0, name='up'), GridPos(0, 1, name='right'), GridPos(1, 0, name='down'), GridPos(0, -1, name='left')
+    assert (p + up).tuple() == (2, 0) and (p + left).tuple() == (3, 0) and (p + left) == p          # the west wall: "unchanged pos => fail", ray.py:395-396
+    q = GridPos(20, 20, 20, 20)
+    assert (q + down) == q and (q + right) == q and (q - down).tuple() == (19, 20) and (q + up).max_row == 20
+    assert (GridPos(0, 0, 4, 4) - GridPos(1, 1)).tuple() == (0, 0)
+    assert p == (3, 0) and p == [3, 0] and p == GridPos(3, 0) and p != (3, 1) and p != GridPos(0, 3) and not (p == 'up') and p != None  # noqa: E711
+    r, c = p
+    assert (r, c) == (3, 0) and p[0] == 3 and p[1] == 0 and len(p) == 2 and tuple(p) == p.tuple()
+    assert str(p) == '(3, 0)' and hash(p) == hash((3, 0)) and {p: 1}[GridPos(3, 0)] == 1
+    assert up.name == 'up' and 'up' in repr(up)
+
+
+def test_facades_declare_the_reference_attributes():
+    """Every public attribute SURVEY 8b lists for CraftingWorldEnvRay (ray.py:75-141), plus observation_vector (ray.py:185-187), fixed_state_list
+    (ray.py:116-118) and generate_fixed_states (ray.py:149-154), exists on the N=1 classes -- as a property, a method or an instance attribute the
+    constructor sets (read from the source: no GPU here)."""
+    import inspect
+    import gym_craftingworld_amd.env as envmod
+    src = inspect.getsource(envmod.CraftingWorldEnv)
+    names = ['observation_space', 'action_space', 'np_random', 'obs_one_hot', 'agent_pos', 'desired_goal_vector', 'achieved_goal_vector',
+             'INIT_OBS_VECTOR', 'step_num', 'ep_no', 'MAX_STEPS', 'STATE_W', 'STATE_H', 'observation_vector', 'observation_vector_space',
+             'fixed_state_list', 'generate_fixed_states', 'obs_image', 'INIT_OBS', 'desired_goal', 'observation', 'ACTIONS', 'task_list',
+             'selected_tasks', 'number_of_tasks', 'stacking', 'fixed_init_state', 'store_gif', 'render_save_rate', 'seed', 'reset', 'step', 'render',
+             'compute_reward', 'allow_gif_storage']
+    for n in names:
+        assert hasattr(envmod.CraftingWorldEnv, n) or ('self.%s = ' % n) in src or ('self.%s, ' % n) in src or (', self.%s = ' % n) in src, n
+    for cls in (envmod.CraftingWorldEnvFlat, envmod.CraftingWorldEnvOneHot, envmod.CraftingWorldEnvAltObs):
+        assert issubclass(cls, envmod.CraftingWorldEnv)
+    for prop in ('agent_pos', 'obs_one_hot', 'INIT_OBS_VECTOR', 'observation_vector', 'fixed_state_list', 'np_random'):
+        assert isinstance(getattr(envmod.CraftingWorldEnv, prop), property), prop
+
+
+def test_docs_name_only_kernels_that_exist():
+    """The public header, bench.py and the package's docstrings name kernels a rocprofv3 trace of a run would list: every cw_*_kernel they
+    mention must be a __global__ of csrc/cw_kernels.hip (round 4 left names of kernels that were gone)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip = open(os.path.join(root, 'gym_craftingworld_amd', 'csrc', 'cw_kernels.hip')).read()
+    defined = set(re.findall(r'__global__[^;{]*?\b(cw_\w+_kernel)\s*\(', hip))
+    assert {'cw_step_fused_kernel', 'cw_render_pieces_kernel', 'cw_refill_kernel', 'cw_reset_kernel'} <= defined
+    defined.add('cw_sweep_kernel')                       # (a host function of cw_kernels.hip: picks the sweep's template instance)
+    files = ['include/craftingworld.h', 'bench.py', 'INTEGRATION.md', 'README.md', 'gym_craftingworld_amd/vec_env.py', 'gym_craftingworld_amd/env.py',
+             'gym_craftingworld_amd/csrc/cw_engine.cpp', 'gym_craftingworld_amd/csrc/cw_layout.h', 'gym_craftingworld_amd/csrc/cw_kernels.hip']
+    for f in files:
+        for k in set(re.findall(r'\bcw_\w+_kernel\b', open(os.path.join(root, f)).read())):
+            assert k in defined, (f, k)

@@ -96,8 +96,11 @@ def _rccl_worker(rank, world, port, q, failing_rank, fail_at):
 
     def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
         if group == 'fake-rccl':
-            if rank == failing_rank and fail_at == 'probe':
-                raise RuntimeError('injected: ncclAllReduce failed')
+            if fail_at == 'probe':
+                if rank == failing_rank:
+                    raise RuntimeError('injected: ncclAllReduce failed')
+                time.sleep(2.0)                       # the healthy ranks wait for a peer that never arrives: blocking wait, then the group's timeout
+                raise RuntimeError('injected: timed out waiting for the probe all-reduce (blocking wait)')
             group = None
         return real_all_reduce(t, op=op, group=group)
 
@@ -109,24 +112,30 @@ def _rccl_worker(rank, world, port, q, failing_rank, fail_at):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('failing_rank,fail_at,expect_group', [(1, 'create', False), (0, 'create', False), (None, None, True)])
-def test_rccl_agreement_when_one_rank_fails(failing_rank, fail_at, expect_group):
-    """bench.py's timing collectives go over RCCL only if it works on EVERY rank (sharding.agree_on_rccl).  One of two ranks fails to create its
-    RCCL group (injected; the group is a gloo one here): both must land on gloo at once -- the healthy rank must not enter the group's first
-    collective and wait out its timeout.  Nobody fails: both keep the group."""
+@pytest.mark.parametrize('world,failing_rank,fail_at,expect_group', [
+    (2, 1, 'create', False), (2, 0, 'create', False), (2, 1, 'probe', False), (2, None, None, True),
+    (8, 3, 'create', False), (8, 5, 'probe', False), (8, None, None, True)])
+def test_rccl_agreement_when_one_rank_fails(world, failing_rank, fail_at, expect_group):
+    """bench.py's timing collectives go over RCCL only if it works on EVERY rank (sharding.agree_on_rccl).  One rank of two -- or a MIDDLE rank of the
+    eight of the driver's scaling run -- fails (injected; the group is a gloo one here), either when it creates its RCCL group or in the probe
+    all-reduce (its peers then wait in theirs until the blocking wait times out): every rank must land on gloo, within seconds of one another and
+    without waiting out the 20-s group timeout at the create stage.  Nobody fails: everybody keeps the group."""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q, failing_rank, fail_at)) for r in range(2)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q, failing_rank, fail_at)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    out = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert [o[1] for o in out] == [expect_group, expect_group], out
+    assert [o[1] for o in out] == [expect_group] * world, out
     assert all(o[3] < 15.0 for o in out), out                  # (nobody waited out the 20-s group timeout)
     if not expect_group:
-        assert 'injected' in out[failing_rank][2] and out[1 - failing_rank][2] == 'on another rank'
+        assert 'injected' in out[failing_rank][2]
+        for r in range(world):
+            if r != failing_rank:
+                assert out[r][2] == ('on another rank' if fail_at == 'create' else out[r][2]) and (fail_at == 'create' or 'timed out' in out[r][2]), out[r]
