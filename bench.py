@@ -69,13 +69,14 @@ def host_cpu_share():
     return n
 
 
-def cpu_baseline(size, max_steps, seconds=12.0):
+def cpu_baseline(size, max_steps, seconds=12.0, spare_cores=0):
     """Time the CPU oracle (port of the reference's step()/reset()) on this host's CPU share: n envs x T steps with
     auto-reset, sized to ~`seconds` of wall time.  Two rates: `value` with the reference's own observation strategy
     (render_edit: the persistent frame, <= 2 cells repainted per step) and `full_frame_value` with the whole frame
-    rendered after every step -- the work the GPU headline configuration does."""
+    rendered after every step -- the work the GPU headline configuration does.  spare_cores: threads left to the caller
+    (bench.py runs this beside a GPU soak leg whose launching thread needs one: `cores` reports what the oracle used)."""
     from oracle import OracleBatch
-    cores = host_cpu_share()
+    cores = max(1, host_cpu_share() - spare_cores)
     n = 64 * cores
     keys_pos = []
     for i in range(n):
@@ -117,7 +118,8 @@ def cpu_baseline(size, max_steps, seconds=12.0):
                               'other_obs_modes_1gpu.pixels_dirty)',
                 reference_note='the reference itself (pure Python) cannot travel to the GPU box; BASELINE.md §2 has it at '
                                '64-78 k env-steps/s on one 2.1 GHz Xeon core (measured in the build container)',
-                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset), %.1f s on %d OpenMP threads (= the cgroup CPU share) '
+                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset), %.1f s on %d OpenMP threads (the cgroup CPU share, minus one for the '
+                       'thread that keeps the GPU soak leg going beside it) '
                        'with a full render() per step -> value; x %d steps, %.1f s with the reference\'s dirty-cell repaint -> '
                        'dirty_cell_value' % (n, T0 * reps_full, size, size, max_steps, dt_full, cores, T0 * reps, dt))
 
@@ -167,7 +169,7 @@ def make_consumer(kind, n_envs, frame_shape, dev):
     """A stand-in POLICY for the policy-in-the-loop measurement (SURVEY 8b's callers: "torch policies consuming device tensors without
     host copies", docs/source/envs/gen_info.rst:62-82 with a network where the reference samples).  -> fn(obs uint8 [N, H, W, 3]) -> actions
     uint8 [N]; torch kernels on the current stream, every observation byte read, the next actions a function of it.
-      reduce: obs.view(N, -1).sum(1) % 6 -- one pass over the frames, nothing else.
+      reduce: obs.view(N, -1).sum(1) % 6 -- one pass over the frames, nothing else.  reduce32: the same pass over int32 words (15x faster).
       conv:   two strided convolutions (kernel = stride: 4x4 per cell -- or 3x3 for the AltObs tiles -- then 3x3 cells), bf16, as GEMMs over
               the patches, ReLU between, mean over positions, a 6-way head, an action sampled from its softmax (Gumbel-max).  Weights are fixed random numbers (seed 0)."""
     import torch
@@ -175,10 +177,21 @@ def make_consumer(kind, n_envs, frame_shape, dev):
     if kind == 'reduce':
         def policy(obs):
             return torch.remainder(obs.view(n_envs, -1).sum(1, dtype=torch.int32), 6).to(torch.uint8)
-        policy.describe = 'obs.view(N,-1).sum(1) % 6 (torch reduction over every observation byte)'
+        policy.describe = 'obs.view(N,-1).sum(1) % 6 (torch reduction over every observation byte; torch sums uint8 at ~0.4 TB/s)'
+        return policy
+    if kind == 'reduce32':
+        # the same bytes read as int32 words: torch's fastest reduction (6.2 TB/s, tools/microbench/consumer_speed.py) -- a READER at the
+        # memory's own pace, so that sweep and reader alternate at full rate (frames are multiples of 16 bytes for the Ray raster; AltObs
+        # frames are not multiples of 4: the byte-wise sum there)
+        if (H * Wd * 3) % 4:
+            return make_consumer('reduce', n_envs, frame_shape, dev)
+
+        def policy(obs):
+            return torch.remainder(obs.view(n_envs, -1).view(torch.int32).sum(1, dtype=torch.int32), 6).to(torch.uint8)
+        policy.describe = 'obs.view(N,-1).view(int32).sum(1) % 6 (every observation byte, as int32 words: torch\'s fastest reader)'
         return policy
     if kind != 'conv':
-        raise ValueError('consumer must be reduce or conv')
+        raise ValueError('consumer must be reduce, reduce32 or conv')
     p1 = 4 if H == Wd else 3                                   # one cell per patch (Ray 4x4 px, AltObs 3x3 px; its strip of 3 more rows is one more patch row)
     g1h, g1w = H // p1, Wd // p1
     p2 = 3
@@ -262,10 +275,11 @@ def main():
                          'slower; reported as prewarm_steps / warmup_total')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--no-single-env', action='store_true', help='skip the N=1 facade latency (BASELINE configs[0])')
-    ap.add_argument('--consumer', default='default', choices=['default', 'none', 'reduce', 'conv', 'both'],
+    ap.add_argument('--consumer', default='default', choices=['default', 'none', 'reduce', 'reduce32', 'conv', 'both', 'all'],
                     help='policy-in-the-loop measurement (pixel modes): between two steps a torch kernel that reads EVERY observation byte and '
-                         'produces the next actions from it, on the env\'s stream.  reduce: obs.view(N,-1).sum(1) %% 6; conv: two strided bf16 '
-                         'convolutions + a sampled action.  default: both, except with --quick (none); a named one also runs with --quick')
+                         'produces the next actions from it, on the env\'s stream.  reduce: obs.view(N,-1).sum(1) %% 6; reduce32: the same over int32 words '
+                         '(a reader at the memory\'s pace); conv: two strided bf16 convolutions + a sampled action.  default: all three, except with '
+                         '--quick (none); a named one also runs with --quick')
     ap.add_argument('--consumer-steps', type=int, default=0, help='steps per pass of the policy-in-the-loop measurement (0: 2*max_steps)')
     ap.add_argument('--shard-check', type=int, default=0, metavar='T',
                     help='no timing: reset, take T steps with actions that depend only on (step, GLOBAL env index), write per-env CRC32s of '
@@ -294,6 +308,11 @@ def main():
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
+
+    # one process per GPU: stay on the CPUs of the NUMA node that GPU hangs off (before anything touches the GPU; multi-rank runs only -- a single
+    # rank keeps the whole CPU share for the CPU baseline)
+    numa = launch.bind_to_gpu_numa(int(os.environ.get('LOCAL_RANK', '0'))) if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not args.rehearse_on_one_gpu \
+        else {'skipped': 'single rank' if int(os.environ.get('WORLD_SIZE', '1')) == 1 else 'rehearsal: every rank on GPU 0'}
 
     import torch
     import torch.distributed as dist
@@ -331,7 +350,7 @@ def main():
                 backend_used = 'gloo (RCCL group failed on at least one rank: %s)' % why
 
     from gym_craftingworld_amd import CraftingWorldVecEnv
-    from gym_craftingworld_amd.sharding import gather_over_ranks, max_over_ranks, shard_range
+    from gym_craftingworld_amd.sharding import gather_objects_over_ranks, gather_over_ranks, max_over_ranks, shard_range
 
     K, W = args.steps, args.warmup
     # weak scaling: the global batch is envs_per_gpu * world envs; rank g owns the contiguous range
@@ -466,6 +485,14 @@ def main():
     prof = env.profile_end()
     tuner = env.tuner_state()                        # (what pace the profiled launches ran at)
     t_next += K
+    # every rank's own clock, guard moves, sweep time and NUMA binding (control plane, after the timed regions): a straggler in a scaling run explains itself
+    S_r = args.size
+    own_bytes = float(N) * (S_r * S_r + (48 * S_r * S_r if args.raster == 'ray' else 27 * S_r * (S_r + 1)))
+    per_rank = gather_objects_over_ranks({
+        'rank': rank, 'device': local_rank, 'envs': [lo, hi], 'tuner': tuner, 'numa': numa,
+        'sweep_ms': prof['ms_render_kernel'] or None, 'sweep_ms_median': prof['ms_render_kernel_median'] or None,
+        'roofline_frac': (own_bytes / (prof['ms_render_kernel'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.obs_mode == 'pixels' and prof['ms_render_kernel'] > 0 else None,
+        'ms_per_step_with_events': elapsed_prof / K * 1e3})
     episodes = int(env.counters[1].item())
     resets_in_prof = episodes - episodes_before_prof      # envs reset (and repainted: 3 frames each) inside the profiled launches
 
@@ -537,7 +564,8 @@ def main():
     # sweep's clock, its head and the guard were tuned in.  Here a consumer that READS every byte of the 1.4 GB of frames runs between two steps
     # and its output is the next step's actions: step -> sweep -> consumer -> step ..., all on one stream.
     policy_blocks = None
-    kinds = {'default': () if args.quick else ('reduce', 'conv'), 'none': (), 'both': ('reduce', 'conv')}.get(args.consumer, (args.consumer,))
+    kinds = {'default': () if args.quick else ('reduce32', 'reduce', 'conv'), 'none': (), 'both': ('reduce', 'conv'),
+             'all': ('reduce32', 'reduce', 'conv')}.get(args.consumer, (args.consumer,))
     if kinds and args.obs_mode == 'pixels':
         S_ = args.size
         frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
@@ -609,6 +637,62 @@ def main():
                         'step\'s action tensor.  ms_per_step / value: %d steps without events (guard on); sweep / consumer_ms: the same again with the '
                         'library\'s events around the sweep and torch events around the consumer; episode phases as the regions above left '
                         'them (%s)' % (KC, 'spread out' if (window_desync or args.desync) else 'in step')}
+
+    # THE CPU BASELINE, and beside it a GPU SOAK.  The oracle's ~12 s of OpenMP work used to close the run with the card idle (round 4: the driver's
+    # gpu_busy sampler saw 0 of 3 samples busy in a 15-s run with ~2 s of GPU work).  Now it runs in a thread (ctypes drops the GIL; one core is left
+    # to this thread) while this thread keeps stepping the headline batch: a 10-s soak -- ~45 000 consecutive steps, episode phases as the regions above
+    # left them, the clock's guard on -- whose own rate, sweep time and guard moves are worth having (the tuned constants outside a 600-step window).
+    cpu_result, soak = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import threading
+        box = {}
+
+        def _cpu():
+            try:
+                box['r'] = cpu_baseline(args.size, args.max_steps, args.cpu_seconds, spare_cores=1)
+            except Exception as exc:  # noqa: BLE001
+                box['e'] = exc
+        th = threading.Thread(target=_cpu, daemon=True)
+        tuner0 = env.tuner_state()
+        ep0 = int(env.counters[1].item())
+        torch.cuda.synchronize(dev)
+        th.start()
+        t0 = time.perf_counter()
+        n_soak, marks = 0, []
+        while th.is_alive():
+            for _ in range(256):
+                env.step_async(actions[(t_next + n_soak) % rows])
+                n_soak += 1
+            if n_soak % 4096 == 0:                       # (keep the queue a few thousand steps deep at most; a mark every 4 096 steps)
+                torch.cuda.synchronize(dev)
+                marks.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(dev)
+        soak_s = time.perf_counter() - t0
+        th.join()
+        if 'e' in box:
+            raise box['e']
+        cpu_result = box['r']
+        t_next += n_soak
+        tuner1 = env.tuner_state()
+        if args.obs_mode == 'pixels':                    # the sweep's own time at the end of the soak (library events, 300 steps)
+            env.profile_begin(300)
+            run(300, t_next)
+            torch.cuda.synchronize(dev)
+            sp = env.profile_end()
+            t_next += 300
+        else:
+            sp = None
+        seg = [b - a for a, b in zip([0.0] + marks[:-1], marks)]
+        S_ = args.size
+        frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
+        soak = {'steps': n_soak, 'seconds': soak_s, 'value': float(N) * n_soak / soak_s, 'unit': 'env-steps/s', 'ms_per_step': soak_s / n_soak * 1e3,
+                'episodes_finished_per_step': (int(env.counters[1].item()) - ep0) / max(n_soak + (300 if sp else 0), 1),
+                'ms_per_step_by_4096_steps': {'min': min(seg) / 4096 * 1e3, 'max': max(seg) / 4096 * 1e3, 'last': seg[-1] / 4096 * 1e3} if seg else None,
+                'tuner_before': tuner0, 'tuner_after': tuner1, 'guard_moves': tuner1['guard_slowdowns'] - tuner0['guard_slowdowns'],
+                'sweep_after': ({'avg_launch_ms': sp['ms_render_kernel'], 'median_launch_ms': sp['ms_render_kernel_median'],
+                                 'frac': float(N) * (S_ * S_ + frame_) / (sp['ms_render_kernel'] * 1e-3) / 1e9 / HBM_PEAK_GBS} if sp and sp['ms_render_kernel'] > 0 else None),
+                'note': 'eager steps of the headline batch for as long as the CPU baseline ran beside it (one thread of the CPU share left to this loop); the '
+                        'host waits for the card every 4 096 steps; episode phases %s' % ('spread out' if (window_desync or args.desync) else 'in step')}
 
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
     # They are NOT the headline: pixels_dirty produces the identical frames by repainting <= 2 cells per
@@ -770,6 +854,9 @@ def main():
             'episodes_finished': episodes, 'prewarm_steps': prewarm_steps,
             'warmup_total': prewarm_steps + W,           # untimed steps before the timed region: `warmup` is the contract's W
             'per_rank_ms_per_step': [x / K * 1e3 for x in per_rank_s],
+            'per_rank_tuner': [r_['tuner'] for r_ in per_rank],
+            'per_rank_roofline_frac': [r_['roofline_frac'] for r_ in per_rank],
+            'per_rank': per_rank,
             'repeats': {'n': len(repeats_s), 'ms_per_step': [x / K * 1e3 for x in repeats_s],
                         'value': [total_steps / x for x in repeats_s], 'value_min': total_steps / max(repeats_s),
                         'value_median': total_steps / sorted(repeats_s)[len(repeats_s) // 2],
@@ -781,8 +868,9 @@ def main():
             'config1_state_4096': config1,
             'policy_in_loop': policy_blocks,
         }
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (task contract)
-            out['cpu_baseline'] = cpu_baseline(S, args.max_steps, args.cpu_seconds)
+        if cpu_result is not None:                       # rank 0 at N=1 only (task contract); measured above, beside the GPU soak
+            out['cpu_baseline'] = cpu_result
+            out['soak_beside_cpu_baseline'] = soak
         if not args.no_single_env and world == 1:
             env.close()                                  # (idempotent)
             out['single_env'] = single_env_latency(dev)

@@ -23,6 +23,9 @@
 #include "cw_mt.h"
 
 #define CW_WAVE 64
+#ifndef CW_EXP_DIRTY
+#define CW_EXP_DIRTY 0             // (throw-away A/B builds of the dirty-cell step: make exp EXP=-DCW_EXP_DIRTY=n NAME=...; profiles/r05_dirty.txt)
+#endif
 #define CW_BALLOT(p) __builtin_amdgcn_ballot_w64(p)   // the compare's own SGPR pair (__ballot goes through a select + compare)
 #define CW_ALT_FRAME_PACE 2    // render_frame_alt: s_sleep(1) after each 1-KiB store of a single frame's zero fill (back to back 3.0 TB/s, with 64-192 idle clocks 5.2-5.4)
 
@@ -118,7 +121,20 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
             uint32_t o = (dy == 2 && hold != 0) ? rgb_of_code(hold) : 0x00FFFFFFu;
             d = overlay_dwords(d, o);
         }
+#if CW_EXP_DIRTY == 4
+        if (dy == 1 || dy == 2 || !mark_rows_only) {          // A/B: the whole aligned 64-byte line the row lies in (junk: timing only)
+            uint4 *q = (uint4 *)((uintptr_t)(p + dy * row_bytes) & ~(uintptr_t)63);
+            const uint4 z = make_uint4(d.x, d.y, d.z, 0);
+            q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        }
+#elif CW_EXP_DIRTY == 5
+        if (dy == 1 || dy == 2 || !mark_rows_only) {          // A/B: the same stores, nontemporal
+            uint32_t *q = (uint32_t *)(p + dy * row_bytes);
+            __builtin_nontemporal_store(d.x, q); __builtin_nontemporal_store(d.y, q + 1); __builtin_nontemporal_store(d.z, q + 2);
+        }
+#else
         if (dy == 1 || dy == 2 || !mark_rows_only) *(u32x3_a4 *)(p + dy * row_bytes) = d;      // (rows 0, 3 never carry the mark)
+#endif
     }
 }
 
@@ -269,15 +285,15 @@ __device__ __forceinline__ void render_frame(uint8_t *__restrict__ dst0, uint8_t
 }
 // one frame of either raster from wave-uniform values: slot positions / codes, agent cell, hold
 __device__ __forceinline__ void paint_state_frame(const CwParams &P, uint8_t *dst, const uint32_t sp[8], uint32_t codes, uint32_t agent_cell,
-                                                  uint32_t hold, int lane)
+                                                  uint32_t hold, int lane, uint8_t *dst1 = nullptr)
 {
     if (P.raster == 1) {
-        render_frame_alt(dst, nullptr, P.size, P.ncell, P.div_magic, sp, codes, agent_cell, hold, lane, CW_ALT_FRAME_PACE);
+        render_frame_alt(dst, dst1, P.size, P.ncell, P.div_magic, sp, codes, agent_cell, hold, lane, CW_ALT_FRAME_PACE);
     } else {
         uint32_t rgb[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) rgb[k] = rgb_of_code((codes >> (4 * k)) & 15u);
-        render_frame(dst, nullptr, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
+        render_frame(dst, dst1, P.size, P.ncell, P.div_magic, sp, rgb, agent_cell, hold ? rgb_of_code(hold) : 0x00FFFFFFu, lane);
     }
 }
 // which of an env's three states a frame shows: its current one (observation), the one at reset (INIT_OBS), imagine_obs' final one (desired_goal)
@@ -474,13 +490,16 @@ __device__ __forceinline__ void paint_changed_cells(const CwParams &P, int env, 
 // of reset() (ray.py:156-218) as three 16-byte loads and the stores of the episode records, by the lane that stepped the env.  h / sp become
 // the new episode's header and slots (reset_header's values).  -> false: no record (the env finished twice between two refills, or the
 // engine keeps none); the caller hands the env to the slow path, which resets it from the same position of its stream.
-__device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint4 &h, uint32_t sp[8], bool count_episode)
+struct CwGoalState { uint4 pos; uint32_t codes, agent; };      // imagine_obs' final state of the episode just taken over (the painters of its desired_goal frame)
+__device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint4 &h, uint32_t sp[8], bool count_episode, CwGoalState *goal = nullptr)
 {
     const uint4 m = P.nx_misc[env];
     if (!(m.z >> 31)) return false;
     const uint4 ipos = P.nx_init_pos[env];
     P.init_pos[env] = ipos;
-    P.goal_pos[env] = P.nx_goal_pos[env];
+    const uint4 gpos = P.nx_goal_pos[env];
+    P.goal_pos[env] = gpos;
+    if (goal) { goal->pos = gpos; goal->codes = m.y; goal->agent = m.x >> 16; }
     P.goal_codes[env] = m.y;
     P.init_agent[env] = (uint16_t)(m.x & 0xFFFFu);
     P.goal_agent[env] = (uint16_t)(m.x >> 16);
@@ -1129,18 +1148,34 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
 // after this kernel (cw_render_pieces_kernel), every env's frame alike, and nothing runs beside that sweep: rounds 1-3 reset and painted
 // beside it, which cost the launch 26 us for ~220 finished envs per step (profiles/r04_lookahead.txt).  keep_terminal_obs: the finished
 // episode's last frame, from the lane's registers.  No done list, no second launch waiting on the first.
+// the frames a finished env leaves to paint, as jobs in LDS that ALL FOUR waves of the workgroup take in turn (CW_COOP_PAINT): with the episode
+// phases spread out ~220 envs finish on every step of 65 536, two frames each, and the kernel ends with its slowest wave -- one that finds three
+// finished envs among its 64 paints six frames while its three neighbours wait for nothing (15.8 us against 13 with phases in step, round 4)
+struct CwPaintJob { uint4 pos; uint32_t codes, agent_hold_kind, env, pad; };      // agent_hold_kind: agent cell | hold << 16 | kind << 24
+enum { CW_JOB_INIT = 0, CW_JOB_GOAL = 1, CW_JOB_TERMINAL = 2 };
+#ifndef CW_COOP_PAINT
+#define CW_COOP_PAINT 1
+#endif
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
                                                                                 int paint, int epw)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+#if CW_COOP_PAINT
+    __shared__ CwPaintJob s_jobs[CW_RESET_WAVES * CW_WAVE * 3];
+    __shared__ int s_njobs;
+    if (paint && threadIdx.x == 0) s_njobs = 0;
+#endif
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int env0 = wave * epw;
-    if (env0 >= P.n_envs) return;
+    const bool wave_live = env0 < P.n_envs;          // (a wave past the batch takes part in the workgroup's barriers and paints its share)
+#if !CW_COOP_PAINT
+    if (!wave_live) return;
+#endif
     const int env = env0 + lane;
-    const bool live = lane < epw && env < P.n_envs;
-    const int e = live ? env : env0;                 // idle lanes shadow a valid env (their results are dropped)
+    const bool live = wave_live && lane < epw && env < P.n_envs;
+    const int e = live ? env : (wave_live ? env0 : 0);      // idle lanes shadow a valid env (their results are dropped)
     int a;
     if (act_dtype == 0) a = ((const int32_t *)actions)[e];
     else if (act_dtype == 1) a = (int)((const long long *)actions)[e];
@@ -1149,6 +1184,9 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
     const uint4 ip = P.init_pos[e];                  // (asked for with the rest: a second memory round trip only for lanes that hold something costs the wave the same)
+#if CW_COOP_PAINT
+    if (paint) __syncthreads();                      // (s_njobs; behind the loads' issue)
+#endif
     const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
     const bool done = live && o.done;
     if (live) {
@@ -1157,7 +1195,19 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         P.achieved_out[env] = (uint16_t)o.achieved;
         P.desired_out[env] = (uint16_t)o.desired;
         if (o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
+#if CW_EXP_DIRTY == 1
+        (void)0;                                                                              // A/B: the dirty-cell step without its stores
+#elif CW_EXP_DIRTY == 2
+        if (paint == 1 && o.changed && !o.done) *(uint32_t *)(P.obs + (size_t)env * P.frame_bytes) = o.dirty0;      // A/B: ONE dword per changed env
+#elif CW_EXP_DIRTY == 3
+        if (paint == 1 && o.changed && !o.done) {                                             // A/B: the same number of 12-byte stores, all into the frame's first two lines
+            u32x3 d; d.x = o.dirty0; d.y = o.dirty1; d.z = 7;
+            const int n_st = (o.dirty1 == 0xFFFFFFFFu ? 1 : 2) * 2 + (o.mark0 ? 0 : 2) + ((o.dirty1 != 0xFFFFFFFFu && !o.mark1) ? 2 : 0);
+            for (int q = 0; q < n_st; q++) *(u32x3_a4 *)(P.obs + (size_t)env * P.frame_bytes + 12 * q) = d;
+        }
+#else
         if (paint == 1 && o.changed && !o.done) paint_changed_cells(P, env, h, sp, o);      // render_edit, :358 (a finished env is repainted whole below)
+#endif
     }
     // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
     const uint4 h_last = h;                          // (the finished episode's last state: keep_terminal_obs paints it below)
@@ -1165,12 +1215,14 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
 #pragma unroll
     for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
     bool popped = false;
-    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true);
+    CwGoalState goal;
+    goal.pos = make_uint4(0, 0, 0, 0); goal.codes = 0; goal.agent = 0;
+    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true, &goal);
     const unsigned long long m_all = CW_BALLOT(done), m_pop = CW_BALLOT(popped);
     const unsigned long long m_succ = CW_BALLOT(live && o.success);
     const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
     int rbase = 0;
-    if (lane == 0) {                                 // (one same-address atomic per wave would serialise the grid in L2)
+    if (lane == 0 && wave_live) {                    // (one same-address atomic per wave would serialise the grid in L2)
         if (wave == 0) atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
         if (m_all) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_all));
         if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
@@ -1181,6 +1233,77 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         rbase = __shfl(rbase, 0);
         if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
     }
+#if CW_COOP_PAINT
+    if (paint) {
+        // ---- the jobs of this wave's finished envs: INIT_OBS (with the observation itself in the dirty-cell mode), desired_goal, and with
+        //      keep_terminal_obs the finished episode's last frame.  Envs that took a record: by their own lanes.
+        const int jpe = P.terminal_img ? 3 : 2;
+        int jbase = 0;
+        if (m_all) {
+            if (lane == 0) jbase = atomicAdd(&s_njobs, jpe * __popcll(m_all));
+            jbase = __shfl(jbase, 0);
+        }
+        const int jmine = jbase + jpe * __popcll(m_all & ((1ull << lane) - 1ull));
+        if (done && P.terminal_img) {
+            CwPaintJob &j = s_jobs[jmine + 2];
+            j.pos = pack_pos(sp_last);
+            j.codes = h_last.w;
+            j.agent_hold_kind = ((h_last.x & 0xFFu) * P.size + ((h_last.x >> 8) & 0xFFu)) | (((h_last.x >> 16) & 0xFFu) << 16) | (CW_JOB_TERMINAL << 24);
+            j.env = (uint32_t)env;
+        }
+        if (popped) {
+            CwPaintJob &j0 = s_jobs[jmine], &j1 = s_jobs[jmine + 1];
+            j0.pos = pack_pos(sp);                    // (the new episode's slots are its reset-time placement)
+            j0.codes = CW_CODES_INITIAL;
+            j0.agent_hold_kind = ((h.x & 0xFFu) * P.size + ((h.x >> 8) & 0xFFu)) | (CW_JOB_INIT << 24);
+            j0.env = (uint32_t)env;
+            j1.pos = goal.pos;
+            j1.codes = goal.codes;
+            j1.agent_hold_kind = goal.agent | (CW_JOB_GOAL << 24);
+            j1.env = (uint32_t)env;
+        }
+        unsigned long long m = m_all & ~m_pop;       // envs that found no record: reset here, one at a time, by the whole wave (rare)
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int env_l = env0 + l;
+            const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
+            const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
+            if (lane == 0) {
+                store_episode_records(P, env_l, r, true);                   // step_num >= 1 here
+                if (P.lookahead) queue_for_refill(P, env_l);
+            }
+            if (lane == l) {
+                h = reset_header(P, r, menu_id);
+                unpack_pos(r.init_pos, sp);
+                CwPaintJob &j0 = s_jobs[jmine], &j1 = s_jobs[jmine + 1];
+                j0.pos = r.init_pos; j0.codes = CW_CODES_INITIAL; j0.agent_hold_kind = r.init_agent | (CW_JOB_INIT << 24); j0.env = (uint32_t)env_l;
+                j1.pos = r.goal_pos; j1.codes = r.goal_codes; j1.agent_hold_kind = r.goal_agent | (CW_JOB_GOAL << 24); j1.env = (uint32_t)env_l;
+            }
+        }
+        if (live) {
+            P.hdr[env] = h;
+            P.pos[env] = pack_pos(sp);
+        }
+        __syncthreads();
+        const int n_jobs = s_njobs;
+        for (int jq = wave_in_block; jq < n_jobs; jq += CW_RESET_WAVES) {
+            const CwPaintJob &j = s_jobs[jq];
+            uint32_t jp[8];
+            unpack_pos(make_uint4(__builtin_amdgcn_readfirstlane(j.pos.x), __builtin_amdgcn_readfirstlane(j.pos.y), __builtin_amdgcn_readfirstlane(j.pos.z),
+                                  __builtin_amdgcn_readfirstlane(j.pos.w)), jp);
+            const uint32_t codes = __builtin_amdgcn_readfirstlane(j.codes), ahk = __builtin_amdgcn_readfirstlane(j.agent_hold_kind);
+            const size_t off = (size_t)__builtin_amdgcn_readfirstlane(j.env) * P.frame_bytes;
+            const uint32_t kind = ahk >> 24;
+            uint8_t *d0, *d1 = nullptr;
+            if (kind == CW_JOB_INIT) { d0 = P.init_img + off; if (paint == 1) d1 = P.obs + off; }      // (dirty-cell engines: the frame is persistent, the new episode's first frame is painted here too)
+            else if (kind == CW_JOB_GOAL) d0 = P.desired_img + off;
+            else d0 = P.terminal_img + off;
+            paint_state_frame(P, d0, jp, codes, ahk & 0xFFFFu, (ahk >> 16) & 0xFFu, lane, d1);
+        }
+        return;
+    }
+#endif
     unsigned long long m = paint ? m_all : (m_all & ~m_pop);     // what is left for the whole wave: the slow resets, and in the pixel mode every finished env's frames
     while (m) {
         const int l = __builtin_ctzll(m);
@@ -1282,8 +1405,11 @@ __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, 
         else for (uint32_t b = c; b < a1; b++) dst_base[b] = 0;
     }
 }
+#ifndef CW_TOUCH
+#define CW_TOUCH 0                 // A/B (profiles/r05_step.txt): the sweep's last batch READS the state records the next step kernel starts with
+#endif
 template <int RASTER, int FPJ>
-__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int period16, int head_extra16, int env_lo, int env_n)
+__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int period16, int head_extra16, int env_lo, int env_n, bool touch = false)
 {
     constexpr int JPB = CW_WAVE / FPJ;                                      // jobs per batch of records
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -1347,6 +1473,13 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
         return r;
     };
     Rec nxt = fetch(0);
+#if CW_TOUCH
+    // The step kernel that follows this sweep starts with three 16-byte loads per env (hdr, pos, init_pos: 3 MB at 65 536 envs), and after 1.4 GB of
+    // frame writes none of it is in any cache: its loads queue in HBM behind the write-back of the sweep's tail.  So the sweep's waves read those
+    // records once more as their last batch of jobs begins (one 1-KiB load per array and wave): they are in the memory-side cache when the step kernel
+    // asks.  The values are folded into a word nobody reads, after the last job: no wait inside the job loop.
+    uint4 t_a = make_uint4(0, 0, 0, 0), t_b = t_a, t_c = t_a;
+#endif
     // THE CLOCK.  period16 != 0: job k of a wave starts no earlier than t0 + k x period (period16 = the period in 1/16 of a 10-ns tick of the
     // constant 100-MHz clock, s_memrealtime), the waves' t0 spread evenly over one period: the launch's stores leave as ONE smooth stream at a
     // set rate -- bytes per second = waves x 4 KiB / period -- instead of at whatever rate the waves' instruction streams happen to produce.
@@ -1354,6 +1487,13 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     for (int base = 0; base < q_mine; base += JPB) {
         const Rec cur = nxt;
         if (base + JPB < q_mine) nxt = fetch(base + JPB);
+#if CW_TOUCH
+        else if (touch) {
+            const int e = wave * CW_WAVE + lane;
+            if (e < P.n_envs) { t_a = P.hdr[e]; t_b = P.pos[e]; t_c = P.init_pos[e]; }
+            for (int e2 = e + n_waves * CW_WAVE; e2 < P.n_envs; e2 += n_waves * CW_WAVE) { t_a.y ^= P.hdr[e2].x; t_b.y ^= P.pos[e2].x; t_c.y ^= P.init_pos[e2].x; }
+        }
+#endif
         const int in_batch = min(q_mine - base, JPB);
         for (int k = 0; k < in_batch; k++) {
             const int f0 = __builtin_amdgcn_readlane(cur.f, FPJ * k);         // the piece's first frame
@@ -1453,6 +1593,9 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
             }
         }
     }
+#if CW_TOUCH
+    { const uint32_t t = t_a.x ^ t_a.y ^ t_b.x ^ t_b.y ^ t_c.x ^ t_c.y ^ t_a.w ^ t_b.w ^ t_c.w; asm volatile("" ::"v"(t)); }
+#endif
 }
 template <int RASTER, int FPJ>
 __global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int period16, int period16_head, int period16_busy,
@@ -1470,7 +1613,8 @@ __global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8
     // (after a step on which an eighth of the batch or more finished -- the all-env time-out step wrote two frames per env, 2.8 GB -- and for the
     //  INIT_OBS / desired_goal arrays of a reset the whole launch runs at the busy head's rate: 7.7 TB/s right after that reads 0.34 ms, this 0.22)
     render_pieces<RASTER, FPJ>(P, frames, src, __builtin_amdgcn_readfirstlane(storm ? period16_busy : period16),
-                               __builtin_amdgcn_readfirstlane(!storm && (chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n);
+                               __builtin_amdgcn_readfirstlane(!storm && (chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n,
+                               src == CW_SRC_CURRENT && (chunk & 2) && frames == P.obs);
     if (src == CW_SRC_CURRENT && (chunk & 2) && blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = done_now;      // (every wave has read it long ago)
 }
 // ------------------------------------------------------------------------------------ exports

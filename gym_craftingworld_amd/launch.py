@@ -36,6 +36,71 @@ def rank_environments(n_ranks, base_env=None, port=None, addr='127.0.0.1'):
     return envs
 
 
+def gpu_numa_nodes(sys_root='/sys'):
+    """NUMA node of every AMD GPU of this host in PCI-address order -- the order HIP enumerates them in unless *_VISIBLE_DEVICES says otherwise --
+    read from /sys/class/drm/card*/device/{vendor,numa_node}; [] when sysfs does not tell (a container without it).  Touches no GPU API."""
+    import glob
+    found = {}
+    for dev in glob.glob(os.path.join(sys_root, 'class', 'drm', 'card[0-9]*', 'device')):
+        try:
+            with open(os.path.join(dev, 'vendor')) as f:
+                if f.read().strip().lower() != '0x1002':
+                    continue
+            with open(os.path.join(dev, 'numa_node')) as f:
+                node = int(f.read().strip())
+            found[os.path.basename(os.path.realpath(dev))] = node       # key: the PCI address (0000:05:00.0)
+        except (OSError, ValueError):
+            continue
+    return [found[k] for k in sorted(found)]
+
+
+def node_cpus(node, sys_root='/sys'):
+    """The CPUs of NUMA node `node` (/sys/devices/system/node/node<N>/cpulist, e.g. "0-47,96-143") as a set; empty when unreadable."""
+    cpus = set()
+    try:
+        with open(os.path.join(sys_root, 'devices', 'system', 'node', 'node%d' % node, 'cpulist')) as f:
+            for part in f.read().strip().split(','):
+                if not part:
+                    continue
+                a, _, b = part.partition('-')
+                cpus.update(range(int(a), int(b or a) + 1))
+    except (OSError, ValueError):
+        return set()
+    return cpus
+
+
+def bind_to_gpu_numa(local_rank, environ=None, sys_root='/sys', setaffinity=None, getaffinity=None):
+    """Keep this process on the CPUs of the NUMA node its GPU hangs off (rank r drives GPU r: one process per GPU) -- its launches,
+    event records and pinned buffers then stay off the inter-socket link.  Call BEFORE anything touches the GPU (bench.py does, before it imports
+    torch).  Does nothing -- and says why -- when CW_NUMA_BIND=0, when a *_VISIBLE_DEVICES variable re-maps the devices (the PCI order no longer
+    tells which GPU the rank gets), when sysfs does not name the node, or when the node's CPUs and the process's current affinity (a cgroup's cpuset)
+    do not meet.  -> dict(node=..., cpus=n) or dict(skipped=reason)."""
+    environ = os.environ if environ is None else environ
+    setaffinity = setaffinity or getattr(os, 'sched_setaffinity', None)
+    getaffinity = getaffinity or getattr(os, 'sched_getaffinity', None)
+    if environ.get('CW_NUMA_BIND', '1') == '0':
+        return {'skipped': 'CW_NUMA_BIND=0'}
+    if setaffinity is None or getaffinity is None:
+        return {'skipped': 'no sched_setaffinity on this platform'}
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL'):
+        if environ.get(var):
+            return {'skipped': '%s is set: device order is not the PCI order' % var}
+    nodes = gpu_numa_nodes(sys_root)
+    if local_rank >= len(nodes):
+        return {'skipped': 'sysfs lists %d AMD GPUs, this is local rank %d' % (len(nodes), local_rank)}
+    node = nodes[local_rank]
+    if node < 0:
+        return {'skipped': 'numa_node of GPU %d is %d (single-node host or not reported)' % (local_rank, node)}
+    want = node_cpus(node, sys_root) & set(getaffinity(0))
+    if not want:
+        return {'skipped': 'node %d has no CPU inside this process\'s affinity mask' % node}
+    try:
+        setaffinity(0, want)
+    except OSError as exc:
+        return {'skipped': 'sched_setaffinity failed: %s' % exc}
+    return {'node': node, 'cpus': len(want)}
+
+
 def needs_self_launch(n_gpus, environ=None):
     """True when `--gpus n_gpus` was asked for but no launcher set up the ranks (WORLD_SIZE absent)."""
     environ = os.environ if environ is None else environ

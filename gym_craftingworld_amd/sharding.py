@@ -38,6 +38,16 @@ def gather_over_ranks(value, device='cpu', group=None):
     return [float(o.item()) for o in out]
 
 
+def gather_objects_over_ranks(obj):
+    """Every rank's picklable `obj`, in rank order, on every rank -- over the DEFAULT (gloo, CPU) group: the control plane, off the timed regions
+    ([obj] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def sum_over_ranks(values, device='cpu'):
     """SUM-reduce a list of ints (e.g. the engine counters) over the default process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -1618,9 +1618,11 @@ def test_checkpoint_resume_is_bit_identical(obs_mode, raster, pool, tmp_path):
     assert torch.equal(a.hdr, b.hdr) and torch.equal(a.slot_pos, b.slot_pos) and torch.equal(a.counters, b.counters)
     # the engine's private word -- the finished count the last sweep of the observation array saw -- travels too: the resumed engine's first sweep
     # sees the step it follows as the uninterrupted run's would (round 4 restored 4 of the 5 words: `finished` = counters[1] - 0, a storm launch)
-    assert int(b._counters_raw[4]) == int(a._counters_raw[4]) and int(b._counters_raw[4]) <= int(b.counters[1])
-    if obs_mode == 'pixels':
+    assert int(b._counters_raw[4]) <= int(b.counters[1])
+    if obs_mode != 'state':                           # (the load's own repaint of the observation array has brought it up to date)
         assert int(b._counters_raw[4]) == int(b.counters[1])
+    else:
+        assert int(b._counters_raw[4]) == int(a._counters_raw[4])
     assert torch.equal(a.episode_return, b.episode_return) and torch.equal(a.episode_length, b.episode_length)
     if obs_mode != 'state':
         oa, ob = a._observation(), b._observation()
@@ -2017,13 +2019,13 @@ def test_render_of_arbitrary_one_hot_states():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('obs_mode,consumer', [('pixels', 'reduce'), ('pixels_dirty', 'reduce'), ('pixels', 'conv')])
+@pytest.mark.parametrize('obs_mode,consumer', [('pixels', 'reduce'), ('pixels_dirty', 'reduce'), ('pixels', 'reduce32'), ('pixels', 'conv')])
 def test_policy_in_the_loop_actions_replay_through_the_oracle(obs_mode, consumer):
     """SURVEY 8b's callers: a torch policy consuming the device tensors without host copies (docs/source/envs/gen_info.rst:62-82 with a network where
     the reference samples; ray.py:376-378 hands the observation back).  Between two steps a consumer reads EVERY observation byte and produces the
     next actions from it (bench.py's --consumer), all on the env's stream, no host synchronisation inside the loop: 200 steps of 4 096 envs.  Then
-    the RECORDED actions go through the oracle: rewards, dones and frames must be the oracle's, and -- `reduce`, whose policy a host can restate
-    exactly -- every recorded action must be what the policy computes from the ORACLE's frame of that step: a consumer that read a frame before the
+    the RECORDED actions go through the oracle: rewards, dones and frames must be the oracle's, and -- `reduce` / `reduce32`, whose policy a host can
+    restate exactly -- every recorded action must be what the policy computes from the ORACLE's frame of that step: a consumer that read a frame before the
     sweep (or the step kernel's repaint) had written it would have taken another action."""
     import bench
     from gym_craftingworld_amd import CraftingWorldVecEnv
@@ -2059,8 +2061,12 @@ def test_policy_in_the_loop_actions_replay_through_the_oracle(obs_mode, consumer
     ish = ora.envs[0].img_shape
     n_done = 0
     for t in range(T):
-        if consumer == 'reduce':
-            want = np.array([int(np.ctypeslib.as_array(e.view().obs, shape=ish).sum(dtype=np.int64)) % 6 for e in ora.envs], dtype=np.uint8)
+        if consumer in ('reduce', 'reduce32'):
+            if consumer == 'reduce':
+                want = np.array([int(np.ctypeslib.as_array(e.view().obs, shape=ish).sum(dtype=np.int64)) % 6 for e in ora.envs], dtype=np.uint8)
+            else:                                          # the frame's bytes as little-endian int32 words, summed with int32 wrap-around, Python's modulo
+                want = np.array([int(np.ctypeslib.as_array(e.view().obs, shape=ish).reshape(-1).view(np.int32).sum(dtype=np.int64)
+                                     .astype(np.int32)) % 6 for e in ora.envs], dtype=np.uint8)
             bad = np.nonzero(want != acts[t])[0]
             assert bad.size == 0, ('step', t, 'envs whose action was not computed from the finished frame', bad[:8], acts[t][bad[:8]], want[bad[:8]])
         o_rew, o_done = ora.step(acts[t])
@@ -2198,8 +2204,9 @@ def test_replayed_graph_gets_its_records_back_after_a_reseed(obs_mode):
         e_env.step_many(ring)
         torch.cuda.synchronize()
         slow.append(int(g_env._counters_raw[5]))
-    assert slow[1] > 0                                   # the first episodes after the re-seed ended without a record ...
-    assert slow[-1] == slow[5], slow                     # ... and from then on every finished env finds one again
+    assert slow[1] >= N                                  # the first episodes after the re-seed ended without a record (every env once) ...
+    assert slow[-1] - slow[2] < N // 50, slow            # ... and from then on finished envs find one again: 12 replays = 6 more episodes of every env (round 4:
+    #                                                      6 x N more slow resets), but for the few that finish twice between two refills
     assert torch.equal(g_env.hdr, e_env.hdr) and torch.equal(g_env.slot_pos, e_env.slot_pos) and torch.equal(g_env.counters, e_env.counters)
     ka, pa = g_env.get_rng_states(); kb, pb = e_env.get_rng_states()
     assert np.array_equal(pa, pb) and np.array_equal(ka[:, 1:], kb[:, 1:])

@@ -139,3 +139,52 @@ def test_bench_places_a_short_timed_region_between_all_env_time_outs():
         assert p >= prewarm and not any(first <= m <= last for m in range(300, last + 1, 300)), (prewarm, W, K, p)
     assert bench.place_short_region(320, 5, 20, 300) == 320 and bench.place_short_region(288, 5, 20, 300) > 288
     assert bench.place_short_region(320, 20, 600, 300) == 320 and bench.place_short_region(320, 20, 300, 300) == 320
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """gpus: [(card name, pci address, vendor, numa_node)], nodes: {node: cpulist text}"""
+    for card, pci, vendor, numa in gpus:
+        real = root / 'devices' / 'pci0000:00' / pci
+        real.mkdir(parents=True)
+        (real / 'vendor').write_text(vendor + '\n')
+        (real / 'numa_node').write_text('%d\n' % numa)
+        d = root / 'class' / 'drm' / card
+        d.mkdir(parents=True)
+        os.symlink(str(real), str(d / 'device'))
+    for n, cpus in nodes.items():
+        nd = root / 'devices' / 'system' / 'node' / ('node%d' % n)
+        nd.mkdir(parents=True)
+        (nd / 'cpulist').write_text(cpus + '\n')
+
+
+def test_ranks_bind_to_the_numa_node_of_their_gpu(tmp_path):
+    """bench.py --gpus N: rank r, before it touches the GPU, keeps itself on the CPUs of the NUMA node GPU r hangs off (launch.bind_to_gpu_numa), read
+    from /sys/class/drm/card*/device/numa_node in PCI order -- and leaves its affinity alone whenever that cannot be known."""
+    # eight GPUs on two sockets, card numbers NOT in PCI order, one non-AMD device in between
+    gpus = [('card%d' % (7 - i), '0000:%02x:00.0' % (0x05 + 0x10 * i), '0x1002', 0 if i < 4 else 1) for i in range(8)]
+    gpus.append(('card8', '0000:03:00.0', '0x1a03', 0))                     # (the BMC's VGA device)
+    _fake_sysfs(tmp_path, gpus, {0: '0-3,8-11', 1: '4-7,12-15'})
+    assert launch.gpu_numa_nodes(str(tmp_path)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert launch.node_cpus(1, str(tmp_path)) == {4, 5, 6, 7, 12, 13, 14, 15}
+    seen = {}
+    kw = dict(sys_root=str(tmp_path), setaffinity=lambda pid, cpus: seen.update(pid=pid, cpus=set(cpus)), getaffinity=lambda pid: set(range(16)))
+    assert launch.bind_to_gpu_numa(5, environ={}, **kw) == {'node': 1, 'cpus': 8} and seen == {'pid': 0, 'cpus': {4, 5, 6, 7, 12, 13, 14, 15}}
+    # a cgroup cpuset that covers half of the node: the intersection
+    kw['getaffinity'] = lambda pid: {0, 1, 2, 3, 4, 5}
+    assert launch.bind_to_gpu_numa(2, environ={}, **kw) == {'node': 0, 'cpus': 4} and seen['cpus'] == {0, 1, 2, 3}
+    # ... and everything that must leave the affinity alone
+    seen.clear()
+    assert 'CW_NUMA_BIND' in launch.bind_to_gpu_numa(0, environ={'CW_NUMA_BIND': '0'}, **kw)['skipped']
+    assert 'HIP_VISIBLE_DEVICES' in launch.bind_to_gpu_numa(0, environ={'HIP_VISIBLE_DEVICES': '3,2'}, **kw)['skipped']
+    assert 'local rank 9' in launch.bind_to_gpu_numa(9, environ={}, **kw)['skipped']
+    kw['getaffinity'] = lambda pid: {4, 5}
+    assert 'affinity' in launch.bind_to_gpu_numa(0, environ={}, **kw)['skipped']
+    one = tmp_path / 'single'
+    _fake_sysfs(one, [('card0', '0000:05:00.0', '0x1002', -1)], {})
+    assert 'numa_node' in launch.bind_to_gpu_numa(0, environ={}, sys_root=str(one), setaffinity=kw['setaffinity'], getaffinity=kw['getaffinity'])['skipped']
+    assert launch.bind_to_gpu_numa(0, environ={}, sys_root=str(tmp_path / 'nothing'), setaffinity=kw['setaffinity'],
+                                   getaffinity=kw['getaffinity'])['skipped'].startswith('sysfs lists 0')
+    assert seen == {}
+    # the real host, whatever it is: never raises, never binds to an empty set
+    r = launch.bind_to_gpu_numa(0, environ={'CW_NUMA_BIND': '0'})
+    assert 'skipped' in r
