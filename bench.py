@@ -828,7 +828,8 @@ def main():
             'quote': {'metric_window': window['value'] if window else None, 'metric_window_desync': window_desync['value'] if window_desync else None},
             'roofline': {'bound': 'hbm', 'kernel': dominant,
                          # (a rocprofv3 trace lists the sweep by raster and frames per job: cw_render_pieces_kernel<raster, 2> for frames of 4 KiB and more)
-                         'kernel_in_trace': (('%s<%d, %d>' % (dominant, 1 if args.raster == 'alt' else 0, frames_per_job(frame))) if dominant.startswith('cw_render_pieces') else dominant),
+                         'kernel_in_trace': (('%s<%d, %d>' % (dominant, 1 if args.raster == 'alt' else 0, frames_per_job(frame))) if dominant.startswith('cw_render_pieces') else
+                                             ('%s<%d>' % (dominant, 4 if frames_per_job(frame) <= 4 else 8)) if dominant.startswith('cw_render_gather') else dominant),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          # the WHOLE step against the same roof: A x N / ms_per_step (A = SURVEY 8d's bytes per env-step: 48 + S*S + frame in the

@@ -532,6 +532,12 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
+        tn.gather = geti("CW_TUNE_GATHER", tn.gather);
+        tn.gather_max_size = geti("CW_TUNE_GATHER_MAX_SIZE", tn.gather_max_size);
+        if (tn.gather_max_size > 9) tn.gather_max_size = 9;                       // (cw_render_gather_kernel's tables: frames under 4 KiB)
+        tn.small_frame_bytes = geti("CW_TUNE_SMALL_FRAME_BYTES", tn.small_frame_bytes);
+        tn.small_blocks_per_cu = geti("CW_TUNE_SMALL_BLOCKS", tn.small_blocks_per_cu);
+        if (tn.small_blocks_per_cu < 1 || tn.small_blocks_per_cu > 8) tn.small_blocks_per_cu = 1;
     }
 
     int rc = CW_OK;
@@ -1001,6 +1007,7 @@ const char *cw_render_kernel_name(const cw_engine *e)
 {
     if (!e || e->obs_mode == CW_OBS_STATE) return "";
     if (e->obs_mode == CW_OBS_PIXELS_DIRTY) return e->auto_reset ? "cw_step_fused_kernel" : "cw_step_kernel";
+    if (e->tune.gather && e->P.raster == CW_RASTER_RAY && e->S <= e->tune.gather_max_size) return "cw_render_gather_kernel";
     return "cw_render_pieces_kernel";
 }
 

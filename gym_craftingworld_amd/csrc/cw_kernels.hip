@@ -1394,7 +1394,9 @@ __global__ __launch_bounds__(256) void cw_render_frames_kernel(CwParams P, uint8
 // The sweep covers envs [env_lo, env_lo + env_n) (a chunk of the batch, cw_piece_chunks): offsets inside a chunk are 32-bit.
 #define CW_PIECE 4096u             // (a sharp optimum: 2 / 8 / 16 KiB pieces are 79 / 18-24 / 20-27 % slower, profiles/history/r03_pieces.txt G)
 #define CW_PIECE_STORES 4          // 1-KiB stores per piece
+#ifndef CW_HEAD_JOBS
 #define CW_HEAD_JOBS 64            // the jobs of every wave at a launch's start that run a notch slower (~40 us) ...
+#endif
 #define CW_BUSY_FINISHED 16ull     // ... two notches after a step on which at least this many envs finished
 // the array's last, partial piece: zeros for [a0, a1), 16-byte chunks where a whole chunk fits, single bytes after it
 __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, uint32_t a0, uint32_t a1, int lane)
@@ -1405,11 +1407,8 @@ __device__ __attribute__((noinline)) void piece_fill_partial(uint8_t *dst_base, 
         else for (uint32_t b = c; b < a1; b++) dst_base[b] = 0;
     }
 }
-#ifndef CW_TOUCH
-#define CW_TOUCH 0                 // A/B (profiles/r05_step.txt): the sweep's last batch READS the state records the next step kernel starts with
-#endif
 template <int RASTER, int FPJ>
-__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int period16, int head_extra16, int env_lo, int env_n, bool touch = false)
+__device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames, int src, int period16, int head_extra16, int env_lo, int env_n)
 {
     constexpr int JPB = CW_WAVE / FPJ;                                      // jobs per batch of records
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -1473,13 +1472,6 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
         return r;
     };
     Rec nxt = fetch(0);
-#if CW_TOUCH
-    // The step kernel that follows this sweep starts with three 16-byte loads per env (hdr, pos, init_pos: 3 MB at 65 536 envs), and after 1.4 GB of
-    // frame writes none of it is in any cache: its loads queue in HBM behind the write-back of the sweep's tail.  So the sweep's waves read those
-    // records once more as their last batch of jobs begins (one 1-KiB load per array and wave): they are in the memory-side cache when the step kernel
-    // asks.  The values are folded into a word nobody reads, after the last job: no wait inside the job loop.
-    uint4 t_a = make_uint4(0, 0, 0, 0), t_b = t_a, t_c = t_a;
-#endif
     // THE CLOCK.  period16 != 0: job k of a wave starts no earlier than t0 + k x period (period16 = the period in 1/16 of a 10-ns tick of the
     // constant 100-MHz clock, s_memrealtime), the waves' t0 spread evenly over one period: the launch's stores leave as ONE smooth stream at a
     // set rate -- bytes per second = waves x 4 KiB / period -- instead of at whatever rate the waves' instruction streams happen to produce.
@@ -1487,13 +1479,6 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
     for (int base = 0; base < q_mine; base += JPB) {
         const Rec cur = nxt;
         if (base + JPB < q_mine) nxt = fetch(base + JPB);
-#if CW_TOUCH
-        else if (touch) {
-            const int e = wave * CW_WAVE + lane;
-            if (e < P.n_envs) { t_a = P.hdr[e]; t_b = P.pos[e]; t_c = P.init_pos[e]; }
-            for (int e2 = e + n_waves * CW_WAVE; e2 < P.n_envs; e2 += n_waves * CW_WAVE) { t_a.y ^= P.hdr[e2].x; t_b.y ^= P.pos[e2].x; t_c.y ^= P.init_pos[e2].x; }
-        }
-#endif
         const int in_batch = min(q_mine - base, JPB);
         for (int k = 0; k < in_batch; k++) {
             const int f0 = __builtin_amdgcn_readlane(cur.f, FPJ * k);         // the piece's first frame
@@ -1593,9 +1578,6 @@ __device__ __forceinline__ void render_pieces(const CwParams &P, uint8_t *frames
             }
         }
     }
-#if CW_TOUCH
-    { const uint32_t t = t_a.x ^ t_a.y ^ t_b.x ^ t_b.y ^ t_c.x ^ t_c.y ^ t_a.w ^ t_b.w ^ t_c.w; asm volatile("" ::"v"(t)); }
-#endif
 }
 template <int RASTER, int FPJ>
 __global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8_t *frames, int src, int period16, int period16_head, int period16_busy,
@@ -1613,9 +1595,150 @@ __global__ __launch_bounds__(256) void cw_render_pieces_kernel(CwParams P, uint8
     // (after a step on which an eighth of the batch or more finished -- the all-env time-out step wrote two frames per env, 2.8 GB -- and for the
     //  INIT_OBS / desired_goal arrays of a reset the whole launch runs at the busy head's rate: 7.7 TB/s right after that reads 0.34 ms, this 0.22)
     render_pieces<RASTER, FPJ>(P, frames, src, __builtin_amdgcn_readfirstlane(storm ? period16_busy : period16),
-                               __builtin_amdgcn_readfirstlane(!storm && (chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n,
-                               src == CW_SRC_CURRENT && (chunk & 2) && frames == P.obs);
+                               __builtin_amdgcn_readfirstlane(!storm && (chunk & 1) ? (busy ? period16_busy : period16_head) - period16 : 0), env_lo, env_n);
     if (src == CW_SRC_CURRENT && (chunk & 2) && blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = done_now;      // (every wave has read it long ago)
+}
+// ---- SMALL Ray frames (frame_bytes < 4 KiB: grids up to 9x9, the registered craftingworldflat-v3's 8x8 among them): the GATHER painter ------------
+// The sweep above writes a piece as zeros and then its lit items ON TOP: every 12-byte cell row is one more write request to the L2, a piece of small
+// frames holds dozens of them, and it is the L2's write-REQUEST rate, not bytes, that bounds it (8x8: 0.75 of the HBM peak, 5x5: 0.35 -- DESIGN 4.3).
+// Here every lane computes the FINAL content of its own aligned 16-byte chunk and stores it once: a job is still the j-th aligned 4-KiB piece of the
+// array, but it leaves as four plain 1-KiB stores -- one request per 64-byte line, no second pass.  Per job:
+//   1. the colour table of the frames the piece overlaps (<= NF of them), in LDS, one dword per cell: zeroed, then SCATTERED into -- lane = (frame,
+//      object slot) writes COLORS_N[code] at its cell (one object per cell: no two lanes meet), then one lane per frame ORs the agent's flag
+//      (1 + what it holds) into bits 24..26 of its cell;
+//   2. chunk q of a frame always covers the same bytes of the same <= 2 cells (a cell row is 12 bytes, frames are multiples of 16 bytes, so a chunk
+//      starts 0, 4 or 8 bytes into a cell row and never leaves its frame; the second cell may be the first of the next pixel row): a table built once
+//      per workgroup holds, per chunk slot, both cells, their pixel rows and that phase.  A lane reads the slot's entry and the two colours, builds
+//      each cell's 12-byte row (with the agent's mark where the flag is set and the pixel row is 1 or 2, ray.py:483-486) and picks its four dwords.
+// Records are fetched a batch of 64 / NF jobs ahead, one (job, frame) per lane, exactly as in render_pieces.  Same clock, same launch geometry.
+#define CW_GATHER_MAX_S 9
+template <int NF>
+__global__ __launch_bounds__(256) void cw_render_gather_kernel(CwParams P, uint8_t *frames, int src, int period16, int env_lo, int env_n)
+{
+    constexpr int JPB = CW_WAVE / NF;
+    constexpr int COL_WORDS = (NF * CW_GATHER_MAX_S * CW_GATHER_MAX_S + 255) / 256 * 256;     // (the zeroing writes whole 1-KiB rounds)
+    __shared__ uint32_t s_col[256 / CW_WAVE][COL_WORDS];
+    __shared__ uint32_t s_slot[CW_GATHER_MAX_S * CW_GATHER_MAX_S * 3];                          // chunk slots of one frame: 48 S^2 / 16
+    const int lane = threadIdx.x & (CW_WAVE - 1);
+    const int wpb = blockDim.x / CW_WAVE;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    const int n_waves = (int)gridDim.x * wpb;
+    const int wave = (int)blockIdx.x * wpb + wave_in_block;
+    const uint32_t S = (uint32_t)P.size, ncell = (uint32_t)P.ncell, FB = P.frame_bytes, row_bytes = 12u * S, Q = FB >> 4;
+    // ---- the chunk-slot table (the same for every frame): cell A | cell B << 8 | pixel row of A << 16 | of B << 18 | phase << 20
+    for (uint32_t q = threadIdx.x; q < Q; q += blockDim.x) {
+        const uint32_t o = 16u * q, y = o / row_bytes, x = o - y * row_bytes, c0 = x / 12u, ph = (x - 12u * c0) >> 2;
+        const uint32_t cell_a = (y >> 2) * S + c0;
+        uint32_t cell_b, dy_b;
+        if (c0 + 1u < S) { cell_b = cell_a + 1u; dy_b = y & 3u; }
+        else { const uint32_t y2 = min(y + 1u, 4u * S - 1u); cell_b = (y2 >> 2) * S; dy_b = y2 & 3u; }      // (the next pixel row's first cell; a frame's last chunk ends with its last cell: never here)
+        s_slot[q] = cell_a | (cell_b << 8) | ((y & 3u) << 16) | (dy_b << 18) | (ph << 20);
+    }
+    __syncthreads();
+    uint8_t *const dst_base = frames + (size_t)env_lo * FB;
+    const uint32_t total = (uint32_t)env_n * FB;
+    const int n_jobs = (int)((total + CW_PIECE - 1u) / CW_PIECE);
+    if (wave >= n_jobs) return;
+    const int q_mine = (n_jobs + n_waves - 1) / n_waves;
+    uint32_t *const col = s_col[wave_in_block];
+    const uint32_t v_rgb = rgb_of_code((uint32_t)lane & 15u);              // COLORS_N by cell code, one entry per lane (ds_bpermute)
+    const uint32_t fr = (uint32_t)lane >> 3, slot = (uint32_t)lane & 7u;   // what this lane scatters: (frame of the job, object slot)
+    const uint32_t sh_pos = 16u * (slot & 1u), sh_item = 4u * slot;
+    const uint32_t m_p0 = (slot & 6u) == 0u ? 0xFFFFFFFFu : 0u, m_p1 = (slot & 6u) == 2u ? 0xFFFFFFFFu : 0u;
+    const uint32_t m_p2 = (slot & 6u) == 4u ? 0xFFFFFFFFu : 0u, m_p3 = (slot & 6u) == 6u ? 0xFFFFFFFFu : 0u;
+    const uint32_t q_magic = (uint32_t)((1ull << 32) / Q) + 1u;            // x / Q == mulhi(x, magic) for x < 2^16 (a piece holds 256 chunks)
+    // most frames a piece overlaps (cw_frames_per_job's count before rounding) x cells, in rounds of 256 dwords: what a job zeroes of its colour table
+    const int zero_rounds = __builtin_amdgcn_readfirstlane((int)((((CW_PIECE - 1u) / FB + 2u) * ncell + 255u) / 256u));
+    __builtin_amdgcn_s_setprio(3);
+    struct Rec { int f; uint32_t hx, hw; uint4 p; };                      // hx: agent row | col << 8 | hold << 16
+    auto fetch = [&](int base) {
+        Rec r;
+        const int i = base + lane / NF;
+        const int id = i * n_waves + wave;
+        r.f = -1; r.hx = 0; r.hw = 0;
+        r.p = make_uint4(0, 0, 0, 0);
+        if (i < q_mine && id < n_jobs) {
+            const int f = (int)(((uint32_t)id * CW_PIECE) / FB) + (lane % NF);
+            if (f < env_n) {
+                r.f = f;
+                const int e = env_lo + f;
+                if (src == CW_SRC_CURRENT) {
+                    const uint32_t *h = (const uint32_t *)(P.hdr + e);
+                    r.hx = h[0];
+                    r.hw = h[3];
+                    r.p = P.pos[e];
+                } else {
+                    r.hx = src == CW_SRC_INIT ? (uint32_t)P.init_agent[e] : (uint32_t)P.goal_agent[e];
+                    r.hw = src == CW_SRC_INIT ? CW_CODES_INITIAL : P.goal_codes[e];
+                    r.p = src == CW_SRC_INIT ? P.init_pos[e] : P.goal_pos[e];
+                }
+            }
+        }
+        if (src == CW_SRC_CURRENT) r.hx &= 0x00FFFFFFu;
+        else { const uint32_t ar = __umulhi(r.hx, P.div_magic); r.hx = ar | ((r.hx - ar * S) << 8); }
+        return r;
+    };
+    Rec nxt = fetch(0);
+    uint32_t t_next16 = ((uint32_t)__builtin_amdgcn_s_memrealtime() << 4) + (uint32_t)(((long long)wave * period16) / n_waves);
+    for (int base = 0; base < q_mine; base += JPB) {
+        const Rec cur = nxt;
+        if (base + JPB < q_mine) nxt = fetch(base + JPB);
+        const int in_batch = min(q_mine - base, JPB);
+        for (int k = 0; k < in_batch; k++) {
+            const int f0 = __builtin_amdgcn_readlane(cur.f, NF * k);          // the piece's first frame
+            if (f0 < 0) continue;
+            const uint32_t a0 = (uint32_t)((base + k) * n_waves + wave) * CW_PIECE;
+            const uint32_t a1 = min(a0 + CW_PIECE, total);
+            // ---- 1. the colour table of the piece's frames
+            for (int z = 0; z < zero_rounds; z++) *(uint4 *)(col + 256 * z + 4 * lane) = make_uint4(0, 0, 0, 0);
+            {   // (every lane takes part in the permutes -- a ds_bpermute reads zero from a lane that is switched off --, the frame's lanes write)
+                const int from = (int)(((uint32_t)(NF * k) + (fr & (uint32_t)(NF - 1))) << 2);
+                const uint32_t hx = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.hx), hw = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.hw);
+                const int ff = __builtin_amdgcn_ds_bpermute(from, cur.f);
+                const uint32_t pd = ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.x) & m_p0) | ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.y) & m_p1) |
+                                    ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.z) & m_p2) | ((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)cur.p.w) & m_p3);
+                const uint32_t pos = (pd >> sh_pos) & 0xFFFFu, code = (hw >> sh_item) & 15u;
+                const uint32_t rgb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(code << 2), (int)v_rgb);
+                const bool frame_on = fr < (uint32_t)NF && ff >= 0 && (uint32_t)ff * FB < a1;
+                if (frame_on && code != 0 && pos < ncell) col[fr * ncell + pos] = rgb;
+                if (frame_on && slot == 0u)                                   // the agent: 1 + what it holds, in bits 24..26 of its cell (after the objects: a wave's LDS operations keep their order)
+                    atomicOr(&col[fr * ncell + (hx & 0xFFu) * S + ((hx >> 8) & 0xFFu)], (1u + ((hx >> 16) & 0xFFu)) << 24);
+            }
+            if (period16) {                                                   // ---- the job's slot on the clock (render_pieces: THE CLOCK)
+                const uint32_t now16 = (uint32_t)__builtin_amdgcn_s_memrealtime() << 4;
+                const int wait16 = (int)(t_next16 - now16);
+                if (wait16 > 0) {
+                    for (int z = (wait16 * 5) >> 8; z > 0; z--) __builtin_amdgcn_s_sleep(1);
+                    while ((int)(t_next16 - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 4)) > 0) { }
+                } else if (wait16 < -period16) t_next16 = now16 - (uint32_t)period16;
+                t_next16 += (uint32_t)period16;
+            }
+            // ---- 2. every lane its four chunks
+            const uint32_t q0 = (a0 >> 4) - (uint32_t)f0 * Q;                 // chunk index of the piece's first chunk, counted from frame f0's first
+#pragma unroll
+            for (int st = 0; st < CW_PIECE_STORES; st++) {
+                const uint32_t g = q0 + 64u * st + (uint32_t)lane;            // (< 256 + Q)
+                const uint32_t i = __umulhi(g, q_magic), q = g - i * Q;       // frame of the job, chunk slot in it
+                const uint32_t e = s_slot[q];
+                const uint32_t ca = col[i * ncell + (e & 0xFFu)], cb = col[i * ncell + ((e >> 8) & 0xFFu)];
+                u32x3 da = cell_row_dwords(ca & 0x00FFFFFFu), db = cell_row_dwords(cb & 0x00FFFFFFu);
+                const uint32_t dya = (e >> 16) & 3u, dyb = (e >> 18) & 3u, fa = ca >> 24, fb = cb >> 24;
+                // the agent's mark on pixels 1, 2 of pixel rows 1 and 2 of its cell: white, row 2 in the colour of what it holds (ray.py:483-486)
+                const uint32_t ha = fa == 2u ? (110u | (69u << 8) | (39u << 16)) : fa == 3u ? (255u | (105u << 8) | (180u << 16)) : (100u | (100u << 8) | (200u << 16));
+                const uint32_t hb = fb == 2u ? (110u | (69u << 8) | (39u << 16)) : fb == 3u ? (255u | (105u << 8) | (180u << 16)) : (100u | (100u << 8) | (200u << 16));
+                if (fa != 0u && (dya == 1u || dya == 2u)) da = overlay_dwords(da, (dya == 2u && fa > 1u) ? ha : 0x00FFFFFFu);
+                if (fb != 0u && (dyb == 1u || dyb == 2u)) db = overlay_dwords(db, (dyb == 2u && fb > 1u) ? hb : 0x00FFFFFFu);
+                const uint32_t ph = e >> 20;
+                uint4 out;
+                out.x = ph == 0u ? da.x : ph == 1u ? da.y : da.z;
+                out.y = ph == 0u ? da.y : ph == 1u ? da.z : db.x;
+                out.z = ph == 0u ? da.z : ph == 1u ? db.x : db.y;
+                out.w = ph == 0u ? db.x : ph == 1u ? db.y : db.z;
+                const uint32_t at = a0 + 1024u * st + 16u * (uint32_t)lane;
+                if (at < a1) *(uint4 *)(dst_base + at) = out;               // (frames are multiples of 16 bytes: a chunk is inside the array or past its end)
+            }
+        }
+    }
 }
 // ------------------------------------------------------------------------------------ exports
 // dense grid codes [N][S][S]; one thread per 4 cells
@@ -1824,6 +1947,18 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
+// Workgroups of a sweep's launch.  ONE per CU for the frames of the BASELINE configs: their sweep follows its clock to the memory's own edge, and more
+// store streams in flight only slow it (cw_render_grid).  SMALL frames (under small_frame_bytes: several frames per 4-KiB piece, dozens of items) are
+// another regime -- their jobs are bound by instruction issue and LDS / request latency, not by bytes, and a CU hides that with more waves:
+// small_blocks_per_cu workgroups per CU (5x5: 0.34 -> 0.45 of the HBM peak with the same painter, 0.53 with the gather painter;
+// profiles/r05_small_frames.txt).
+static inline bool cw_use_gather(const CwParams &P, const CwTuning &tn) { return tn.gather && P.raster == 0 && P.size <= tn.gather_max_size; }
+static inline int cw_sweep_blocks(const CwParams &P, const CwTuning &tn, long long pieces)
+{
+    const bool small = (int)P.frame_bytes < tn.small_frame_bytes;
+    const int per_cu = small && pieces > 4ll * tn.n_cu * tn.small_blocks_per_cu ? tn.small_blocks_per_cu : 1;
+    return cw_render_grid(tn, pieces) * per_cu;
+}
 typedef void (*CwSweepKernel)(CwParams, uint8_t *, int, int, int, int, int, int, int);
 static CwSweepKernel cw_sweep_kernel(int raster, int fpj)
 {
@@ -1839,7 +1974,15 @@ static void cw_launch_sweep(const CwParams &P, const CwTuning &tn, uint8_t *fram
     for (int c = 0; c < n_chunks; c++) {
         const int env_n = min(per, P.n_envs - c * per);
         const long long pieces = ((long long)env_n * P.frame_bytes + CW_PIECE - 1) / CW_PIECE;
-        hipLaunchKernelGGL(k, dim3(cw_render_grid(tn, pieces)), dim3(256), 0, st, P, frames, src, tn.period16, tn.period16_head, tn.period16_busy, (c == 0 ? 1 : 0) | (c == n_chunks - 1 ? 2 : 0), c * per, env_n);
+        if (cw_use_gather(P, tn)) {                              // the smallest Ray frames: every 16-byte chunk computed and stored once
+            const int grid = cw_sweep_blocks(P, tn, pieces);
+            if (cw_frames_per_job(P.frame_bytes) <= 4)
+                hipLaunchKernelGGL(cw_render_gather_kernel<4>, dim3(grid), dim3(256), 0, st, P, frames, src, tn.period16, c * per, env_n);
+            else
+                hipLaunchKernelGGL(cw_render_gather_kernel<8>, dim3(grid), dim3(256), 0, st, P, frames, src, tn.period16, c * per, env_n);
+            continue;
+        }
+        hipLaunchKernelGGL(k, dim3(cw_sweep_blocks(P, tn, pieces)), dim3(256), 0, st, P, frames, src, tn.period16, tn.period16_head, tn.period16_busy, (c == 0 ? 1 : 0) | (c == n_chunks - 1 ? 2 : 0), c * per, env_n);
     }
 }
 
@@ -1956,7 +2099,7 @@ void cwk_sweep_shape(const CwParams *P, const CwTuning *T, int *n_chunks, int *w
     int per = 0;
     *n_chunks = cw_piece_chunks(*P, *T, &per);
     const long long pieces = ((long long)min(per, P->n_envs) * P->frame_bytes + CW_PIECE - 1) / CW_PIECE;
-    *waves = cw_render_grid(*T, pieces) * (256 / CW_WAVE);
+    *waves = cw_sweep_blocks(*P, *T, pieces) * (256 / CW_WAVE);
     *jobs_per_wave = (int)((pieces + *waves - 1) / *waves);
 }
 

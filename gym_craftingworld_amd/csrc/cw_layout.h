@@ -48,6 +48,10 @@ struct CwTuning {
     int period16_busy = 0;          // ... and of those after a step on which envs finished (their frames were written just before the sweep)
     int render_chunk_rounds = 896;  // a large batch is swept in launches of at most this many rounds of 3 KB per wave over consecutive env ranges:
                                     // 131 072 envs at 21x21 (0: one launch whatever the batch)
+    int gather = 1;                 // the smallest Ray frames (grids up to gather_max_size) by cw_render_gather_kernel; 0: by the piece sweep like all others (CW_TUNE_GATHER)
+    int gather_max_size = 7;        // (measured: the gather painter wins up to 7x7, the piece sweep from 8x8 on; profiles/r05_small_frames.txt)
+    int small_frame_bytes = 4096;   // frames under this many bytes are swept with small_blocks_per_cu workgroups per CU instead of one (CW_TUNE_SMALL_FRAME_BYTES)
+    int small_blocks_per_cu = 4;    // (CW_TUNE_SMALL_BLOCKS)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
 };
 

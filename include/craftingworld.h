@@ -265,7 +265,8 @@ int cw_profile_end(cw_engine *e, cw_profile *out);
 /* Name of the kernel that paints this engine's frames, as a rocprofv3 kernel trace of the same run lists it (without template arguments):
  * CW_OBS_PIXELS_FULL: "cw_render_pieces_kernel" -- the one painter of whole frame arrays, a clocked sweep of aligned 4-KiB pieces; a trace
  * shows cw_render_pieces_kernel<raster, frames per job> (<0, 2> for Ray frames of 4 KiB and more, <1, 2> AltObs; 4 / 8 / 16 frames per job for
- * smaller frames); this is what ms_render_kernel brackets.  CW_OBS_PIXELS_DIRTY: the step kernel itself, which repaints the <= 2 changed cells
+ * smaller frames) -- or "cw_render_gather_kernel" for the smallest Ray frames (grids up to 7x7; <4> / <8> frames per piece in a trace), where
+ * every lane computes its own 16-byte chunks; this is what ms_render_kernel brackets.  CW_OBS_PIXELS_DIRTY: the step kernel itself, which repaints the <= 2 changed cells
  * ("cw_step_fused_kernel" with auto_reset, else "cw_step_kernel").  CW_OBS_STATE: "" (nothing is painted).  A static string. */
 const char *cw_render_kernel_name(const cw_engine *e);
 

@@ -2211,3 +2211,48 @@ def test_replayed_graph_gets_its_records_back_after_a_reseed(obs_mode):
     ka, pa = g_env.get_rng_states(); kb, pb = e_env.get_rng_states()
     assert np.array_equal(pa, pb) and np.array_equal(ka[:, 1:], kb[:, 1:])
     g_env.close(); e_env.close()
+
+
+@pytest.mark.gpu
+def test_soak_the_clock_and_its_guard_outside_the_bench_loop(monkeypatch):
+    """The sweep's clock (7.7 TB/s and its two heads), the busy threshold and the guard were found in bench.py's back-to-back loop on three boxes of one pool
+    (DESIGN 4.3).  Here they run where they were NOT tuned: 5 000 steps of the headline batch with the episode phases spread out (~220 envs finish on every
+    step), a second engine on the same card taking a step of its own every 50th step, the host never waiting.  The guard may give way (twice at most) but
+    must not run away, where it did not move the clock is cw_create's, and over the last 1 000 steps the sweep must still write at >= 0.84 of the HBM peak."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    for k in list(os.environ):
+        if k.startswith('CW_TUNE_'):
+            monkeypatch.delenv(k)
+    N, T = 65536, 5000
+    env = CraftingWorldVecEnv(N, obs_mode='pixels', size=(21, 21), max_steps=300, seed=2024)
+    other = CraftingWorldVecEnv(16384, obs_mode='pixels', size=(21, 21), max_steps=300, seed=7)
+    env.reset(); other.reset()
+    env.set_state(step_num=((np.arange(N) * 7) % 300).astype(np.int32))
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    acts = torch.randint(0, 6, (256, N), device='cuda', dtype=torch.uint8, generator=gen)
+    t0 = env.tuner_state()
+    assert t0['period16'] > 0 and t0['guard_slowdowns'] == 0 and t0['period16_head'] > t0['period16'] and t0['period16_busy'] > t0['period16_head']
+    for t in range(T - 1000):
+        env.step_async(acts[t % 256])
+        if t % 50 == 49:
+            other.step_async(acts[t % 256][:16384])
+    torch.cuda.synchronize()
+    t1 = env.tuner_state()
+    env.profile_begin(1000)
+    for t in range(T - 1000, T):
+        env.step_async(acts[t % 256])
+        if t % 50 == 49:
+            other.step_async(acts[t % 256][:16384])
+    torch.cuda.synchronize()
+    p = env.profile_end()
+    frac = N * (441 + 21168) / (p['ms_render_kernel'] * 1e-3) / 8e12
+    print('soak: cw_create %s, after 4000 steps %s; last 1000 sweeps %.4f ms (median %.4f) = %.3f of the peak'
+          % (t0, t1, p['ms_render_kernel'], p['ms_render_kernel_median'], frac))
+    assert 0 <= t1['guard_slowdowns'] <= 2, (t0, t1)
+    if t1['guard_slowdowns'] == 0:
+        assert t1['period16'] == t0['period16']
+    else:                                                   # (a notch is 0.2 TB/s, ~15 ns of a ~550-ns period: two notches at most)
+        assert t0['period16'] <= t1['period16'] <= t0['period16'] * 1.07, (t0, t1)
+    assert frac >= 0.84, (frac, p, t0, t1)
+    assert int(env.counters[1]) > 4 * N                     # (every env finished ~16 episodes on the way: the steady state, not a quiet run)
+    env.close(); other.close()
