@@ -718,6 +718,29 @@ def main():
             dt = dts[0]
             rec = {'value': n_envs * k2 / dt, 'unit': 'env-steps/s', 'ms_per_step': dt / k2 * 1e3, 'steps': k2, 'n_gpus': 1, 'launch': 'eager, one cw_step per Python call',
                    'repeats': {'n': 3, 'value': [n_envs * k2 / x for x in dts], 'us_per_step': [x / k2 * 1e6 for x in dts]}}
+            # the step kernel's own time (library events around cw_step_fused_kernel, 200 steps) against the HBM roof by SURVEY 8d's bytes per env-step:
+            # A = 48 (state) / 48 + 96 (the reference's dirty-cell repaint).  Neither is bandwidth-bound, and the block says what bounds it instead.
+            e2.profile_begin(200)
+            for t in range(200):
+                e2.step_async(acts[(7 + t) % rows])
+            torch.cuda.synchronize(dev)
+            pk = e2.profile_end()
+            a_bytes = 48.0 + (96.0 if mode == 'pixels_dirty' else 0.0)
+            k_ms = pk['ms_step_kernel']
+            rec['roofline'] = {
+                'bound': 'launch + end-of-kernel write-back' if mode == 'pixels_dirty' else 'launch / latency', 'kernel': 'cw_step_fused_kernel',
+                'algorithmic_bytes_per_env_step': a_bytes, 'algorithmic_bytes_per_launch': a_bytes * n_envs, 'avg_launch_ms': k_ms,
+                'achieved': a_bytes * n_envs / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': a_bytes * n_envs / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                'step_frac': a_bytes * n_envs / (dt / k2) / 1e9 / HBM_PEAK_GBS,
+                'counters': 'profiles/r05_pmc_dirty.json (rocprofv3 --pmc, one pass per counter group, both modes)',
+                'what_bounds_it': ('the waves live ~1.5 us of a 13-us launch (SQ_WAVE_CYCLES); the rest is dispatch and the end-of-kernel write-back of the L2: '
+                                   '163 000 dirty lines against 21 000 in the state-only mode, 129 000 of them partial (32-byte requests with byte masks, '
+                                   'TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) -- the cost follows the number of LINES touched (~3 per move: two pixel rows of two '
+                                   'cells), not requests or bytes: the same stores into two lines per env cost a third, whole-line or nontemporal stores '
+                                   'cost more (profiles/r05_dirty.txt)') if mode == 'pixels_dirty' else
+                                  ('one kernel launch: 3.6 us at its shortest, 6.2 us on average -- dispatch, one round trip to HBM for 48 bytes per env, '
+                                   'the write-back of 21 000 lines; 0.6 TB/s of algorithmic bytes is what that leaves')}
             block = acts[:k2].contiguous()
             kb = int(block.shape[0])                     # (the action pool holds `rows` rows: fewer than k2 when max_steps > 512)
             e2.step_many(block)

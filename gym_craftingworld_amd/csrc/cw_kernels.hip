@@ -23,9 +23,6 @@
 #include "cw_mt.h"
 
 #define CW_WAVE 64
-#ifndef CW_EXP_DIRTY
-#define CW_EXP_DIRTY 0             // (throw-away A/B builds of the dirty-cell step: make exp EXP=-DCW_EXP_DIRTY=n NAME=...; profiles/r05_dirty.txt)
-#endif
 #define CW_BALLOT(p) __builtin_amdgcn_ballot_w64(p)   // the compare's own SGPR pair (__ballot goes through a select + compare)
 #define CW_ALT_FRAME_PACE 2    // render_frame_alt: s_sleep(1) after each 1-KiB store of a single frame's zero fill (back to back 3.0 TB/s, with 64-192 idle clocks 5.2-5.4)
 
@@ -121,20 +118,7 @@ __device__ __forceinline__ void paint_cell(uint8_t *frame, int S, uint32_t cell,
             uint32_t o = (dy == 2 && hold != 0) ? rgb_of_code(hold) : 0x00FFFFFFu;
             d = overlay_dwords(d, o);
         }
-#if CW_EXP_DIRTY == 4
-        if (dy == 1 || dy == 2 || !mark_rows_only) {          // A/B: the whole aligned 64-byte line the row lies in (junk: timing only)
-            uint4 *q = (uint4 *)((uintptr_t)(p + dy * row_bytes) & ~(uintptr_t)63);
-            const uint4 z = make_uint4(d.x, d.y, d.z, 0);
-            q[0] = z; q[1] = z; q[2] = z; q[3] = z;
-        }
-#elif CW_EXP_DIRTY == 5
-        if (dy == 1 || dy == 2 || !mark_rows_only) {          // A/B: the same stores, nontemporal
-            uint32_t *q = (uint32_t *)(p + dy * row_bytes);
-            __builtin_nontemporal_store(d.x, q); __builtin_nontemporal_store(d.y, q + 1); __builtin_nontemporal_store(d.z, q + 2);
-        }
-#else
         if (dy == 1 || dy == 2 || !mark_rows_only) *(u32x3_a4 *)(p + dy * row_bytes) = d;      // (rows 0, 3 never carry the mark)
-#endif
     }
 }
 
@@ -1195,19 +1179,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         P.achieved_out[env] = (uint16_t)o.achieved;
         P.desired_out[env] = (uint16_t)o.desired;
         if (o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
-#if CW_EXP_DIRTY == 1
-        (void)0;                                                                              // A/B: the dirty-cell step without its stores
-#elif CW_EXP_DIRTY == 2
-        if (paint == 1 && o.changed && !o.done) *(uint32_t *)(P.obs + (size_t)env * P.frame_bytes) = o.dirty0;      // A/B: ONE dword per changed env
-#elif CW_EXP_DIRTY == 3
-        if (paint == 1 && o.changed && !o.done) {                                             // A/B: the same number of 12-byte stores, all into the frame's first two lines
-            u32x3 d; d.x = o.dirty0; d.y = o.dirty1; d.z = 7;
-            const int n_st = (o.dirty1 == 0xFFFFFFFFu ? 1 : 2) * 2 + (o.mark0 ? 0 : 2) + ((o.dirty1 != 0xFFFFFFFFu && !o.mark1) ? 2 : 0);
-            for (int q = 0; q < n_st; q++) *(u32x3_a4 *)(P.obs + (size_t)env * P.frame_bytes + 12 * q) = d;
-        }
-#else
         if (paint == 1 && o.changed && !o.done) paint_changed_cells(P, env, h, sp, o);      // render_edit, :358 (a finished env is repainted whole below)
-#endif
     }
     // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
     const uint4 h_last = h;                          // (the finished episode's last state: keep_terminal_obs paints it below)

@@ -1175,7 +1175,10 @@ def test_altobs_stacked_obs_replays_the_reference_fixture(reference_dtypes):
                                            (3000, 21, 'alt'), (5000, 9, 'alt'), (65536, 21, 'alt'), (4001, 22, 'alt'), (1500, 32, 'alt'), (2999, 12, 'alt'),
                                            (3111, 4, 'alt'), (2777, 5, 'alt'), (1234, 8, 'alt'), (999, 11, 'alt'),
                                            (3001, 21, 'ray-chunked'), (70000, 21, 'ray-chunked'), (20000, 8, 'ray-chunked'), (30001, 5, 'ray-chunked'),
-                                           (20011, 13, 'alt-chunked'), (30000, 5, 'alt-chunked')])
+                                           (20011, 13, 'alt-chunked'), (30000, 5, 'alt-chunked'),
+                                           # batches large enough for the four workgroups per CU that frames under 4 KiB are swept with, both painters
+                                           (65536, 5, 'ray'), (50001, 7, 'ray'), (100003, 4, 'ray'), (40000, 8, 'ray'), (30011, 9, 'ray'), (60001, 6, 'alt'),
+                                           (5003, 5, 'ray-nogather'), (2222, 7, 'ray-nogather')])
 def test_full_frame_step_of_every_frame_size_equals_the_dirty_cell_engine(N, size, raster, monkeypatch):
     """The full-frame step = step kernel (finished envs take their look-ahead records), ONE sweep of aligned 4-KiB pieces over the
     observation array whatever the frame size (a piece overlaps two frames from 10x10 / AltObs 12x12 up, as many as nine of the smallest),
@@ -1186,10 +1189,14 @@ def test_full_frame_step_of_every_frame_size_equals_the_dirty_cell_engine(N, siz
     if raster.endswith('-chunked'):  # large batches are swept in several launches over consecutive env ranges (cw_piece_chunks): here the chunks are 4 096 envs,
         raster = raster[:-8]         # the last one shorter
         monkeypatch.setenv('CW_TUNE_RENDER_CHUNK_ROUNDS', '1')
+    gather = raster == 'ray' and size <= 7           # the smallest Ray frames: cw_render_gather_kernel (every lane computes its own 16-byte chunks)
+    if raster.endswith('-nogather'):                  # ... and the piece sweep on the same frames
+        raster, gather = raster[:-9], False
+        monkeypatch.setenv('CW_TUNE_GATHER', '0')
     monkeypatch.setenv('CW_TUNE_PERIOD_NS', '700' if N % 2 else '0')       # (clocked and unclocked sweeps paint the same frames)
     kw = dict(size=(size, size), max_steps=7, seed=29, raster=raster)
     full = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
-    assert full.render_kernel_name() == 'cw_render_pieces_kernel'
+    assert full.render_kernel_name() == ('cw_render_gather_kernel' if gather else 'cw_render_pieces_kernel')
     dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
     for e in (full, dirty):
         e.reset()

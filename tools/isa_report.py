@@ -2,7 +2,7 @@
 """Per-kernel resource table of the HIP engine as built by THIS toolchain.
 
     python tools/isa_report.py            print the table
-    python tools/isa_report.py --write    ... and rewrite profiles/r04_isa_resources.txt (tests/test_isa.py prints a warning when a build differs)
+    python tools/isa_report.py --write    ... and rewrite profiles/r05_isa_resources.txt (tests/test_isa.py prints a warning when a build differs)
 
 Source: hipcc -Rpass-analysis=kernel-resource-usage (registers, spills, scratch, occupancy, LDS)."""
 import os
@@ -13,7 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gym_craftingworld_amd', 'csrc')
-RECORD = os.path.join(ROOT, 'profiles', 'r04_isa_resources.txt')
+RECORD = os.path.join(ROOT, 'profiles', 'r05_isa_resources.txt')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '--cuda-device-only', '-x', 'hip']
 
