@@ -734,7 +734,7 @@ def main():
                 'frac': a_bytes * n_envs / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
                 'step_frac': a_bytes * n_envs / (dt / k2) / 1e9 / HBM_PEAK_GBS,
                 'counters': 'profiles/r05_pmc_dirty.json (rocprofv3 --pmc, one pass per counter group, both modes)',
-                'what_bounds_it': ('the waves live ~1.5 us of a 13-us launch (SQ_WAVE_CYCLES); the rest is dispatch and the end-of-kernel write-back of the L2: '
+                'what_bounds_it': ('a wave lives ~6 us of a 13-us launch, one more than in the state-only mode (SQ_WAVE_CYCLES); the rest is dispatch and the end-of-kernel write-back of the L2: '
                                    '163 000 dirty lines against 21 000 in the state-only mode, 129 000 of them partial (32-byte requests with byte masks, '
                                    'TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) -- the cost follows the number of LINES touched (~3 per move: two pixel rows of two '
                                    'cells), not requests or bytes: the same stores into two lines per env cost a third, whole-line or nontemporal stores '

@@ -1341,16 +1341,44 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     if (h.n_menus != mine.n_menus || h.menus_hash != mine.menus_hash)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: the checkpoint was written with different task menus (selected_tasks / "
                     "number_of_tasks / stacking / reward_style)");
-    if (h.lookahead != mine.lookahead)
-        return fail(CW_ERR_INVALID, "cw_checkpoint_load: the checkpoint was written %s look-ahead records, this engine runs %s them (auto_reset / CW_TUNE_LOOKAHEAD)",
-                    h.lookahead ? "with" : "without", mine.lookahead ? "with" : "without");
-    if (h.total_bytes != mine.total_bytes || length < h.total_bytes)
+    // A checkpoint written WITH look-ahead records can be resumed by an engine that keeps none (CW_TUNE_LOOKAHEAD=0, host-mapped outputs) and the
+    // other way round: the records are not state, only work done ahead -- where one waits, the env's stream is rewound by the draws it took
+    // (cwh_mt_rewind) and the record dropped; an engine that keeps records recomputes them at its next refill.
+    const size_t N = (size_t)e->n;
+    const size_t la_bytes = N * 16 * 3 + N * 4 + 8;
+    const unsigned long long expect = mine.total_bytes + (h.lookahead && !mine.lookahead ? la_bytes : 0) - (!h.lookahead && mine.lookahead ? la_bytes : 0);
+    if (h.total_bytes != expect || length < h.total_bytes)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
     HIP_TRY(quiesce(e));
     const unsigned char *p = (const unsigned char *)buf + sizeof(h);
+    const unsigned char *blob_mt = nullptr, *blob_idx = nullptr;
     for (const CkptSection &sec : ckpt_sections(e)) {
+        if (sec.dev == (void *)e->P.mt) blob_mt = p;
+        if (sec.dev == (void *)e->P.mt_idx) blob_idx = p;
+        const bool la_section = sec.dev == (void *)e->P.nx_init_pos || sec.dev == (void *)e->P.nx_goal_pos || sec.dev == (void *)e->P.nx_misc ||
+                                sec.dev == (void *)e->P.refill_list || sec.dev == (void *)e->P.refill_count;
+        if (la_section && h.lookahead != mine.lookahead) continue;           // (handled below)
         if (sec.bytes) HIP_TRY(aux_copy(e, sec.dev, p, sec.bytes, hipMemcpyDefault));
         p += sec.bytes;
+    }
+    if (h.lookahead && !mine.lookahead) {            // p: the file's look-ahead sections (nx_init_pos, nx_goal_pos, nx_misc, list, count)
+        const uint32_t *misc = (const uint32_t *)(p + N * 32);
+        std::vector<uint32_t> key(CW_MT_N), words(CW_MT_N);
+        HIP_TRY(hipStreamSynchronize(e->aux));
+        for (size_t i = 0; i < N; i++) {
+            if (!(misc[i * 4 + 2] >> 31)) continue;
+            int32_t pos = 0;
+            memcpy(&pos, blob_idx + i * 4, 4);
+            memcpy(words.data(), blob_mt + i * CW_MT_N * 4, CW_MT_N * 4);
+            cwh_mt_to_numpy(words.data(), pos, key.data());
+            cwh_mt_rewind(key.data(), &pos, misc[i * 4 + 3]);
+            const int32_t idx = cwh_mt_from_numpy(key.data(), pos);
+            HIP_TRY(aux_copy(e, e->P.mt + i * CW_MT_N, key.data(), CW_MT_N * 4, hipMemcpyHostToDevice));
+            HIP_TRY(aux_copy(e, e->P.mt_idx + i, &idx, 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipStreamSynchronize(e->aux));                           // (key / idx are reused by the next env)
+        }
+    } else if (!h.lookahead && mine.lookahead) {
+        HIP_TRY(lookahead_drop(e));                  // no record anywhere: the next refill computes every env's
     }
     e->has_reset = true;
     e->la_refill_all = e->P.lookahead != 0;          // (harmless: envs that hold a record are skipped)

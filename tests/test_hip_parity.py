@@ -568,6 +568,11 @@ def test_multi_device_facade_and_gymnasium_adapter(obs_mode):
         assert torch.equal(o['observation'], torch.cat([x[0]['observation'] for x in outs]))
         assert not bool((term & trunc).any())
         assert bool((r[term] == 15).all()) and bool((r[trunc] == -1).all())
+        # gymnasium.vector's episode statistics: info['episode'] = {'r': return, 'l': length} with the mask info['_episode'] -- a success at step l
+        # returns 15 - (l - 1), a time-out -15 (ray.py:361-367 summed by the loop)
+        ep, fin = info['episode'], info['_episode']
+        assert torch.equal(fin, term | trunc)
+        assert bool((ep['r'][term] == 16 - ep['l'][term]).all()) and bool((ep['r'][trunc] == -15).all()) and bool((ep['l'][trunc] == 15).all())
         n_term += int(term.sum().item())
         n_trunc += int(trunc.sum().item())
     assert n_trunc > 0 and n_term > 0
@@ -2263,3 +2268,53 @@ def test_soak_the_clock_and_its_guard_outside_the_bench_loop(monkeypatch):
     assert frac >= 0.84, (frac, p, t0, t1)
     assert int(env.counters[1]) > 4 * N                     # (every env finished ~16 episodes on the way: the steady state, not a quiet run)
     env.close(); other.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode', ['state', 'pixels'])
+def test_checkpoints_cross_lookahead_settings(obs_mode, tmp_path, monkeypatch):
+    """Look-ahead records are work done ahead, not state: a checkpoint written by an engine that keeps them resumes on one that keeps none
+    (CW_TUNE_LOOKAHEAD=0; the streams of envs whose record waited are rewound by the record's draws, cwh_mt_rewind) and the other way round (the
+    records are recomputed at the next refill) -- either way bit-identical to the run that never stopped, RNG streams included."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N = 700
+    kw = dict(size=(8, 8), max_steps=13, obs_mode=obs_mode, seed=3)
+    gen = torch.Generator(device='cuda').manual_seed(16)
+    acts = torch.randint(0, 6, (150, N), device='cuda', dtype=torch.uint8, generator=gen)
+    a = CraftingWorldVecEnv(N, **kw)                      # keeps records
+    assert a.tuner_state()['lookahead'] == 1
+    a.reset()
+    for t in range(37):
+        a.step(acts[t])
+    pa = str(tmp_path / 'with_records')
+    a.save_checkpoint(pa)
+    monkeypatch.setenv('CW_TUNE_LOOKAHEAD', '0')
+    b = CraftingWorldVecEnv(N, **dict(kw, seed=99))       # keeps none
+    monkeypatch.delenv('CW_TUNE_LOOKAHEAD')
+    assert b.tuner_state()['lookahead'] == 0
+    b.load_checkpoint(pa)
+    ka, qa = a.get_rng_states(); kb, qb = b.get_rng_states()
+    assert np.array_equal(qa % 624, qb % 624) and np.array_equal(ka[:, 1:], kb[:, 1:])
+    for t in range(37, 90):
+        _, ra, da, _ = a.step(acts[t])
+        _, rb, db, _ = b.step(acts[t])
+        assert torch.equal(ra, rb) and torch.equal(da, db), t
+    assert torch.equal(a.hdr, b.hdr) and torch.equal(a.slot_pos, b.slot_pos) and torch.equal(a.counters, b.counters)
+    pb = str(tmp_path / 'without_records')
+    b.save_checkpoint(pb)
+    assert os.path.getsize(pb) < os.path.getsize(pa)
+    c = CraftingWorldVecEnv(N, **dict(kw, seed=5))        # keeps records again
+    c.load_checkpoint(pb)
+    for t in range(90, 150):
+        oa, ra, da, _ = a.step(acts[t])
+        oc, rc, dc, _ = c.step(acts[t])
+        assert torch.equal(ra, rc) and torch.equal(da, dc), t
+    assert torch.equal(a.hdr, c.hdr) and torch.equal(a.slot_pos, c.slot_pos) and torch.equal(a.counters, c.counters)
+    if obs_mode == 'pixels':
+        for k in oa:
+            assert torch.equal(oa[k], oc[k]), k
+    ka, qa = a.get_rng_states(); kc, qc = c.get_rng_states()
+    assert np.array_equal(qa % 624, qc % 624) and np.array_equal(ka[:, 1:], kc[:, 1:])
+    assert int(c._counters_raw[5]) < N // 4              # (c found records again after its first refill: no slow resets to speak of)
+    for e in (a, b, c):
+        e.close()
