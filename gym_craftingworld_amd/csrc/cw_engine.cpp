@@ -532,6 +532,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) tn.n_cu = prop.multiProcessorCount;
         tn.render_chunk_rounds = geti("CW_TUNE_RENDER_CHUNK_ROUNDS", tn.render_chunk_rounds);
+        tn.step_envs_per_wave = geti("CW_TUNE_STEP_ENVS_PER_WAVE", tn.step_envs_per_wave);
+        if (tn.step_envs_per_wave != 8 && tn.step_envs_per_wave != 16 && tn.step_envs_per_wave != 32) tn.step_envs_per_wave = 64;
         tn.gather = geti("CW_TUNE_GATHER", tn.gather);
         tn.gather_max_size = geti("CW_TUNE_GATHER_MAX_SIZE", tn.gather_max_size);
         if (tn.gather_max_size > 9) tn.gather_max_size = 9;                       // (cw_render_gather_kernel's tables: frames under 4 KiB)

@@ -1969,9 +1969,9 @@ static inline int cw_reset_grid(const CwTuning &tn, int jobs)
 
 // envs per wavefront of the kernels that reset inline (an inline reset occupies the whole wave, one finished env at a time -- rare now that
 // finished envs take their look-ahead records): aim for ~1024 waves (one per SIMD) -- 64 envs per wave for large batches, down to 8 for small ones
-static int cw_envs_per_wave(int n)
+static int cw_envs_per_wave(int n, int most = 64)
 {
-    int epw = 64;
+    int epw = most;
     while (epw > 8 && (n + epw - 1) / epw < 1024) epw >>= 1;
     return epw;
 }
@@ -1988,7 +1988,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     const bool ev_all = ev && obs_mode != 1;                   // (full-frame mode: only the dominant kernel is bracketed -- every event record costs a pipeline bubble)
     if (ev_all) (void)hipEventRecord(ev[0], st);
     if (auto_reset) {
-        const int epw = cw_envs_per_wave(n);
+        const int epw = cw_envs_per_wave(n, tn.step_envs_per_wave);
         const int waves = (n + epw - 1) / epw;
         hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
                            *P, actions, act_dtype, obs_mode == 2 ? 1 : obs_mode == 1 ? 2 : 0, epw);
