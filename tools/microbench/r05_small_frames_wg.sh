@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: workgroups per CU for the sweep of small frames (CW_TUNE_SMALL_BLOCKS), both painters
 cd ${GRAFT_REPO_ROOT:-.}
 run() { label=$1; raster=$2; sizes=$3; shift 3
   for s in $sizes; do
@@ -7,10 +9,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('%-12s %-3s %2dx%-2d value %.4e  ms/step %.4f  sweep %.4f ms (median %.4f)  frac %.3f (median %.3f)  period16 %d' % ('$label', '$raster', $s, $s, d['value'], d['ms_per_step'], r['avg_launch_ms'], r['median_launch_ms'], r['frac'], r['frac_at_median_launch'], d['tuner']['period16']))"
   done
 }
-run plain_2wg ray "4 5 6 7 8 9" CW_TUNE_GATHER_BLOCKS=2
-run plain_4wg ray "4 5 6 7 8 9" CW_TUNE_GATHER_BLOCKS=4
-run plain_8wg ray "4 5 6 7" CW_TUNE_GATHER_BLOCKS=8
-run gather_8wg ray "4 5 6 7" CW_TUNE_GATHER=1 CW_TUNE_GATHER_BLOCKS=8
-run plain_2wg alt "5 8" CW_TUNE_GATHER_BLOCKS=2
-run plain_4wg alt "5 8" CW_TUNE_GATHER_BLOCKS=4
-run staged_8wg alt "5 8" CW_TUNE_STAGED=1 CW_TUNE_GATHER_BLOCKS=8
+for wg in 1 2 4 8; do
+  run pieces_${wg}wg ray "4 5 6 7 8 9" CW_TUNE_GATHER=0 CW_TUNE_SMALL_BLOCKS=$wg
+  run gather_${wg}wg ray "4 5 6 7" CW_TUNE_SMALL_BLOCKS=$wg
+  run pieces_${wg}wg alt "5 8" CW_TUNE_SMALL_BLOCKS=$wg
+done
