@@ -2318,3 +2318,55 @@ def test_checkpoints_cross_lookahead_settings(obs_mode, tmp_path, monkeypatch):
     assert int(c._counters_raw[5]) < N // 4              # (c found records again after its first refill: no slow resets to speak of)
     for e in (a, b, c):
         e.close()
+
+
+@pytest.mark.gpu
+def test_synchronous_calls_do_not_wait_for_another_engines_work():
+    """Two engines on one device (MultiDeviceVecEnv, a learner beside an env): a synchronous call on one must not wait for what the OTHER has queued
+    (round 4: hipDeviceSynchronize in cw_seed_* / cw_get_mt / cw_get_state / checkpoints stalled everybody).  ~0.6 s of sweeps are queued on B's stream;
+    A.get_state() / get_rng_states() / seed() return long before they have run -- and a stream the caller destroyed after use makes the engine fall back to
+    one device-wide wait instead of failing."""
+    import ctypes as C
+    import time
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    a = CraftingWorldVecEnv(2048, obs_mode='pixels', size=(9, 9), max_steps=20, seed=1)
+    b = CraftingWorldVecEnv(65536, obs_mode='pixels', size=(21, 21), max_steps=300, seed=2)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    acts = torch.randint(0, 6, (65536,), device='cuda', dtype=torch.uint8)
+    with torch.cuda.stream(sa):
+        a.reset()
+        for _ in range(10):
+            a.step_async(acts[:2048])
+    with torch.cuda.stream(sb):
+        b.reset()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sb):
+        t0 = time.perf_counter()
+        for _ in range(3000):                             # ~0.65 s of card time, enqueued in ~50 ms
+            b.step_async(acts)
+        t_enq = time.perf_counter() - t0
+    with torch.cuda.stream(sa):
+        t0 = time.perf_counter()
+        st = a.get_state()
+        a.get_rng_states()
+        a.seed(5)
+        t_calls = time.perf_counter() - t0
+    done_by_then = int(b.counters[0].item()) // 65536     # (this read waits for nothing but its own copy ... on the null stream: see below)
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert st['grid'].shape == (2048, 9, 9)
+    assert t_all > 0.3, (t_enq, t_calls, t_all)           # B's work really was long ...
+    assert t_calls < 0.5 * t_all, (t_enq, t_calls, t_all)  # ... and A's synchronous calls did not sit it out
+    # a stream handed to the engine and destroyed by the caller before the next synchronous call: the engine notices and waits for the device instead
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    s = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(s)) == 0
+    assert a._lib.cw_reset(a._h, s) == 0
+    for _ in range(5):
+        assert a._lib.cw_step(a._h, C.c_void_p(acts.data_ptr()), 2, s) == 0
+    assert hip.hipStreamSynchronize(s) == 0 and hip.hipStreamDestroy(s) == 0
+    a._settle = lambda: None
+    st2 = a.get_state()                                   # (quiesce: hipStreamSynchronize on the dead handle fails -> hipDeviceSynchronize)
+    assert int(st2['step_num'].max()) == 5
+    del done_by_then
+    a.close(); b.close()
