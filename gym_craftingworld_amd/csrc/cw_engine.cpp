@@ -567,7 +567,15 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     ALLOC_OUT(episode_length, N);
     ALLOC_OUT(episode_return, N);
     ALLOC(counters, 8);
-    if (rc == CW_OK && hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) rc = fail(CW_ERR_HIP, "cw_create: no private stream");
+    if (rc == CW_OK) {
+        // the private stream of the synchronous entry points: at the HIGHEST priority -- the runtime multiplexes streams of one priority onto a handful of
+        // hardware queues, and a copy queued behind another engine's thousand pending steps in the same queue waits for them like a device-wide wait
+        int pr_least = 0, pr_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = pr_greatest = 0;
+        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, pr_greatest) != hipSuccess &&
+            hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess)
+            rc = fail(CW_ERR_HIP, "cw_create: no private stream");
+    }
     if (cfg->obs_mode != CW_OBS_STATE) {
         ALLOC_OUT(obs, N * P.frame_bytes);
         ALLOC_OUT(desired_img, N * P.frame_bytes);
