@@ -313,7 +313,7 @@ static void prof_free(cw_engine *e)
 // launch time of the per-step render as currently configured (launches queued back to back, one wait: see calibrate_render_pace): the median and the
 // 90th percentile of 20 launches -- the write path has a slower regime that a configuration may enter launch by launch (profiles/r03_pieces.txt N-P), and
 // a median does not show a configuration that does so one time in three
-static int timed_render_stats(cw_engine *e, double *median, double *p90)
+static int timed_render_stats(cw_engine *e, double *median, double *p90, double *mean = nullptr)
 {
     enum { LAUNCHES = 24, SKIP = 4 };
     hipEvent_t evs[2 * LAUNCHES] = {};
@@ -331,6 +331,7 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90)
     const int n = LAUNCHES - SKIP;
     *median = ms[SKIP + n / 2];
     *p90 = ms[SKIP + (9 * n) / 10 - 1];
+    if (mean) { double acc = 0; for (int i = SKIP; i < LAUNCHES; i++) acc += ms[i]; *mean = acc / n; }
     return CW_OK;
 }
 
@@ -375,10 +376,10 @@ static int calibrate_sweep(cw_engine *e)
     // paces itself: the clock then only costs its reads).  The one with the best 90th-percentile launch: in its saturated regime the memory
     // system is slower AND erratic (7.5 TB/s: 0.214-0.235 ms launch by launch where 7.0 reads 0.2112 +- 0.0005), so the slow launches tell.
     static const double rates[] = {7.7, 7.4, 7.2, 7.0, 6.8, 6.6, 0.0};
-    char log[840] = "";
+    char log[1024] = "";
     size_t len = 0;
     int rc = CW_OK;
-    double best_p90 = 0, med = 0, p90 = 0;
+    double best_p90 = 0, med = 0, p90 = 0, mean = 0;
     rc = timed_render_stats(e, &med, &p90);           // (a card that idled through set-up runs its first launches a few per cent slower: not counted)
     // what a sweep costs beside its jobs (a launch's ramp and tail, the events around it), at a rate the memory system keeps up with easily: the guard's yardstick
     set_sweep_rate(e, 6.4);
@@ -388,8 +389,8 @@ static int calibrate_sweep(cw_engine *e)
     if (forced_rate && atof(forced_rate) > 0) { e->sweep_rate = atof(forced_rate); best_p90 = 1e-9; }
     for (size_t i = 0; i < sizeof(rates) / sizeof(rates[0]) && rc == CW_OK && !forced_rate; i++) {
         set_sweep_rate(e, rates[i]);
-        rc = timed_render_stats(e, &med, &p90);
-        if (len < sizeof(log) - 48) len += (size_t)snprintf(log + len, sizeof(log) - len, " %.1f TB/s (%.0f ns): %.4f/%.4f |", rates[i], tn.period16 / 1.6, med, p90);
+        rc = timed_render_stats(e, &med, &p90, &mean);
+        if (len < sizeof(log) - 56) len += (size_t)snprintf(log + len, sizeof(log) - len, " %.1f TB/s (%.0f ns): %.4f/%.4f/%.4f |", rates[i], tn.period16 / 1.6, med, p90, mean);
         if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; e->sweep_rate = rates[i]; }
     }
     set_sweep_rate(e, e->sweep_rate);
@@ -399,7 +400,7 @@ static int calibrate_sweep(cw_engine *e)
         for (hipEvent_t &ev : e->guard_ev)
             if (hipEventCreate(&ev) != hipSuccess) e->guard_on = false;
     if (getenv("CW_TUNE_VERBOSE"))
-        fprintf(stderr, "[craftingworld] sweep clock, ms per sweep (median/90th percentile of 20; 0.0 TB/s = unclocked):%s -> %s%.0f ns\n", log,
+        fprintf(stderr, "[craftingworld] sweep clock, ms per sweep (median/90th percentile/mean of 20; 0.0 TB/s = unclocked):%s -> %s%.0f ns\n", log,
                 tn.period16 ? "" : "unclocked, ", tn.period16 / 1.6);
     return rc;
 }

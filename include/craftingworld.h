@@ -182,7 +182,11 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
 
 /* --- n_steps consecutive step()s from a DEVICE action array [n_steps][N] (dtype as cw_step): exactly what n_steps calls of cw_step enqueue,
  * in one call (a host loop in Python costs more per call than a state-only step takes on the card).  The frames and outputs left behind are
- * the last step's.  Capturable into a HIP graph as one piece (a replay re-reads the action array: refill it in place between replays). */
+ * the last step's.  Capturable into a HIP graph as one piece (a replay re-reads the action array: refill it in place between replays).
+ * A captured sequence carries ONE look-ahead refill at its head (plus the regular one every max_steps/4 steps inside it): a replayed graph must
+ * refill by itself.  That launch costs ~15 us whatever its list holds -- capture sequences of a refill period or more (a graph of a single
+ * cw_step pays it on every replay: three times a 5-us state-only step).  An env that finds no record is reset on the spot and rejoins the list,
+ * so a graph replayed after a re-seed has its records back after one episode. */
 int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_steps, cw_stream_t stream);
 
 /* --- n_steps consecutive step()s (+ auto-reset) for every env in ONE persistent kernel launch --
