@@ -1877,6 +1877,13 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert d['n_gpus'] == 2 and d['steps'] == 12 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['dist_backend'] == 'gloo'
     assert d['config']['envs_per_gpu'] == 4096 and d['value'] > 0
     assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
+    # every rank explains itself on rank 0's line: its shard, its clock and guard, its sweep time against the roof, its NUMA binding (or why not)
+    pr = d['per_rank']
+    assert [r['rank'] for r in pr] == [0, 1] and [r['envs'] for r in pr] == [[0, 4096], [4096, 8192]]
+    assert all(r['tuner']['guard_slowdowns'] in (-1, 0) and 'period16' in r['tuner'] for r in pr)
+    assert all(0 < r['roofline_frac'] < 1 and r['sweep_ms'] > 0 for r in pr) and d['per_rank_roofline_frac'] == [r['roofline_frac'] for r in pr]
+    assert all('skipped' in r['numa'] and 'rehearsal' in r['numa']['skipped'] for r in pr) and len(d['per_rank_tuner']) == 2
+    assert d['policy_in_loop'] is None                   # (--quick)
 
 
 def test_shards_of_self_launched_ranks_equal_the_single_batch(tmp_path):
