@@ -570,9 +570,10 @@ def main():
         S_ = args.size
         frame_ = 48 * S_ * S_ if args.raster == 'ray' else 27 * S_ * (S_ + 1)
         sweep_bytes = float(N) * (S_ * S_ + frame_)
-        KC = args.consumer_steps if args.consumer_steps > 0 else 2 * args.max_steps
         policy_blocks = {}
         for kind in kinds:
+            # (a pass of the conv consumer is 8.5 ms per step: a third of the window is plenty to time a 0.2-ms sweep 200 times)
+            KC = args.consumer_steps if args.consumer_steps > 0 else (max(100, 2 * args.max_steps // 3) if kind == 'conv' else 2 * args.max_steps)
             policy = make_consumer(kind, N, env.frame_shape, dev)
             obs_t = env._obs
             a = actions[0].clone()
