@@ -846,29 +846,6 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
     if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
 }
 
-// the frames of a freshly reset env (ray.py:191-193: desired_goal, observation, INIT_OBS), painted by the wave that just reset it.  with_obs:
-// all three (dirty-cell engines: the frame is persistent); without: INIT_OBS and desired_goal only (full-frame engines: the observation array
-// is swept after the step kernel, every env's frame alike)
-__device__ __forceinline__ void paint_reset_frames(const CwParams &P, int env, const CwResetOut &r, int lane, bool with_obs)
-{
-    const size_t off = (size_t)env * P.frame_bytes;
-    uint32_t sp[8], gp[8], rgb[8], grgb[8];
-    unpack_pos(r.init_pos, sp);
-    unpack_pos(r.goal_pos, gp);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        rgb[k] = rgb_of_code((uint32_t)k + 1u);
-        grgb[k] = rgb_of_code((r.goal_codes >> (4 * k)) & 15u);
-    }
-    uint8_t *const d0 = with_obs ? P.obs + off : P.init_img + off, *const d1 = with_obs ? P.init_img + off : nullptr;
-    if (P.raster == 1) {
-        render_frame_alt(d0, d1, P.size, P.ncell, P.div_magic, sp, CW_CODES_INITIAL, r.init_agent, 0u, lane, CW_ALT_FRAME_PACE);
-        render_frame_alt(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, r.goal_codes, r.goal_agent, 0u, lane, CW_ALT_FRAME_PACE);
-    } else {
-        render_frame(d0, d1, P.size, P.ncell, P.div_magic, sp, rgb, r.init_agent, 0x00FFFFFFu, lane);
-        render_frame(P.desired_img + off, nullptr, P.size, P.ncell, P.div_magic, gp, grgb, r.goal_agent, 0x00FFFFFFu, lane);
-    }
-}
 // the record of an episode as the look-ahead arrays hold it (refill) / as the episode arrays hold it after a pop
 __device__ __forceinline__ void store_next_record(const CwParams &P, int env, const CwResetOut &r)
 {
@@ -876,19 +853,6 @@ __device__ __forceinline__ void store_next_record(const CwParams &P, int env, co
     P.nx_goal_pos[env] = r.goal_pos;
     P.nx_misc[env] = make_uint4(r.init_agent | (r.goal_agent << 16), r.goal_codes, r.desired | (r.subset << 16) | 0x80000000u, r.draws);
 }
-__device__ __forceinline__ CwResetOut load_episode_record(const CwParams &P, int env)
-{
-    CwResetOut r;
-    const uint4 ip = P.init_pos[env], gp = P.goal_pos[env];
-    r.init_pos = make_uint4(__builtin_amdgcn_readfirstlane(ip.x), __builtin_amdgcn_readfirstlane(ip.y), __builtin_amdgcn_readfirstlane(ip.z), __builtin_amdgcn_readfirstlane(ip.w));
-    r.goal_pos = make_uint4(__builtin_amdgcn_readfirstlane(gp.x), __builtin_amdgcn_readfirstlane(gp.y), __builtin_amdgcn_readfirstlane(gp.z), __builtin_amdgcn_readfirstlane(gp.w));
-    r.init_agent = __builtin_amdgcn_readfirstlane((uint32_t)P.init_agent[env]);
-    r.goal_agent = __builtin_amdgcn_readfirstlane((uint32_t)P.goal_agent[env]);
-    r.goal_codes = __builtin_amdgcn_readfirstlane(P.goal_codes[env]);
-    r.desired = r.subset = r.draws = 0;
-    return r;
-}
-
 // reset() of EVERY env (cw_reset, ray.py:156-218), one wavefront per env: a waiting look-ahead record is taken over, any other env is
 // reset here from its stream.  (cw_reset then sweeps the three frame arrays and refills the records.)
 __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwParams P)
@@ -1137,26 +1101,15 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
 // finished envs among its 64 paints six frames while its three neighbours wait for nothing (15.8 us against 13 with phases in step, round 4)
 struct CwPaintJob { uint4 pos; uint32_t codes, agent_hold_kind, env, pad; };      // agent_hold_kind: agent cell | hold << 16 | kind << 24
 enum { CW_JOB_INIT = 0, CW_JOB_GOAL = 1, CW_JOB_TERMINAL = 2 };
-#ifndef CW_COOP_PAINT
-#define CW_COOP_PAINT 1
-#endif
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
-                                                                                int paint, int epw)
+// One workgroup's share of a step: wave `wave` (global index) steps the envs [wave * epw, wave * epw + epw), finished envs take their records, the workgroup
+// paints the frames a reset changes.
+__device__ __forceinline__ void fused_step(const CwParams &P, const void *actions, int act_dtype, int paint, int epw, int wave, uint32_t *s_mt_wave,
+                                           CwPaintJob *s_jobs, int *s_njobs)
 {
-    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-#if CW_COOP_PAINT
-    __shared__ CwPaintJob s_jobs[CW_RESET_WAVES * CW_WAVE * 3];
-    __shared__ int s_njobs;
-    if (paint && threadIdx.x == 0) s_njobs = 0;
-#endif
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int env0 = wave * epw;
     const bool wave_live = env0 < P.n_envs;          // (a wave past the batch takes part in the workgroup's barriers and paints its share)
-#if !CW_COOP_PAINT
-    if (!wave_live) return;
-#endif
     const int env = env0 + lane;
     const bool live = wave_live && lane < epw && env < P.n_envs;
     const int e = live ? env : (wave_live ? env0 : 0);      // idle lanes shadow a valid env (their results are dropped)
@@ -1168,9 +1121,10 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
     const uint4 ip = P.init_pos[e];                  // (asked for with the rest: a second memory round trip only for lanes that hold something costs the wave the same)
-#if CW_COOP_PAINT
-    if (paint) __syncthreads();                      // (s_njobs; behind the loads' issue)
-#endif
+    if (paint) {
+        if (threadIdx.x == 0) *s_njobs = 0;
+        __syncthreads();                             // (behind the loads' issue)
+    }
     const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
     const bool done = live && o.done;
     if (live) {
@@ -1205,17 +1159,17 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         rbase = __shfl(rbase, 0);
         if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
     }
-#if CW_COOP_PAINT
+    // ---- the jobs of this wave's finished envs (pixel modes): INIT_OBS (with the observation itself in the dirty-cell mode), desired_goal, and with
+    //      keep_terminal_obs the finished episode's last frame.  Envs that took a record: by their own lanes.
+    const int jpe = P.terminal_img ? 3 : 2;
+    int jmine = 0;
     if (paint) {
-        // ---- the jobs of this wave's finished envs: INIT_OBS (with the observation itself in the dirty-cell mode), desired_goal, and with
-        //      keep_terminal_obs the finished episode's last frame.  Envs that took a record: by their own lanes.
-        const int jpe = P.terminal_img ? 3 : 2;
         int jbase = 0;
         if (m_all) {
-            if (lane == 0) jbase = atomicAdd(&s_njobs, jpe * __popcll(m_all));
+            if (lane == 0) jbase = atomicAdd(s_njobs, jpe * __popcll(m_all));
             jbase = __shfl(jbase, 0);
         }
-        const int jmine = jbase + jpe * __popcll(m_all & ((1ull << lane) - 1ull));
+        jmine = jbase + jpe * __popcll(m_all & ((1ull << lane) - 1ull));
         if (done && P.terminal_img) {
             CwPaintJob &j = s_jobs[jmine + 2];
             j.pos = pack_pos(sp_last);
@@ -1234,68 +1188,14 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
             j1.agent_hold_kind = goal.agent | (CW_JOB_GOAL << 24);
             j1.env = (uint32_t)env;
         }
-        unsigned long long m = m_all & ~m_pop;       // envs that found no record: reset here, one at a time, by the whole wave (rare)
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int env_l = env0 + l;
-            const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
-            const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
-            if (lane == 0) {
-                store_episode_records(P, env_l, r, true);                   // step_num >= 1 here
-                if (P.lookahead) queue_for_refill(P, env_l);
-            }
-            if (lane == l) {
-                h = reset_header(P, r, menu_id);
-                unpack_pos(r.init_pos, sp);
-                CwPaintJob &j0 = s_jobs[jmine], &j1 = s_jobs[jmine + 1];
-                j0.pos = r.init_pos; j0.codes = CW_CODES_INITIAL; j0.agent_hold_kind = r.init_agent | (CW_JOB_INIT << 24); j0.env = (uint32_t)env_l;
-                j1.pos = r.goal_pos; j1.codes = r.goal_codes; j1.agent_hold_kind = r.goal_agent | (CW_JOB_GOAL << 24); j1.env = (uint32_t)env_l;
-            }
-        }
-        if (live) {
-            P.hdr[env] = h;
-            P.pos[env] = pack_pos(sp);
-        }
-        __syncthreads();
-        const int n_jobs = s_njobs;
-        for (int jq = wave_in_block; jq < n_jobs; jq += CW_RESET_WAVES) {
-            const CwPaintJob &j = s_jobs[jq];
-            uint32_t jp[8];
-            unpack_pos(make_uint4(__builtin_amdgcn_readfirstlane(j.pos.x), __builtin_amdgcn_readfirstlane(j.pos.y), __builtin_amdgcn_readfirstlane(j.pos.z),
-                                  __builtin_amdgcn_readfirstlane(j.pos.w)), jp);
-            const uint32_t codes = __builtin_amdgcn_readfirstlane(j.codes), ahk = __builtin_amdgcn_readfirstlane(j.agent_hold_kind);
-            const size_t off = (size_t)__builtin_amdgcn_readfirstlane(j.env) * P.frame_bytes;
-            const uint32_t kind = ahk >> 24;
-            uint8_t *d0, *d1 = nullptr;
-            if (kind == CW_JOB_INIT) { d0 = P.init_img + off; if (paint == 1) d1 = P.obs + off; }      // (dirty-cell engines: the frame is persistent, the new episode's first frame is painted here too)
-            else if (kind == CW_JOB_GOAL) d0 = P.desired_img + off;
-            else d0 = P.terminal_img + off;
-            paint_state_frame(P, d0, jp, codes, ahk & 0xFFFFu, (ahk >> 16) & 0xFFu, lane, d1);
-        }
-        return;
     }
-#endif
-    unsigned long long m = paint ? m_all : (m_all & ~m_pop);     // what is left for the whole wave: the slow resets, and in the pixel mode every finished env's frames
+    unsigned long long m = m_all & ~m_pop;           // envs that found no record: reset here, one at a time, by the whole wave (rare)
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
         const int env_l = env0 + l;
-        const bool took = (m_pop >> l) & 1ull;
-        if (paint && P.terminal_img) {               // keep_terminal_obs: the finished episode's last frame
-            uint32_t tp[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) tp[k] = __builtin_amdgcn_readlane(sp_last[k], l);
-            const uint32_t hx = __builtin_amdgcn_readlane(h_last.x, l), codes = __builtin_amdgcn_readlane(h_last.w, l);
-            paint_state_frame(P, P.terminal_img + (size_t)env_l * P.frame_bytes, tp, codes, (hx & 0xFFu) * P.size + ((hx >> 8) & 0xFFu), (hx >> 16) & 0xFFu, lane);
-        }
-        if (took) {                                  // (the records lane l stored a moment ago, read back by the whole wave)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            paint_reset_frames(P, env_l, load_episode_record(P, env_l), lane, paint == 1);
-            continue;
-        }
         const uint32_t menu_id = __builtin_amdgcn_readlane(h.x, l) >> 24;
-        const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
+        const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt_wave, lane);
         if (lane == 0) {
             store_episode_records(P, env_l, r, true);                       // step_num >= 1 here
             if (P.lookahead) queue_for_refill(P, env_l);
@@ -1303,13 +1203,43 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
         if (lane == l) {
             h = reset_header(P, r, menu_id);
             unpack_pos(r.init_pos, sp);
+            if (paint) {
+                CwPaintJob &j0 = s_jobs[jmine], &j1 = s_jobs[jmine + 1];
+                j0.pos = r.init_pos; j0.codes = CW_CODES_INITIAL; j0.agent_hold_kind = r.init_agent | (CW_JOB_INIT << 24); j0.env = (uint32_t)env_l;
+                j1.pos = r.goal_pos; j1.codes = r.goal_codes; j1.agent_hold_kind = r.goal_agent | (CW_JOB_GOAL << 24); j1.env = (uint32_t)env_l;
+            }
         }
-        if (paint) paint_reset_frames(P, env_l, r, lane, paint == 1);
     }
     if (live) {
         P.hdr[env] = h;
         P.pos[env] = pack_pos(sp);
     }
+    if (!paint) return;
+    __syncthreads();
+    const int n_jobs = *s_njobs;
+    for (int jq = wave_in_block; jq < n_jobs; jq += CW_RESET_WAVES) {
+        const CwPaintJob &j = s_jobs[jq];
+        uint32_t jp[8];
+        unpack_pos(make_uint4(__builtin_amdgcn_readfirstlane(j.pos.x), __builtin_amdgcn_readfirstlane(j.pos.y), __builtin_amdgcn_readfirstlane(j.pos.z),
+                              __builtin_amdgcn_readfirstlane(j.pos.w)), jp);
+        const uint32_t codes = __builtin_amdgcn_readfirstlane(j.codes), ahk = __builtin_amdgcn_readfirstlane(j.agent_hold_kind);
+        const size_t off = (size_t)__builtin_amdgcn_readfirstlane(j.env) * P.frame_bytes;
+        const uint32_t kind = ahk >> 24;
+        uint8_t *d0, *d1 = nullptr;
+        if (kind == CW_JOB_INIT) { d0 = P.init_img + off; if (paint == 1) d1 = P.obs + off; }      // (dirty-cell engines: the frame is persistent, the new episode's first frame is painted here too)
+        else if (kind == CW_JOB_GOAL) d0 = P.desired_img + off;
+        else d0 = P.terminal_img + off;
+        paint_state_frame(P, d0, jp, codes, ahk & 0xFFFFu, (ahk >> 16) & 0xFFu, lane, d1);
+    }
+}
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
+                                                                                int paint, int epw)
+{
+    __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
+    __shared__ CwPaintJob s_jobs[CW_RESET_WAVES * CW_WAVE * 3];
+    __shared__ int s_njobs;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
+    fused_step(P, actions, act_dtype, paint, epw, blockIdx.x * CW_RESET_WAVES + wave_in_block, s_mt[wave_in_block], s_jobs, &s_njobs);
 }
 
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream

@@ -716,7 +716,7 @@ def test_altobs_raster_vs_oracle(obs_mode, S, N):
     obs = env.reset()
     ora.reset()
     assert tuple(obs['observation'].shape) == (N, 3 * S + 3, 3 * S, 3)
-    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_pieces_kernel')
+    assert env.render_kernel_name() == ('cw_step_fused_kernel' if obs_mode == 'pixels_dirty' else 'cw_render_pieces_kernel')      # (AltObs raster: never fused)
     acts = np.random.RandomState(2).randint(0, 6, size=(T, N)).astype(np.int32)
     dacts = torch.as_tensor(acts, device=env.device)
     for t in range(T):
