@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(CW_WAVE) void cw_resident_kernel(CwParams P, CwResi
 // after this kernel (cw_render_pieces_kernel), every env's frame alike, and nothing runs beside that sweep: rounds 1-3 reset and painted
 // beside it, which cost the launch 26 us for ~220 finished envs per step (profiles/r04_lookahead.txt).  keep_terminal_obs: the finished
 // episode's last frame, from the lane's registers.  No done list, no second launch waiting on the first.
-// the frames a finished env leaves to paint, as jobs in LDS that ALL FOUR waves of the workgroup take in turn (CW_COOP_PAINT): with the episode
+// the frames a finished env leaves to paint, as jobs in LDS that ALL FOUR waves of the workgroup take in turn: with the episode
 // phases spread out ~220 envs finish on every step of 65 536, two frames each, and the kernel ends with its slowest wave -- one that finds three
 // finished envs among its 64 paints six frames while its three neighbours wait for nothing (15.8 us against 13 with phases in step, round 4)
 struct CwPaintJob { uint4 pos; uint32_t codes, agent_hold_kind, env, pad; };      // agent_hold_kind: agent cell | hold << 16 | kind << 24
