@@ -347,7 +347,8 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90, double 
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
 // the clock's three periods from one rate: a launch's first CW_HEAD_JOBS jobs run CW_HEAD_NOTCH slower, after a step on which envs finished
 // CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
-static const double CW_HEAD_NOTCH = 0.4, CW_BUSY_NOTCH = 0.75, CW_RATE_FLOOR = 5.0;
+static const double CW_RATE_FLOOR = 5.0;
+static double CW_HEAD_NOTCH = 0.4, CW_BUSY_NOTCH = 0.75;      // (TB/s; CW_TUNE_HEAD_NOTCH / CW_TUNE_BUSY_NOTCH for experiments: profiles/r05_experiments.txt J)
 static const int CW_HEAD_JOBS_HOST = 64;
 static void set_sweep_rate(cw_engine *e, double tb_per_s)
 {
@@ -362,6 +363,8 @@ static int calibrate_sweep(cw_engine *e)
     int n_chunks = 1, jobs_per_wave = 1;
     cwk_sweep_shape(&e->P, &tn, &n_chunks, &e->sweep_waves, &jobs_per_wave);
     e->sweep_jobs = (double)n_chunks * jobs_per_wave;
+    if (const char *v = getenv("CW_TUNE_HEAD_NOTCH")) CW_HEAD_NOTCH = atof(v);
+    if (const char *v = getenv("CW_TUNE_BUSY_NOTCH")) CW_BUSY_NOTCH = atof(v);
     if (const char *per = getenv("CW_TUNE_PERIOD_NS")) {                         // (the heads keep their distance: a forced 545 ns is 7.7 TB/s with 7.3 / 6.95 heads)
         const double ns = atof(per);
         set_sweep_rate(e, ns > 0 ? (double)e->sweep_waves * 4096.0 / (ns * 1e-9) * 1e-12 : 0.0);
