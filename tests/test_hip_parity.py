@@ -1573,6 +1573,20 @@ def test_facade_store_gif_files_and_rng_draw(tmp_path, monkeypatch):
     im = Image.open([f for f in files if os.path.basename(f).startswith('E0(')][0])
     assert im.size == ((2 * 20 + 4) * 4, 20 * 4) and 1 <= im.n_frames <= 7
     plain.close(); rec.close()
+    # CraftingWorldEnvFlat writes a finished episode's GIF only if it achieved something or every 30th episode (craftingworld_flat.py:64-71)
+    flat = cw.CraftingWorldEnvFlat(size=(5, 5), max_steps=4, seed=4, store_gif=True, render_save_rate=1)
+    flat.reset()
+    episodes, achieved = 0, {}
+    while episodes < 33:
+        _, _, d, info = flat.step(int(rng.randint(6)))
+        if d:
+            achieved[flat.ep_no] = bool(info['achieved_goal'].any())
+            flat.reset()
+            episodes += 1
+    eps = sorted(int(os.path.basename(f)[1:].split('(')[0]) for f in glob.glob('renders/env%d/*.gif' % flat.env_id))
+    assert eps == sorted(e for e, a in achieved.items() if a or e % 30 == 0), (eps, achieved)
+    assert 0 in eps and 30 in eps and len(eps) < 33
+    flat.close()
 
 
 @pytest.mark.gpu
