@@ -101,6 +101,15 @@ def cpu_baseline(size, max_steps, seconds=12.0, spare_cores=0):
 
     rate_dirty, reps, dt = timed(batch.rollout, 0.4 * seconds)
     rate_full, reps_full, dt_full = timed(batch.rollout_full_frame, 0.6 * seconds)
+    # BASELINE configs[0] on the CPU (SURVEY 8d ii): ONE env on ONE core, the reference's own loop shape -- 200 random steps, reset on done -- many times over
+    one = OracleBatch(1, rng_states=keys_pos[:1], size=(size, size), max_steps=max_steps)
+    one.reset()
+    a1 = rng.randint(0, 6, size=(200, 1)).astype(np.int8)
+    one.rollout(a1, nthreads=1)
+    t0, n1 = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.25:
+        n1 += one.rollout(a1, nthreads=1)
+    single_core = n1 / (time.perf_counter() - t0)
     calib = None
     try:   # port vs the reference's own Python, both timed in the build container (tools/calibrate_cpu.py)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'cpu_calibration.json')) as f:
@@ -113,6 +122,8 @@ def cpu_baseline(size, max_steps, seconds=12.0, spare_cores=0):
     except (OSError, KeyError, ValueError):
         pass
     return dict(value=rate_full, unit='env-steps/s', cores=cores, kind='port', dirty_cell_value=rate_dirty, calibration=calib,
+                single_env_one_core={'value': single_core, 'unit': 'env-steps/s', 'workload': 'BASELINE configs[0]: one env, 200 random steps at a time, reset on done, '
+                                     'one core, the reference\'s dirty-cell repaint (the reference\'s own Python: 64-78 k env-steps/s, BASELINE.md 2)'},
                 like_for_like='value renders the whole frame after every step, as the GPU headline does; dirty_cell_value '
                               'keeps the reference\'s persistent frame and repaints <= 2 cells per step (compare with '
                               'other_obs_modes_1gpu.pixels_dirty)',
