@@ -1969,6 +1969,17 @@ def test_bench_json_line_carries_the_contract():
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'env-steps/s' and isinstance(c['sample'], str)
     assert d['repeats']['n'] == 3 and d['repeats']['value'][0] == d['value']
     assert d['metric_window']['steps'] == 40 and d['metric_window']['value'] > 0 and len(d['metric_window']['slowest_step_ms']) == 2
+    # round 5: the whole step against the roof; the engine with a consumer between two steps; the CPU baseline beside a GPU soak; per-rank blocks
+    assert 0 < r['step_frac'] < r['frac'] and 0 < r['step_frac_metric_window'] < 1 and 0 < r['step_frac_metric_window_desync'] < 1
+    assert abs(r['step_frac'] - r['step_algorithmic_bytes'] / (d['ms_per_step'] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    pl = d['policy_in_loop']
+    assert set(pl) == {'reduce32', 'reduce', 'conv'}
+    for b in pl.values():
+        assert b['consumer_ms'] > 0 and b['ms_per_step'] > b['consumer_ms'] and 0 < b['sweep']['frac'] < 1 and b['guard_moves'] >= 0
+        assert abs(b['env_ms_per_step'] - (b['ms_per_step'] - b['consumer_ms'])) < 1e-9 and 'tuner_after' in b
+    sk = d['soak_beside_cpu_baseline']
+    assert sk['steps'] >= 256 and sk['value'] > 0 and sk['guard_moves'] >= 0 and c['cores'] >= 1 and c['single_env_one_core']['value'] > 0
+    assert len(d['per_rank']) == 1 and d['per_rank'][0]['numa'] == {'skipped': 'single rank'} and d['per_rank_roofline_frac'] == [r['frac']]
 
 
 @pytest.mark.gpu
