@@ -544,6 +544,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.small_frame_bytes = geti("CW_TUNE_SMALL_FRAME_BYTES", tn.small_frame_bytes);
         tn.small_blocks_per_cu = geti("CW_TUNE_SMALL_BLOCKS", tn.small_blocks_per_cu);
         if (tn.small_blocks_per_cu < 1 || tn.small_blocks_per_cu > 8) tn.small_blocks_per_cu = 1;
+        tn.small_launch_bytes = (long long)geti("CW_TUNE_SMALL_LAUNCH_MB", (int)(tn.small_launch_bytes >> 20)) << 20;
     }
 
     int rc = CW_OK;

@@ -1853,11 +1853,12 @@ static inline int cw_render_grid(const CwTuning &tn, long long jobs)
 // store streams in flight only slow it (cw_render_grid).  SMALL frames (under small_frame_bytes: several frames per 4-KiB piece, dozens of items) are
 // another regime -- their jobs are bound by instruction issue and LDS / request latency, not by bytes, and a CU hides that with more waves:
 // small_blocks_per_cu workgroups per CU (5x5: 0.34 -> 0.45 of the HBM peak with the same painter, 0.53 with the gather painter;
-// profiles/r05_small_frames.txt).
+// profiles/r05_experiments.txt D).  The gather painter wants them whatever the batch (5x5 at 262 144 envs: 0.38 / 0.62 / 0.72 with 1 / 2 / 4); the piece
+// sweep only while its launch is short -- from ~300 MB on one workgroup per CU is the better again (8x8 at 262 144 envs: 0.81 / 0.75 / 0.77), section K.
 static inline bool cw_use_gather(const CwParams &P, const CwTuning &tn) { return tn.gather && P.raster == 0 && P.size <= tn.gather_max_size; }
 static inline int cw_sweep_blocks(const CwParams &P, const CwTuning &tn, long long pieces)
 {
-    const bool small = (int)P.frame_bytes < tn.small_frame_bytes;
+    const bool small = (int)P.frame_bytes < tn.small_frame_bytes && (cw_use_gather(P, tn) || pieces * (long long)CW_PIECE < tn.small_launch_bytes);
     const int per_cu = small && pieces > 4ll * tn.n_cu * tn.small_blocks_per_cu ? tn.small_blocks_per_cu : 1;
     return cw_render_grid(tn, pieces) * per_cu;
 }

@@ -52,6 +52,7 @@ struct CwTuning {
     int gather_max_size = 7;        // (measured: the gather painter wins up to 7x7, the piece sweep from 8x8 on; profiles/r05_small_frames.txt)
     int small_frame_bytes = 4096;   // frames under this many bytes are swept with small_blocks_per_cu workgroups per CU instead of one (CW_TUNE_SMALL_FRAME_BYTES)
     int small_blocks_per_cu = 4;    // (CW_TUNE_SMALL_BLOCKS)
+    long long small_launch_bytes = 320ll << 20;   // ... the piece sweep only while a launch writes less than this (the gather painter always); CW_TUNE_SMALL_LAUNCH_MB
     int step_envs_per_wave = 64;    // most envs a wave of cw_step_fused_kernel steps (64: one wave per SIMD at 65 536 envs; CW_TUNE_STEP_ENVS_PER_WAVE: 8 / 16 / 32 / 64)
     int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
 };
