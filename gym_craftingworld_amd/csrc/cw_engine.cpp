@@ -98,11 +98,17 @@ struct cw_engine {
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
     int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
     double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;
-    bool guard_on = false, guard_pending = false;
-    hipEvent_t guard_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool guard_on = false;
+    // the guard's samples in flight: the host runs up to ~1 000 steps ahead of the card, so a sample recorded now is read a dozen samples later
+    enum { GUARD_RING = 32 };
+    struct GuardSample { hipEvent_t ev[6]; int period16; } guard_ring[GUARD_RING] = {};
+    unsigned guard_head = 0, guard_tail = 0;      // next slot to record into / oldest slot not read yet
     unsigned guard_step = 0;
-    int guard_late = 0, guard_good = 0, guard_slowdowns = 0, guard_period16 = 0;
-    double sweep_rate_top = 0;          // the rate cw_create chose: the guard never goes above it
+    int guard_late = 0, guard_good = 0, guard_slowdowns = 0;
+    double sweep_rate_top = 0;          // the best rate known to hold: cw_create's choice, raised by a probe that paid (sweep_guard_tick)
+    double guard_ms_sum = 0, guard_prev_mean = 0;   // sweep times sampled at the current rate; their mean at the rate a probe left
+    int guard_ms_n = 0, guard_probe_need = 0, guard_probes = 0, guard_recover_need = 64;
+    bool guard_probing = false, guard_recovering = false;   // the last move was a probe / a step back towards the best rate known, not yet confirmed
     int prof_cap = 0, prof_n = 0;
     // the engine's OWN work: the streams it was handed since its last wait (at most 4 are remembered) and a private stream for the synchronous
     // entry points' copies and kernels (cw_seed_*, cw_get_mt, cw_get/set_state, checkpoints): none of them waits for anybody else's work
@@ -398,10 +404,12 @@ static int calibrate_sweep(cw_engine *e)
     }
     set_sweep_rate(e, e->sweep_rate);
     e->sweep_rate_top = e->sweep_rate;
+    e->guard_probe_need = 64;                       // (CW_GUARD_RECOVER, below)
     e->guard_on = rc == CW_OK && e->sweep_rate > 0 && e->auto_reset && !(getenv("CW_TUNE_GUARD") && atoi(getenv("CW_TUNE_GUARD")) == 0);
     if (e->guard_on)
-        for (hipEvent_t &ev : e->guard_ev)
-            if (hipEventCreate(&ev) != hipSuccess) e->guard_on = false;
+        for (auto &smp : e->guard_ring)
+            for (hipEvent_t &ev : smp.ev)
+                if (hipEventCreate(&ev) != hipSuccess) e->guard_on = false;
     if (getenv("CW_TUNE_VERBOSE"))
         fprintf(stderr, "[craftingworld] sweep clock, ms per sweep (median/90th percentile/mean of 20; 0.0 TB/s = unclocked):%s -> %s%.0f ns\n", log,
                 tn.period16 ? "" : "unclocked, ", tn.period16 / 1.6);
@@ -412,46 +420,89 @@ static int calibrate_sweep(cw_engine *e)
 // (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + the busy head + what
 // a launch costs beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 10-16 % launch after launch; at
 // the edge (7.7 TB/s) one launch in ten is 7-12 % late and the rest on time.  Three samples in a row more than 6 % late: the rate goes down by
-// 0.2 TB/s.  It comes back a notch after CW_GUARD_RECOVER samples in a row on time (~4 000 steps), never above what cw_create chose: a disturbance
+// 0.2 TB/s.  It comes back a notch after CW_GUARD_RECOVER samples in a row on time (~4 000 steps), up to the best rate known to hold: a disturbance
 // that has passed -- another process on the card, a thermal excursion -- does not slow the engine for the rest of its life, and a clock that moves
-// once in thousands of steps does not hunt.  -> the event array for this step's launch, or null.
-enum { CW_GUARD_EVERY = 64, CW_GUARD_RECOVER = 64 };
+// once in thousands of steps does not hunt.
+// PROBES (round 5).  cw_create's choice is a measurement of one moment: an engine created while the card was in a worse state settles a notch or two
+// under what the card takes an hour later (7.4 instead of 7.7 TB/s: 2.7 % of every sweep), and round 4's guard only ever went down.  Now, after
+// guard_probe_need samples in a row on time at the best rate known, the guard tries ONE notch more (never beyond CW_RATE_CEILING, the write path's edge)
+// and keeps it only if it PAYS: the mean of CW_PROBE_SAMPLES sweeps at the new rate must be under the mean at the old one -- "on time" is not enough, a
+// clock a little too fast is on time and slower.  A probe that does not pay is undone and the next one waits twice as long.
+// -> the event array for this step's launch, or null.
+enum { CW_GUARD_EVERY = 64, CW_GUARD_RECOVER = 64, CW_PROBE_SAMPLES = 32, CW_PROBE_NEED_MAX = 2048 };
+static const double CW_RATE_CEILING = 7.7;
+static void guard_set_rate(cw_engine *e, double rate)
+{
+    e->sweep_rate = rate;
+    set_sweep_rate(e, rate);
+    e->guard_ms_sum = 0;
+    e->guard_ms_n = 0;
+    e->guard_good = e->guard_late = 0;
+}
 static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
 {
     if (++e->guard_step % CW_GUARD_EVERY) return nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;     // (a captured graph keeps the rate it was captured with)
-    if (e->guard_pending) {
-        if (hipEventQuery(e->guard_ev[5]) != hipSuccess) return nullptr;                                        // (the sampled sweep has not run yet)
+    const bool verbose = getenv("CW_TUNE_VERBOSE") != nullptr;
+    // the samples whose sweeps have run by now, oldest first (the host may be a thousand steps ahead of the card: a sample is read long after it was recorded)
+    while (e->guard_tail != e->guard_head && hipEventQuery(e->guard_ring[e->guard_tail % cw_engine::GUARD_RING].ev[5]) == hipSuccess) {
+        cw_engine::GuardSample &smp = e->guard_ring[e->guard_tail++ % cw_engine::GUARD_RING];
         float ms = 0.f;
-        e->guard_pending = false;
-        if (hipEventElapsedTime(&ms, e->guard_ev[4], e->guard_ev[5]) == hipSuccess && ms > 0.f && e->guard_period16 == e->tune.period16) {
+        if (hipEventElapsedTime(&ms, smp.ev[4], smp.ev[5]) == hipSuccess && ms > 0.f && smp.period16 == e->tune.period16) {      // (a sample of another rate says nothing)
             const double scheduled = (e->sweep_jobs * (e->tune.period16 / 1.6) + CW_HEAD_JOBS_HOST * ((e->tune.period16_busy - e->tune.period16) / 1.6)) * 1e-6 +
                                      e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
             const bool late = ms > 1.06 * scheduled;
             e->guard_late = late ? e->guard_late + 1 : 0;
-            e->guard_good = late ? 0 : e->guard_good + 1;
-            if (e->guard_good >= CW_GUARD_RECOVER && e->sweep_rate + 0.1 < e->sweep_rate_top) {
-                e->sweep_rate += 0.2;
-                set_sweep_rate(e, e->sweep_rate);
-                e->guard_good = 0;
-                if (getenv("CW_TUNE_VERBOSE"))
-                    fprintf(stderr, "[craftingworld] sweep clock: %d samples in a row on time -> back to %.1f TB/s (%.0f ns)\n", CW_GUARD_RECOVER, e->sweep_rate, e->tune.period16 / 1.6);
-            }
-            if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {
-                e->sweep_rate -= 0.2;
-                set_sweep_rate(e, e->sweep_rate);
-                e->guard_late = 0;
-                e->guard_slowdowns++;
-                if (getenv("CW_TUNE_VERBOSE"))
-                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f scheduled, three samples in a row -> %.1f TB/s (%.0f ns)\n", ms, scheduled,
-                            e->sweep_rate, e->tune.period16 / 1.6);
+            // ("in a row" for the way up means MOSTLY: at the edge one launch in ten is late by itself, and 64 strictly in a row would never come)
+            e->guard_good = late ? std::max(0, e->guard_good - 8) : e->guard_good + 1;
+            e->guard_ms_sum += ms;
+            e->guard_ms_n++;
+            if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {                     // ---- not keeping its schedule: a notch down
+                const bool was_probe = e->guard_probing;
+                guard_set_rate(e, e->sweep_rate - 0.2);
+                if (was_probe) { e->guard_probing = false; e->guard_probe_need = std::min(2 * e->guard_probe_need, (int)CW_PROBE_NEED_MAX); }
+                else e->guard_slowdowns++;
+                if (e->guard_recovering) {           // the way back did not hold: the next attempt waits twice as long (no see-saw between two notches)
+                    e->guard_recovering = false;
+                    e->guard_recover_need = std::min(2 * e->guard_recover_need, (int)CW_PROBE_NEED_MAX);
+                }
+                if (verbose)
+                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f scheduled, three samples in a row -> %.1f TB/s (%.0f ns)%s\n", ms, scheduled,
+                            e->sweep_rate, e->tune.period16 / 1.6, was_probe ? " (a probe undone)" : "");
+            } else if (e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES) {                   // ---- a probe's verdict: does the faster clock PAY?
+                const double mean = e->guard_ms_sum / e->guard_ms_n;
+                e->guard_probing = false;
+                if (mean < 0.998 * e->guard_prev_mean) {
+                    e->sweep_rate_top = e->sweep_rate;
+                    e->guard_probe_need = CW_GUARD_RECOVER / 4;                                  // (it paid: the next notch is tried sooner)
+                    if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probe %.1f TB/s pays (%.4f ms against %.4f): kept\n", e->sweep_rate, mean, e->guard_prev_mean);
+                } else {
+                    if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probe %.1f TB/s does not pay (%.4f ms against %.4f): undone\n", e->sweep_rate, mean, e->guard_prev_mean);
+                    guard_set_rate(e, e->sweep_rate - 0.2);
+                    e->guard_probe_need = std::min(2 * e->guard_probe_need, (int)CW_PROBE_NEED_MAX);
+                }
+            } else if (!e->guard_probing && e->guard_good >= e->guard_recover_need && e->sweep_rate + 0.1 < e->sweep_rate_top) {      // ---- back towards the best rate known
+                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %d samples on time -> back to %.1f TB/s\n", e->guard_good, e->sweep_rate + 0.2);
+                guard_set_rate(e, e->sweep_rate + 0.2);
+                e->guard_recovering = true;
+            } else if (e->guard_recovering && e->guard_good >= CW_GUARD_RECOVER) {                // (the way back held)
+                e->guard_recovering = false;
+                e->guard_recover_need = CW_GUARD_RECOVER;
+            } else if (!e->guard_probing && e->guard_good >= e->guard_probe_need && e->guard_ms_n >= CW_PROBE_SAMPLES && e->sweep_rate + 0.1 >= e->sweep_rate_top &&
+                       e->sweep_rate + 0.05 < CW_RATE_CEILING) {                                  // ---- a probe: one notch beyond the best rate known
+                e->guard_prev_mean = e->guard_ms_sum / e->guard_ms_n;
+                guard_set_rate(e, std::min(e->sweep_rate + 0.2, CW_RATE_CEILING));
+                e->guard_probing = true;
+                e->guard_probes++;
+                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probing %.1f TB/s (%.0f ns; %.4f ms so far)\n", e->sweep_rate, e->tune.period16 / 1.6, e->guard_prev_mean);
             }
         }
     }
-    e->guard_pending = true;
-    e->guard_period16 = e->tune.period16;
-    return e->guard_ev;
+    if (e->guard_head - e->guard_tail >= (unsigned)cw_engine::GUARD_RING) return nullptr;      // (every slot in flight: this step goes unsampled)
+    cw_engine::GuardSample &slot = e->guard_ring[e->guard_head++ % cw_engine::GUARD_RING];
+    slot.period16 = e->tune.period16;
+    return slot.ev;
 }
 
 extern "C" {
@@ -664,7 +715,7 @@ int cw_destroy(cw_engine *e)
     if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->res_stream) (void)hipStreamDestroy(e->res_stream);
     if (e->last_work) (void)hipEventDestroy(e->last_work);
-    for (hipEvent_t ev : e->guard_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &smp : e->guard_ring) for (hipEvent_t ev : smp.ev) if (ev) (void)hipEventDestroy(ev);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->host_allocs) (void)hipHostFree(p);
     delete e;

@@ -278,7 +278,8 @@ const char *cw_render_kernel_name(const cw_engine *e);
  * period16 / 16 ticks of the 100-MHz clock, 0: unclocked; period16_head: the period of a launch's first 64 jobs, period16_busy: of those after a
  * step on which envs finished --, and whether the engine
  * keeps look-ahead records (cw_config.auto_reset, device-resident outputs); `resident`: 1 if cw_step_resident can be used on this engine;
- * guard_slowdowns: how often the clock's guard has lowered the rate because sweeps stopped keeping their schedule (-1: no guard).
+ * guard_slowdowns: how often the clock's guard has lowered the rate because sweeps stopped keeping their schedule (-1: no guard; the guard also
+ * probes one notch UP when the best rate known has held for ~4 000 steps and keeps it if the sweeps get shorter: period16 may fall below cw_create's).
  * Only performance depends on any of it. */
 typedef struct cw_tuner_state {
     int32_t period16, period16_head, period16_busy, lookahead, resident, guard_slowdowns;

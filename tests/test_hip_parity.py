@@ -1261,9 +1261,45 @@ def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
             for k in ('observation', 'desired_goal', 'init_observation'):
                 assert torch.equal(e._observation()[k], dirty._observation()[k]), k
         else:
-            assert ts['guard_slowdowns'] <= 1 and p0 <= ts['period16'] <= 1.04 * p0, ts      # (at the edge one launch in four is late: three samples in a row can be)
+            # (at the edge one launch in ten is late, and a box in a worse state than at cw_create does not hold 7.7 TB/s: a notch or two, no more)
+            assert ts['guard_slowdowns'] <= 2 and 0.96 * p0 <= ts['period16'] <= 1.07 * p0, ts
         e.close()
     dirty.close()
+
+
+@pytest.mark.gpu
+def test_clock_guard_probes_find_a_faster_clock_that_pays(monkeypatch):
+    """Round 4's guard only ever lowered the rate; an engine created in a bad moment kept a clock under what the card takes for the rest of its life.  Round 5:
+    after enough samples on time at the best rate known the guard tries one notch more and keeps it only if the sweeps get SHORTER (sweep_guard_tick).
+    Started at 6.8 TB/s (617 ns) the clock must have climbed at least two notches within 30 000 steps, never beyond the write path's edge (7.7 TB/s), with no
+    slowdown counted; the frames are the dirty-cell engine's all the way."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, kw = 65536, dict(size=(21, 21), max_steps=300, seed=3)
+    acts = torch.randint(0, 6, (64, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(2))
+    monkeypatch.setenv('CW_TUNE_RATE_TBS', '6.8')
+    e = CraftingWorldVecEnv(N, obs_mode='pixels', **kw)
+    monkeypatch.delenv('CW_TUNE_RATE_TBS')
+    dirty = CraftingWorldVecEnv(N, obs_mode='pixels_dirty', **kw)
+    e.reset(); dirty.reset()
+    p0 = e.tuner_state()['period16']
+    assert 980 <= p0 <= 995                               # (617 ns in 1/16 ticks of 10 ns)
+    seen = []
+    for t in range(30000):                                 # (alone on the card: another engine's steps between its sweeps are a disturbance the guard gives way to)
+        e.step_async(acts[t % 64])
+        if t % 3000 == 2999:
+            torch.cuda.synchronize()
+            seen.append(e.tuner_state()['period16'])
+    for t in range(30000):
+        dirty.step_async(acts[t % 64])
+    for k in ('observation', 'desired_goal', 'init_observation'):
+        assert torch.equal(e._observation()[k], dirty._observation()[k]), k
+    assert torch.equal(e.counters, dirty.counters)
+    ts = e.tuner_state()
+    print('clock by 3000 steps:', seen, ts)
+    assert ts['period16'] <= p0 - 50, (seen, ts)           # two notches and more (6.8 -> 7.2 TB/s: 987 -> 932)
+    assert ts['period16'] >= 865 and ts['guard_slowdowns'] <= 1, (seen, ts)      # (7.7 TB/s is 872; a probe undone is not a slowdown)
+    assert all(b <= a + 30 for a, b in zip(seen, seen[1:])), seen                # (it climbs; a probe that does not pay is one notch -- ~25 units -- back)
+    e.close(); dirty.close()
 
 
 @pytest.mark.gpu
@@ -2292,11 +2328,11 @@ def test_soak_the_clock_and_its_guard_outside_the_bench_loop(monkeypatch):
     frac = N * (441 + 21168) / (p['ms_render_kernel'] * 1e-3) / 8e12
     print('soak: cw_create %s, after 4000 steps %s; last 1000 sweeps %.4f ms (median %.4f) = %.3f of the peak'
           % (t0, t1, p['ms_render_kernel'], p['ms_render_kernel_median'], frac))
-    assert 0 <= t1['guard_slowdowns'] <= 2, (t0, t1)
+    assert 0 <= t1['guard_slowdowns'] <= 4, (t0, t1)        # (down a notch, back after 64 samples on time, down again: every move counts)
     if t1['guard_slowdowns'] == 0:
-        assert t1['period16'] == t0['period16']
-    else:                                                   # (a notch is 0.2 TB/s, ~15 ns of a ~550-ns period: two notches at most)
-        assert t0['period16'] <= t1['period16'] <= t0['period16'] * 1.07, (t0, t1)
+        assert 0.93 * t0['period16'] <= t1['period16'] <= t0['period16']      # (cw_create's clock, or a faster one a probe found to pay)
+    else:                                                   # (a notch is 0.2 TB/s, ~15 ns of a ~550-ns period: three notches under cw_create's choice at most)
+        assert 0.97 * t0['period16'] <= t1['period16'] <= t0['period16'] * 1.09, (t0, t1)
     assert frac >= 0.84, (frac, p, t0, t1)
     assert int(env.counters[1]) > 4 * N                     # (every env finished ~16 episodes on the way: the steady state, not a quiet run)
     env.close(); other.close()
