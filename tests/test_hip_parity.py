@@ -1271,8 +1271,8 @@ def test_clock_guard_slows_a_saturated_sweep_down(monkeypatch):
 def test_clock_guard_probes_find_a_faster_clock_that_pays(monkeypatch):
     """Round 4's guard only ever lowered the rate; an engine created in a bad moment kept a clock under what the card takes for the rest of its life.  Round 5:
     after enough samples on time at the best rate known the guard tries one notch more and keeps it only if the sweeps get SHORTER (sweep_guard_tick).
-    Started at 6.8 TB/s (617 ns) the clock must have climbed at least two notches within 30 000 steps, never beyond the write path's edge (7.7 TB/s), with no
-    slowdown counted; the frames are the dirty-cell engine's all the way."""
+    Started at 6.8 TB/s (617 ns) the clock must have climbed within 30 000 steps (three or four notches on every box so far; one is the test's floor: how far it
+    pays is the card's state), never beyond the write path's edge (7.7 TB/s), with one slowdown counted at most; the frames are the dirty-cell engine's all the way."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     N, kw = 65536, dict(size=(21, 21), max_steps=300, seed=3)
     acts = torch.randint(0, 6, (64, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(2))
@@ -1296,7 +1296,7 @@ def test_clock_guard_probes_find_a_faster_clock_that_pays(monkeypatch):
     assert torch.equal(e.counters, dirty.counters)
     ts = e.tuner_state()
     print('clock by 3000 steps:', seen, ts)
-    assert ts['period16'] <= p0 - 50, (seen, ts)           # two notches and more (6.8 -> 7.2 TB/s: 987 -> 932)
+    assert ts['period16'] <= p0 - 20, (seen, ts)           # a notch and more (6.8 -> 7.0 TB/s: 987 -> 959; measured 6.8 -> 7.4 / 7.6: 907 / 883)
     assert ts['period16'] >= 865 and ts['guard_slowdowns'] <= 1, (seen, ts)      # (7.7 TB/s is 872; a probe undone is not a slowdown)
     assert all(b <= a + 30 for a, b in zip(seen, seen[1:])), seen                # (it climbs; a probe that does not pay is one notch -- ~25 units -- back)
     e.close(); dirty.close()
@@ -2298,7 +2298,8 @@ def test_soak_the_clock_and_its_guard_outside_the_bench_loop(monkeypatch):
     """The sweep's clock (7.7 TB/s and its two heads), the busy threshold and the guard were found in bench.py's back-to-back loop on three boxes of one pool
     (DESIGN 4.3).  Here they run where they were NOT tuned: 5 000 steps of the headline batch with the episode phases spread out (~220 envs finish on every
     step), a second engine on the same card taking a step of its own every 50th step, the host never waiting.  The guard may give way (twice at most) but
-    must not run away, where it did not move the clock is cw_create's, and over the last 1 000 steps the sweep must still write at >= 0.84 of the HBM peak."""
+    must not run away, where it did not move the clock is cw_create's, and over the last 1 000 steps the sweep must still write at >= 0.80 of the HBM peak
+    (measured 0.865-0.871: the floor sits 7-8 % under, like test_perf_floors_of_the_sweep's)."""
     from gym_craftingworld_amd import CraftingWorldVecEnv
     for k in list(os.environ):
         if k.startswith('CW_TUNE_'):
@@ -2333,7 +2334,7 @@ def test_soak_the_clock_and_its_guard_outside_the_bench_loop(monkeypatch):
         assert 0.93 * t0['period16'] <= t1['period16'] <= t0['period16']      # (cw_create's clock, or a faster one a probe found to pay)
     else:                                                   # (a notch is 0.2 TB/s, ~15 ns of a ~550-ns period: three notches under cw_create's choice at most)
         assert 0.97 * t0['period16'] <= t1['period16'] <= t0['period16'] * 1.09, (t0, t1)
-    assert frac >= 0.84, (frac, p, t0, t1)
+    assert frac >= 0.80, (frac, p, t0, t1)
     assert int(env.counters[1]) > 4 * N                     # (every env finished ~16 episodes on the way: the steady state, not a quiet run)
     env.close(); other.close()
 
