@@ -10,7 +10,7 @@
 Workload = BASELINE.json configs[2] (the config the metric is quoted on): 65 536 envs per GPU,
 21x21 grid, full-frame 4x4-pixel-cell uint8 observation every step, auto-reset, uniform random
 actions, max_steps=300.  One "step" = one cw_step over the whole batch: cw_step_fused_kernel (every env's step; a finished env takes
-the look-ahead record of its next episode and its wave paints the two frames a reset changes), then cw_render_pieces_kernel, the clocked
+the look-ahead record of its next episode and its workgroup's four waves paint the two frames a reset changes), then cw_render_pieces_kernel, the clocked
 sweep that writes the whole observation array; every max_steps/4-th step cw_refill_kernel ahead of them.  Envs shard across
 ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
 are the timing barrier and the max-over-ranks of the elapsed time.
@@ -71,9 +71,9 @@ def host_cpu_share():
 
 def cpu_baseline(size, max_steps, seconds=12.0, spare_cores=0):
     """Time the CPU oracle (port of the reference's step()/reset()) on this host's CPU share: n envs x T steps with
-    auto-reset, sized to ~`seconds` of wall time.  Two rates: `value` with the reference's own observation strategy
-    (render_edit: the persistent frame, <= 2 cells repainted per step) and `full_frame_value` with the whole frame
-    rendered after every step -- the work the GPU headline configuration does.  spare_cores: threads left to the caller
+    auto-reset, sized to ~`seconds` of wall time.  Two rates: `value` with the whole frame rendered after every step -- the work
+    the GPU headline configuration does -- and `dirty_cell_value` with the reference's own observation strategy (render_edit: the
+    persistent frame, <= 2 cells repainted per step); beside them `single_env_one_core`, BASELINE configs[0] on one core.  spare_cores: threads left to the caller
     (bench.py runs this beside a GPU soak leg whose launching thread needs one: `cores` reports what the oracle used)."""
     from oracle import OracleBatch
     cores = max(1, host_cpu_share() - spare_cores)
@@ -750,7 +750,7 @@ def main():
                                    '163 000 dirty lines against 21 000 in the state-only mode, 129 000 of them partial (32-byte requests with byte masks, '
                                    'TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B) -- the cost follows the number of LINES touched (~3 per move: two pixel rows of two '
                                    'cells), not requests or bytes: the same stores into two lines per env cost a third, whole-line or nontemporal stores '
-                                   'cost more (profiles/r05_dirty.txt)') if mode == 'pixels_dirty' else
+                                   'cost more (profiles/r05_experiments.txt B)') if mode == 'pixels_dirty' else
                                   ('one kernel launch: 3.6 us at its shortest, 6.2 us on average -- dispatch, one round trip to HBM for 48 bytes per env, '
                                    'the write-back of 21 000 lines; 0.6 TB/s of algorithmic bytes is what that leaves')}
             block = acts[:k2].contiguous()
