@@ -99,7 +99,8 @@ class CraftingWorldVecEnv:
                  seed_style='numpy', auto_reset=True, task_menus=None, env_menu=None,
                  keep_terminal_obs=False, raster='ray', host_outputs=False):
         if store_gif:
-            raise NotImplementedError('the GIF episode recorder (ray.py:565-597) is host-side debug I/O, out of scope')
+            raise NotImplementedError('the GIF episode recorder (ray.py:565-597) records ONE env: use the N=1 classes (env.py, recorder.py) or '
+                                      'recorder.EpisodeRecorder on a row of this batch')
         w, h = size
         if w != h:
             raise ValueError('non-square grids raise IndexError in the reference (SURVEY.md §8a); rejected')
