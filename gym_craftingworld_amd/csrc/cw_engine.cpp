@@ -107,8 +107,9 @@ struct cw_engine {
     int guard_late = 0, guard_good = 0, guard_slowdowns = 0;
     double sweep_rate_top = 0;          // the best rate known to hold: cw_create's choice, raised by a probe that paid (sweep_guard_tick)
     double guard_ms_sum = 0, guard_prev_mean = 0;   // sweep times sampled at the current rate; their mean at the rate a probe left
+    double guard_ref_ms = 0, guard_ref_prev = 0;    // what the current rate delivered when a trial ACCEPTED it (its yardstick if that is more than its schedule); the one of the rate a trial left
     int guard_ms_n = 0, guard_probe_need = 0, guard_probes = 0, guard_recover_need = 64;
-    bool guard_probing = false, guard_recovering = false;   // the last move was a probe / a step back towards the best rate known, not yet confirmed
+    bool guard_probing = false, guard_recovering = false;   // a TRIAL is running: one notch up, its verdict due after CW_PROBE_SAMPLES samples / ... and it is a step back towards the best rate known, not beyond it
     int prof_cap = 0, prof_n = 0;
     // the engine's OWN work: the streams it was handed since its last wait (at most 4 are remembered) and a private stream for the synchronous
     // entry points' copies and kernels (cw_seed_*, cw_get_mt, cw_get/set_state, checkpoints): none of them waits for anybody else's work
@@ -420,14 +421,17 @@ static int calibrate_sweep(cw_engine *e)
 // (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + the busy head + what
 // a launch costs beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 10-16 % launch after launch; at
 // the edge (7.7 TB/s) one launch in ten is 7-12 % late and the rest on time.  Three samples in a row more than 6 % late: the rate goes down by
-// 0.2 TB/s.  It comes back a notch after CW_GUARD_RECOVER samples in a row on time (~4 000 steps), up to the best rate known to hold: a disturbance
-// that has passed -- another process on the card, a thermal excursion -- does not slow the engine for the rest of its life, and a clock that moves
-// once in thousands of steps does not hunt.
-// PROBES (round 5).  cw_create's choice is a measurement of one moment: an engine created while the card was in a worse state settles a notch or two
-// under what the card takes an hour later (7.4 instead of 7.7 TB/s: 2.7 % of every sweep), and round 4's guard only ever went down.  Now, after
-// guard_probe_need samples in a row on time at the best rate known, the guard tries ONE notch more (never beyond CW_RATE_CEILING, the write path's edge)
-// and keeps it only if it PAYS: the mean of CW_PROBE_SAMPLES sweeps at the new rate must be under the mean at the old one -- "on time" is not enough, a
-// clock a little too fast is on time and slower.  A probe that does not pay is undone and the next one waits twice as long.
+// 0.2 TB/s (a SLOWDOWN: the only move that is not a trial).
+// TRIALS (round 5).  cw_create's choice is a measurement of one moment: an engine created while the card was in a worse state settles a notch or two
+// under what the card takes an hour later (7.4 instead of 7.7 TB/s: 2.7 % of every sweep), and round 4's guard only ever went down -- or came back by
+// its schedule alone.  Now every move UP is a trial: after enough samples on time (guard_recover_need below the best rate known, guard_probe_need at it:
+// a PROBE, never beyond CW_RATE_CEILING, the write path's edge) the guard tries ONE notch more and keeps it only if it PAYS -- the mean of
+// CW_PROBE_SAMPLES sweeps at the new rate must be under the mean at the old one; "on time" is not enough (a clock a little too fast is on time and
+// slower) and not needed either: with something else between the sweeps (another engine's step kernel: profiles/r05_experiments.txt M) every sweep is a
+// constant late, a rate judged by its schedule alone comes to rest a notch or two under the one with the shortest sweeps, and so a rate a trial has
+// accepted is from then on measured against what it delivered then (guard_ref_ms).  A trial that does not pay is undone and the next one of its kind
+// waits twice as long: a disturbance that has passed -- another process on the card, a thermal excursion -- does not slow the engine for the rest of
+// its life, and a clock that moves once in thousands of steps does not hunt.
 // -> the event array for this step's launch, or null.
 enum { CW_GUARD_EVERY = 64, CW_GUARD_RECOVER = 64, CW_PROBE_SAMPLES = 32, CW_PROBE_NEED_MAX = 2048 };
 static const double CW_RATE_CEILING = 7.7;
@@ -438,6 +442,7 @@ static void guard_set_rate(cw_engine *e, double rate)
     e->guard_ms_sum = 0;
     e->guard_ms_n = 0;
     e->guard_good = e->guard_late = 0;
+    e->guard_ref_ms = 0;
 }
 static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
 {
@@ -452,50 +457,50 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
         if (hipEventElapsedTime(&ms, smp.ev[4], smp.ev[5]) == hipSuccess && ms > 0.f && smp.period16 == e->tune.period16) {      // (a sample of another rate says nothing)
             const double scheduled = (e->sweep_jobs * (e->tune.period16 / 1.6) + CW_HEAD_JOBS_HOST * ((e->tune.period16_busy - e->tune.period16) / 1.6)) * 1e-6 +
                                      e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
-            const bool late = ms > 1.06 * scheduled;
+            // the yardstick: the schedule, or what this rate delivered when a trial accepted it (a loop with something else between the sweeps -- another
+            // engine's step kernel -- runs every sweep a constant late, and the best clock is the one with the shortest sweeps, not the one on schedule).
+            // While a trial runs only a sweep FAR off ends it early: its verdict is the mean.
+            const double ref = std::max(scheduled, e->guard_ref_ms);
+            const bool late = ms > (e->guard_probing ? 1.15 : 1.06) * ref;
             e->guard_late = late ? e->guard_late + 1 : 0;
             // ("in a row" for the way up means MOSTLY: at the edge one launch in ten is late by itself, and 64 strictly in a row would never come)
             e->guard_good = late ? std::max(0, e->guard_good - 8) : e->guard_good + 1;
+            if (e->guard_ms_n >= 128) { e->guard_ms_sum *= 0.5; e->guard_ms_n /= 2; }             // (the mean is of the last ~100 samples, not of the rate's whole past)
             e->guard_ms_sum += ms;
             e->guard_ms_n++;
-            if (e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {                     // ---- not keeping its schedule: a notch down
-                const bool was_probe = e->guard_probing;
+            const bool verdict_due = e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES;
+            const double mean = e->guard_ms_sum / e->guard_ms_n;
+            if (e->guard_probing && (e->guard_late >= 3 || (verdict_due && mean >= 0.998 * e->guard_prev_mean))) {      // ---- a trial that does not pay: undone
+                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %s %.1f TB/s does not pay (%.4f ms against %.4f%s): undone\n", e->guard_recovering ? "the way back to" : "probe",
+                                     e->sweep_rate, mean, e->guard_prev_mean, verdict_due ? "" : "; three sweeps far off");
+                const double ref_prev = e->guard_ref_prev;
                 guard_set_rate(e, e->sweep_rate - 0.2);
-                if (was_probe) { e->guard_probing = false; e->guard_probe_need = std::min(2 * e->guard_probe_need, (int)CW_PROBE_NEED_MAX); }
-                else e->guard_slowdowns++;
-                if (e->guard_recovering) {           // the way back did not hold: the next attempt waits twice as long (no see-saw between two notches)
-                    e->guard_recovering = false;
-                    e->guard_recover_need = std::min(2 * e->guard_recover_need, (int)CW_PROBE_NEED_MAX);
-                }
+                e->guard_ref_ms = ref_prev;
+                int &need = e->guard_recovering ? e->guard_recover_need : e->guard_probe_need;     // the next attempt of its kind waits twice as long (no see-saw between two notches)
+                need = std::min(2 * need, (int)CW_PROBE_NEED_MAX);
+                e->guard_probing = e->guard_recovering = false;
+            } else if (verdict_due) {                                                             // ---- a trial that PAYS: kept, and its mean is this rate's yardstick
+                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %s %.1f TB/s pays (%.4f ms against %.4f): kept\n", e->guard_recovering ? "the way back to" : "probe", e->sweep_rate, mean, e->guard_prev_mean);
+                if (e->guard_recovering) e->guard_recover_need = CW_GUARD_RECOVER;
+                else { e->sweep_rate_top = e->sweep_rate; e->guard_probe_need = CW_GUARD_RECOVER / 4; }      // (the next notch is tried sooner)
+                e->guard_ref_ms = mean;
+                e->guard_probing = e->guard_recovering = false;
+            } else if (!e->guard_probing && e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {      // ---- not keeping its schedule: a notch down
+                guard_set_rate(e, e->sweep_rate - 0.2);
+                e->guard_slowdowns++;
                 if (verbose)
-                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f scheduled, three samples in a row -> %.1f TB/s (%.0f ns)%s\n", ms, scheduled,
-                            e->sweep_rate, e->tune.period16 / 1.6, was_probe ? " (a probe undone)" : "");
-            } else if (e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES) {                   // ---- a probe's verdict: does the faster clock PAY?
-                const double mean = e->guard_ms_sum / e->guard_ms_n;
-                e->guard_probing = false;
-                if (mean < 0.998 * e->guard_prev_mean) {
-                    e->sweep_rate_top = e->sweep_rate;
-                    e->guard_probe_need = CW_GUARD_RECOVER / 4;                                  // (it paid: the next notch is tried sooner)
-                    if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probe %.1f TB/s pays (%.4f ms against %.4f): kept\n", e->sweep_rate, mean, e->guard_prev_mean);
-                } else {
-                    if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probe %.1f TB/s does not pay (%.4f ms against %.4f): undone\n", e->sweep_rate, mean, e->guard_prev_mean);
-                    guard_set_rate(e, e->sweep_rate - 0.2);
-                    e->guard_probe_need = std::min(2 * e->guard_probe_need, (int)CW_PROBE_NEED_MAX);
-                }
-            } else if (!e->guard_probing && e->guard_good >= e->guard_recover_need && e->sweep_rate + 0.1 < e->sweep_rate_top) {      // ---- back towards the best rate known
-                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %d samples on time -> back to %.1f TB/s\n", e->guard_good, e->sweep_rate + 0.2);
-                guard_set_rate(e, e->sweep_rate + 0.2);
-                e->guard_recovering = true;
-            } else if (e->guard_recovering && e->guard_good >= CW_GUARD_RECOVER) {                // (the way back held)
-                e->guard_recovering = false;
-                e->guard_recover_need = CW_GUARD_RECOVER;
-            } else if (!e->guard_probing && e->guard_good >= e->guard_probe_need && e->guard_ms_n >= CW_PROBE_SAMPLES && e->sweep_rate + 0.1 >= e->sweep_rate_top &&
-                       e->sweep_rate + 0.05 < CW_RATE_CEILING) {                                  // ---- a probe: one notch beyond the best rate known
-                e->guard_prev_mean = e->guard_ms_sum / e->guard_ms_n;
+                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f, three samples in a row -> %.1f TB/s (%.0f ns)\n", ms, ref, e->sweep_rate, e->tune.period16 / 1.6);
+            } else if (!e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES && e->sweep_rate + 0.05 < CW_RATE_CEILING &&
+                       e->guard_good >= (e->sweep_rate + 0.1 < e->sweep_rate_top ? e->guard_recover_need : e->guard_probe_need)) {
+                // ---- a trial: one notch up -- back towards the best rate known after a slowdown, or beyond it (a probe)
+                e->guard_recovering = e->sweep_rate + 0.1 < e->sweep_rate_top;
+                e->guard_prev_mean = mean;
+                e->guard_ref_prev = e->guard_ref_ms;
                 guard_set_rate(e, std::min(e->sweep_rate + 0.2, CW_RATE_CEILING));
                 e->guard_probing = true;
-                e->guard_probes++;
-                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: probing %.1f TB/s (%.0f ns; %.4f ms so far)\n", e->sweep_rate, e->tune.period16 / 1.6, e->guard_prev_mean);
+                if (!e->guard_recovering) e->guard_probes++;
+                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: trying %.1f TB/s (%.0f ns; %.4f ms so far)%s\n", e->sweep_rate, e->tune.period16 / 1.6, e->guard_prev_mean,
+                                     e->guard_recovering ? " on the way back" : "");
             }
         }
     }
