@@ -459,8 +459,8 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
                                      e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
             // the yardstick: the schedule, or what this rate delivered when a trial accepted it (a loop with something else between the sweeps -- another
             // engine's step kernel -- runs every sweep a constant late, and the best clock is the one with the shortest sweeps, not the one on schedule).
-            // While a trial runs only a sweep FAR off ends it early: its verdict is the mean.
-            const double ref = std::max(scheduled, e->guard_ref_ms);
+            // While a trial runs only sweeps FAR off -- 15 % over the schedule AND over what the rate it left delivered -- end it early: its verdict is the mean.
+            const double ref = std::max(scheduled, e->guard_probing ? e->guard_prev_mean : e->guard_ref_ms);
             const bool late = ms > (e->guard_probing ? 1.15 : 1.06) * ref;
             e->guard_late = late ? e->guard_late + 1 : 0;
             // ("in a row" for the way up means MOSTLY: at the edge one launch in ten is late by itself, and 64 strictly in a row would never come)
