@@ -315,6 +315,41 @@ class CraftingWorldEnv:
     def compute_reward(self, achieved_goal, desired_goal, info=None):
         return self._vec.compute_reward(achieved_goal, desired_goal, info)
 
+    # -- the reference class's small public helpers (host convenience; the per-step values come from the kernels)
+    def compute_reward_equal(self, achieved_goal=None, desired_goal=None, info=None):
+        """ray.py:757-761: MAX_STEPS iff the two goal vectors are equal position by position, else -1 (whatever reward_style the env was built with)."""
+        return self.MAX_STEPS if self.short_circuit_check(desired_goal, achieved_goal, 4) else -1
+
+    def compute_reward_subset(self, achieved_goal=None, desired_goal=None, info=None):
+        """ray.py:763-767: MAX_STEPS iff the largest element of desired - achieved is 0 (nothing desired is missing AND some position is equal), else -1."""
+        d = np.asarray(desired_goal).astype(np.int64).reshape(-1)
+        a = np.asarray(achieved_goal).astype(np.int64).reshape(-1)
+        return self.MAX_STEPS if int((d - a).max()) == 0 else -1
+
+    @staticmethod
+    def short_circuit_check(a, b, n):
+        """ray.py:747-755 compares a and b in n chunks and a tail: together they cover every position, so this is plain equality of the two vectors."""
+        a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+        return a.shape == b.shape and bool((a == b).all())
+
+    def one_hot(self, obj=None, agent=False, holding=None):
+        """ray.py:784-792: one cell's 12-channel row as a list -- channel obj (0..7, OBJECTS order), channel 8 for the agent, channel 9 + holding."""
+        row = [0] * 12
+        if obj is not None:
+            row[obj] = 1
+        if agent:
+            row[8] = 1
+        if holding is not None:
+            row[9 + holding] = 1
+        return row
+
+    @staticmethod
+    def translate_one_hot(one_hot_row):
+        """ray.py:794-799, the inverse: -> (object index or None, the agent channel's value, held item's index 0..2 or None)."""
+        row = np.asarray(one_hot_row)
+        objs, held = row[:8], row[9:]
+        return (int(objs.argmax()) if objs.any() else None), row[8], (int(held.argmax()) if held.any() else None)
+
     def close(self):
         self._vec.close()
 

@@ -132,5 +132,28 @@ def main(n_seeds):
         total_steps, total_resets, successes, len([t for t in todo if not only or t[1] in only]), n_seeds, time.time() - t0))
 
 
+def check_facade_helpers():
+    """The N=1 facade's host helpers (compute_reward_equal / _subset, short_circuit_check, one_hot, translate_one_hot) against the reference's own
+    methods (ray.py:747-767, 784-799).  They need no engine: the class is used without its constructor."""
+    import itertools
+    from gym_craftingworld_amd.env import CraftingWorldEnv as E
+    ref = make_ref_env(import_reference()['ray'], np.random.RandomState(1), size=(5, 5), max_steps=40)
+    mine = E.__new__(E)
+    mine.MAX_STEPS = ref.MAX_STEPS
+    rng = np.random.RandomState(0)
+    vecs = [np.zeros(9, int), np.ones(9, int)] + [rng.randint(0, 2, 9) for _ in range(60)]
+    for a, d in itertools.product(vecs, vecs):
+        assert mine.compute_reward_equal(a, d) == ref.compute_reward_equal(a, d)
+        assert mine.compute_reward_subset(a, d) == ref.compute_reward_subset(a, d)
+        assert E.short_circuit_check(d, a, 4) == ref.short_circuit_check(d, a, 4)
+    for obj, agent, holding in itertools.product([None] + list(range(8)), [False, True], [None, 0, 1, 2]):
+        assert mine.one_hot(obj, agent, holding) == ref.one_hot(obj, agent, holding)
+        row = np.array(ref.one_hot(obj, agent, holding))
+        r1, r2 = E.translate_one_hot(row), type(ref).translate_one_hot(row)
+        assert (r1[0], int(r1[1]), r1[2]) == (r2[0], int(r2[1]), r2[2]), (r1, r2)
+    print('facade helpers == reference on %d goal-vector pairs and 72 one-hot rows' % (len(vecs) ** 2))
+
+
 if __name__ == '__main__':
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 12)
+    check_facade_helpers()
