@@ -6,7 +6,8 @@ gym.vector.VectorEnv-shaped surface for N envs, hand-written HIP kernels underne
 (csrc/, C ABI in include/craftingworld.h).  Importing the package needs neither a GPU nor the
 built library; constructing an env needs both (there is no CPU fallback).
 """
-from .vec_env import ACTION_NAMES, OBJECTS, PICKUPABLE, TASK_LIST, CraftingWorldVecEnv  # noqa: F401
+from .vec_env import (ACTION_NAMES, COLORS, COLORS_H, COLORS_N, DOWN, DROP, LEFT, MAX_STEPS, OBJECTS, PICKUP, PICKUPABLE, RIGHT, STATE_H, STATE_W,  # noqa: F401
+                      TASK_LIST, UP, CraftingWorldVecEnv)
 from .env import CraftingWorldEnv, CraftingWorldEnvAltObs, CraftingWorldEnvFlat, CraftingWorldEnvOneHot  # noqa: F401
 from ._lib import CraftingWorldError  # noqa: F401
 from .adapters import GymnasiumVecAdapter, MultiDeviceVecEnv  # noqa: F401

@@ -25,6 +25,14 @@ TASK_LIST = ['MakeBread', 'EatBread', 'BuildHouse', 'ChopTree', 'ChopRock', 'GoT
 OBJECTS = ['sticks', 'axe', 'hammer', 'rock', 'tree', 'bread', 'house', 'wheat']   # ray.py:21
 PICKUPABLE = ['sticks', 'axe', 'hammer']                       # ray.py:20
 ACTION_NAMES = ['up', 'right', 'down', 'left', 'pickup', 'drop']   # ray.py:130-131
+UP, RIGHT, DOWN, LEFT, PICKUP, DROP = range(6)                  # action ids (ray.py:15-18 names the four moves; 4 / 5 are pickup / drop, ray.py:130-131)
+# the palette (ray.py:26-31), as data for callers that decode frames: an object's 4x4 tile, the same with index 0 = the empty floor, and what the
+# reference SUBTRACTS from the agent's white centre for a held item (255 - its colour).  The kernels carry their own copy (csrc/cw_kernels.hip).
+COLORS = [(110, 69, 39), (255, 105, 180), (100, 100, 200), (100, 100, 100), (0, 128, 0), (205, 133, 63), (197, 91, 97), (240, 230, 140)]
+COLORS_N = [(0, 0, 0)] + COLORS
+COLORS_H = [tuple(255 - c for c in COLORS[k]) for k in range(3)]
+STATE_W = STATE_H = 21                                         # ray.py:43-44: the default grid
+MAX_STEPS = 300                                                # ray.py:46
 
 _OBS_MODES = {'state': L.CW_OBS_STATE, 'pixels': L.CW_OBS_PIXELS_FULL, 'pixels_dirty': L.CW_OBS_PIXELS_DIRTY}
 _ACT_DTYPES = {torch.int32: L.CW_ACT_I32, torch.int64: L.CW_ACT_I64, torch.uint8: L.CW_ACT_U8}

@@ -338,6 +338,25 @@ def test_facade_helper_methods_follow_the_reference_rules():
         assert (o, bool(ag), h) == (obj, agent, holding)
 
 
+def test_module_constants_are_the_reference_palette_and_ids():
+    """The package's module-level constants (ray.py:15-46: action ids, OBJECTS, the palette, the default grid) against the oracle's render: an object's
+    tile is COLORS[k] = COLORS_N[k + 1], the floor COLORS_N[0], the agent's centre white with the held item's colour on the lower row = 255 - COLORS_H."""
+    import gym_craftingworld_amd as cw
+    from oracle.oracle import render
+    assert (cw.UP, cw.RIGHT, cw.DOWN, cw.LEFT, cw.PICKUP, cw.DROP) == (0, 1, 2, 3, 4, 5) and cw.ACTION_NAMES[cw.DOWN] == 'down'
+    assert (cw.STATE_W, cw.STATE_H, cw.MAX_STEPS) == (21, 21, 300) and len(cw.COLORS) == len(cw.OBJECTS) == 8 and cw.PICKUPABLE == cw.OBJECTS[:3]
+    S = 5
+    for k in range(8):
+        g = np.zeros((S, S), np.uint8)
+        g[1, 2] = k + 1
+        img = render(S, g, (4, 4), 0)
+        assert tuple(int(x) for x in img[4, 8]) == cw.COLORS[k] == cw.COLORS_N[k + 1] and tuple(int(x) for x in img[0, 0]) == cw.COLORS_N[0]
+    for h in (1, 2, 3):
+        img = render(S, np.zeros((S, S), np.uint8), (2, 2), h)
+        assert tuple(int(x) for x in img[9, 9]) == (255, 255, 255)
+        assert tuple(255 - int(x) for x in img[10, 9]) == cw.COLORS_H[h - 1] and tuple(int(x) for x in img[10, 10]) == cw.COLORS[h - 1]
+
+
 def test_docs_name_only_kernels_that_exist():
     """The public header, bench.py and the package's docstrings name kernels a rocprofv3 trace of a run would list: every cw_*_kernel they
     mention must be a __global__ of csrc/cw_kernels.hip (round 4 left names of kernels that were gone)."""
