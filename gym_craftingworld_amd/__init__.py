@@ -9,6 +9,7 @@ built library; constructing an env needs both (there is no CPU fallback).
 from .vec_env import (ACTION_NAMES, COLORS, COLORS_H, COLORS_N, DOWN, DROP, LEFT, MAX_STEPS, OBJECTS, PICKUP, PICKUPABLE, RIGHT, STATE_H, STATE_W,  # noqa: F401
                       TASK_LIST, UP, CraftingWorldVecEnv)
 from .env import CraftingWorldEnv, CraftingWorldEnvAltObs, CraftingWorldEnvFlat, CraftingWorldEnvOneHot  # noqa: F401
+CraftingWorldEnvRay = CraftingWorldEnv          # the reference's name for it (envs/__init__.py:1)
 from ._lib import CraftingWorldError  # noqa: F401
 from .adapters import GymnasiumVecAdapter, MultiDeviceVecEnv  # noqa: F401
 

@@ -308,6 +308,10 @@ def test_facades_declare_the_reference_attributes():
         assert hasattr(envmod.CraftingWorldEnv, n) or ('self.%s = ' % n) in src or ('self.%s, ' % n) in src or (', self.%s = ' % n) in src, n
     for cls in (envmod.CraftingWorldEnvFlat, envmod.CraftingWorldEnvOneHot, envmod.CraftingWorldEnvAltObs):
         assert issubclass(cls, envmod.CraftingWorldEnv)
+    import gym_craftingworld_amd as cw
+    import gym_craftingworld_amd.envs as refpath                         # the reference's import path for its four classes (envs/__init__.py:1-4)
+    assert refpath.CraftingWorldEnvRay is cw.CraftingWorldEnvRay is envmod.CraftingWorldEnv and refpath.CraftingWorldEnvFlat is envmod.CraftingWorldEnvFlat
+    assert refpath.CraftingWorldEnvOneHot is envmod.CraftingWorldEnvOneHot and refpath.CraftingWorldEnvAltObs is envmod.CraftingWorldEnvAltObs
     for prop in ('agent_pos', 'obs_one_hot', 'INIT_OBS_VECTOR', 'observation_vector', 'fixed_state_list', 'np_random'):
         assert isinstance(getattr(envmod.CraftingWorldEnv, prop), property), prop
 
