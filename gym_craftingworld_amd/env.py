@@ -27,6 +27,8 @@ from .vec_env import ACTION_NAMES, TASK_LIST, CraftingWorldVecEnv
 
 class CraftingWorldEnv:
     metadata = {'render.modes': ['human', 'Non']}
+    reward_range = (-float('inf'), float('inf'))       # gym.Env's class attributes (the reference inherits them from gym.GoalEnv, ray.py:53): wrappers read them
+    spec = None
     _default_size = (21, 21)
     _default_max_steps = 300
 
@@ -352,6 +354,21 @@ class CraftingWorldEnv:
 
     def close(self):
         self._vec.close()
+
+    # gym.Env's protocol beside step / reset / render / close / seed (the reference gets it from its base class)
+    @property
+    def unwrapped(self):
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __str__(self):
+        return '<%s instance>' % type(self).__name__
 
 
 class CraftingWorldEnvFlat(CraftingWorldEnv):

@@ -303,7 +303,7 @@ def test_facades_declare_the_reference_attributes():
              'INIT_OBS_VECTOR', 'step_num', 'ep_no', 'MAX_STEPS', 'STATE_W', 'STATE_H', 'observation_vector', 'observation_vector_space',
              'fixed_state_list', 'generate_fixed_states', 'obs_image', 'INIT_OBS', 'desired_goal', 'observation', 'ACTIONS', 'task_list',
              'selected_tasks', 'number_of_tasks', 'stacking', 'fixed_init_state', 'store_gif', 'render_save_rate', 'seed', 'reset', 'step', 'render',
-             'compute_reward', 'allow_gif_storage', 'compute_reward_equal', 'compute_reward_subset', 'short_circuit_check', 'one_hot', 'translate_one_hot']
+             'compute_reward', 'allow_gif_storage', 'metadata', 'reward_range', 'spec', 'unwrapped', 'close', '__enter__', '__exit__', 'compute_reward_equal', 'compute_reward_subset', 'short_circuit_check', 'one_hot', 'translate_one_hot']
     for n in names:
         assert hasattr(envmod.CraftingWorldEnv, n) or ('self.%s = ' % n) in src or ('self.%s, ' % n) in src or (', self.%s = ' % n) in src, n
     for cls in (envmod.CraftingWorldEnvFlat, envmod.CraftingWorldEnvOneHot, envmod.CraftingWorldEnvAltObs):
