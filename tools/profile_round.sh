@@ -2,7 +2,7 @@
 # GPU box only: the round's evidence set -> gpurun_out/round/ (copy what is judged into profiles/).
 #   1. bench.py default run (value, roofline from HIP events, cpu_baseline)
 #   2. rocprofv3 --kernel-trace --stats of bench.py --quick for every BASELINE shape: headline, phases spread out, 32x32, 131 072 mixed menus, AltObs
-#   3. PMC traffic passes + calibration (tools/profile_pmc.sh) for the headline, the spread-out phases and 32x32
+#   3. PMC traffic passes + calibration (tools/profile_pmc.sh) for the headline, the spread-out phases, 32x32, AltObs and 131 072 mixed menus
 #   4. (consumer) rocprofv3 --kernel-trace --stats with a reader of every observation byte between two steps (bench.py --consumer reduce32)
 #   bash tools/profile_round.sh [steps: bench | stats | pmc, default all]
 set -e -o pipefail
@@ -28,7 +28,7 @@ consumer)
   cp $(ls $OUT/rocprof_consumer/p_kernel_stats.csv $OUT/rocprof_consumer/*/p_kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats_consumer.csv
   echo "== consumer"; cut -c1-150 $OUT/kernel_stats_consumer.csv | head -5;;
 pmc)
-  for tag in headline desync 32x32; do
+  for tag in headline desync 32x32 alt 131072_mixed; do
     bash tools/profile_pmc.sh $tag $(shape_args $tag) > $OUT/pmc_$tag.log 2>&1 || echo "pmc $tag failed"
     cp $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/summary.json $OUT/pmc_traffic_$tag.json
     python -c "import json;d=json.load(open('$OUT/pmc_traffic_$tag.json'));print('$tag', d.get('hbm_bytes_per_launch'), d.get('algorithmic_bytes_per_launch'), d.get('traffic_over_algorithmic'))"
