@@ -335,6 +335,9 @@ def main():
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
     if args.rehearse_on_one_gpu:
         local_rank = 0
+    masked = [v for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES') if os.environ.get(v)]
+    if world > 1 and masked and torch.cuda.device_count() == 1:
+        local_rank = 0                                   # (a launcher that hands every rank ITS GPU through a *_VISIBLE_DEVICES mask: that GPU is device 0 here)
     if local_rank >= torch.cuda.device_count():
         raise SystemExit('rank %d needs GPU %d but only %d are visible (use --rehearse-on-one-gpu with --dist-backend gloo '
                          'to rehearse the multi-rank flow on one GPU)' % (rank, local_rank, torch.cuda.device_count()))
