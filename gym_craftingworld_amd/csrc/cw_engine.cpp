@@ -790,6 +790,10 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
         for (size_t i = 0; i < N; i++)
             if (misc[i * 4 + 2] >> 31) cwh_mt_rewind(keys + i * CW_MT_N, &pos[i], misc[i * 4 + 3]);
     }
+    // numpy's own form of a stream that stands at a generation's end: it regenerates lazily, so after the 624th draw RandomState.get_state() shows
+    // (the generation just used up, 624), never (the next one, 0) -- the engine's consume-and-replace form holds the next one already
+    for (size_t i = 0; i < N; i++)
+        if (pos[i] == 0) { cwh_mt_untwist(keys + i * CW_MT_N); pos[i] = CW_MT_N; }
     return CW_OK;
 }
 

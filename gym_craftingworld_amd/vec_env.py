@@ -266,6 +266,7 @@ class CraftingWorldVecEnv:
         else:
             base = seeding.create_seed(seed)
             seeds = [(base + i) for i in range(self.num_envs)]
+        self._seeds = seeds
         if self.seed_style == 'gym':
             keys = np.empty((self.num_envs, L.CW_MT_N), dtype=np.uint32)
             pos = np.empty(self.num_envs, dtype=np.int32)

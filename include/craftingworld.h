@@ -150,7 +150,8 @@ int cw_destroy(cw_engine *e);
  * cw_seed_mt injects numpy RandomState states: keys[N][624], pos[N] (RandomState.get_state()[1:3]).
  * cw_seed_int seeds env i like numpy RandomState(seeds[i]) (init_genrand).  Both are synchronous
  * host calls; the conversion itself runs on the device, one lane per env.  cw_get_mt returns states a numpy RandomState accepts via set_state and that
- * continue the identical stream.
+ * continue the identical stream, in numpy's own form: pos in 1..624 (a stream at a generation's end is reported as (that generation, 624), as
+ * RandomState.get_state() does, not as (the next generation, 0)) -- after at least one draw the (key, pos) pair EQUALS the reference generator's.
  * These and the other synchronous entry points (cw_get_state, cw_set_state, cw_get_fixed_states, cw_checkpoint_*) wait for THIS ENGINE'S
  * work only -- whatever it enqueued on the streams it was handed since the last wait -- and do their copies on a stream of the engine's
  * own: another engine on the same device, or a learner, is not stalled (no device-wide synchronisation).  A stream handed to an enqueueing

@@ -271,6 +271,17 @@ void cwo_generate_fixed_states(cwo_env *e) /* ray.py:149-154 */
         sample_state(e, e->pool_grid + (size_t)k * e->ncell, &e->pool_agent[k]);
 }
 
+/* fixed_state_list (ray.py:116-118) as cell indices: out[K][9] = the cells (row*S+col) of objects 0..7 (OBJECTS order) and of the agent */
+void cwo_get_fixed_states(const cwo_env *e, uint16_t *out)
+{
+    for (int k = 0; k < e->cfg.fixed_init_state; k++) {
+        const uint8_t *g = e->pool_grid + (size_t)k * e->ncell;
+        for (int c = 0; c < e->ncell; c++)
+            if (g[c] >= 1 && g[c] <= 8) out[k * 9 + g[c] - 1] = (uint16_t)c;
+        out[k * 9 + 8] = (uint16_t)e->pool_agent[k];
+    }
+}
+
 /* ------------------------------------------------------------------ imagine_obs, ray.py:220-299 */
 static int find_nth(const uint8_t *g, int n, int code, int which)
 {

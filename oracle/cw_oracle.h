@@ -73,6 +73,7 @@ uint32_t cwo_rng_randint(cwo_env *e, uint32_t n); /* RandomState.randint(n)   */
 void cwo_rng_shuffle(cwo_env *e, int32_t *x, int32_t n); /* RandomState.shuffle(arange) */
 
 void cwo_generate_fixed_states(cwo_env *e);  /* ray.py:149-154, draws from the env RNG */
+void cwo_get_fixed_states(const cwo_env *e, uint16_t *out /* [K][9]: cells of objects 0..7 and of the agent */);
 void cwo_reset(cwo_env *e);                  /* ray.py:156-218 */
 /* ray.py:301-378; returns 0, or -1 for an action outside [0,6) (state untouched) */
 int cwo_step(cwo_env *e, int32_t action, int32_t *reward, int32_t *done);

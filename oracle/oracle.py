@@ -67,6 +67,7 @@ def _lib():
         lib.cwo_rng_randint.argtypes = [vp, C.c_uint32]
         lib.cwo_rng_shuffle.argtypes = [vp, i32p, C.c_int32]
         lib.cwo_generate_fixed_states.argtypes = [vp]
+        lib.cwo_get_fixed_states.argtypes = [vp, C.POINTER(C.c_uint16)]
         lib.cwo_reset.argtypes = [vp]
         lib.cwo_step.restype = C.c_int
         lib.cwo_step.argtypes = [vp, C.c_int32, i32p, i32p]
@@ -158,6 +159,12 @@ class OracleEnv:
         x = np.arange(n, dtype=np.int32)
         self._lib.cwo_rng_shuffle(self._h, x.ctypes.data_as(C.POINTER(C.c_int32)), n)
         return x
+
+    def fixed_states(self):
+        """fixed_state_list (ray.py:116-118) as cell indices: uint16 [K, 9] = objects 0..7 then the agent"""
+        out = np.zeros((max(self.cfg.fixed_init_state, 1), 9), dtype=np.uint16)
+        self._lib.cwo_get_fixed_states(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+        return out
 
     # -- env --
     def view(self):

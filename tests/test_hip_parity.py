@@ -66,8 +66,9 @@ def test_golden_fixture_replay(name, obs_mode):
         assert crc(view(obs, 'init_observation')) == g['r_init_img_crc'][ri]
         assert g['r_at_step'][ri] == t
         assert st['ep_no'][0] == g['r_ep_no'][ri]
-        # the MT19937 stream position after EVERY reset is the reference's (numpy holds 624 where the engine holds 0: the same point of the stream)
-        assert env.get_rng_states()[1][0] % 624 == g['r_rng_pos'][ri] % 624, (name, 'rng position', ri)
+        # the MT19937 state after EVERY reset is the reference generator's own: RandomState.get_state()'s key and position (cw_get_mt reports numpy's form)
+        k_, p_ = env.get_rng_states()
+        assert p_[0] == g['r_rng_pos'][ri] and crc(k_[0]) == g['r_rng_crc'][ri], (name, 'rng state', ri)
         if onehot:
             assert np.array_equal(st['goal_grid'][0], g['r_goal_grid'][ri]) and tuple(st['goal_agent_rc'][0]) == tuple(g['r_goal_agent'][ri])
         if ri < len(g['img_desired']):
@@ -99,7 +100,7 @@ def test_golden_fixture_replay(name, obs_mode):
     assert np.array_equal(view(obs, 'observation'), g['final_obs'])
     # the MT19937 stream position after the last reset is the reference's
     keys, pos = env.get_rng_states()
-    assert pos[0] % 624 == g['r_rng_pos'][-1] % 624
+    assert pos[0] == g['r_rng_pos'][-1] and crc(keys[0]) == g['r_rng_crc'][-1]
     env.close()
 
 
@@ -895,8 +896,10 @@ def test_error_behaviour_of_the_boundary():
         pix.rollout(torch.zeros((3, 4), dtype=torch.uint8, device='cuda'))      # rollout is state-only
     one = g.make('craftingworld-v3', size=(5, 5))
     one.reset()
-    with pytest.raises(IndexError):
-        one.step(-1)
+    for bad in (6, -7):
+        with pytest.raises(IndexError):
+            one.step(bad)                                                       # ACTIONS[action], ray.py:308
+    assert one.step(-1)[1] == -1                                                # (-1 is a list index too: 'drop')
     for e in (env, pix, one):
         e.close()
 
@@ -1441,7 +1444,7 @@ def test_facade_render_of_a_supplied_state():
         assert np.array_equal(other.obs_image, before) and np.array_equal(other.render(), before)
         if d:
             break
-    st = env._vec.get_state()
+    st = env.get_state()
     checked = 0
     for hold in (1, 2, 3):                                   # a held item shows on the agent's tile (ray.py:484-486)
         g2 = st['grid'][0].copy()
@@ -1449,7 +1452,7 @@ def test_facade_render_of_a_supplied_state():
         if len(where) == 0:
             continue
         g2[tuple(where[0])] = 0                              # ... picked up: no longer on the grid
-        env._vec.set_state(grid=g2[None], init_grid=st['init_grid'], agent_rc=st['agent_rc'], hold=np.array([hold]))
+        env.set_state(grid=g2[None], init_grid=st['init_grid'], agent_rc=st['agent_rc'], hold=np.array([hold]))
         oh = env.obs_one_hot
         assert oh[:, :, 8 + hold].sum() == 1
         assert np.array_equal(other.render(state=oh), env.render()), hold
@@ -1498,7 +1501,7 @@ def test_altobs_facade_render_of_a_supplied_state():
         assert np.array_equal(env.render(), obs['observation'])
         if d:
             break
-    st = env._vec.get_state()
+    st = env.get_state()
     held = 0
     for hold in (1, 2, 3):                                   # held items: counted on their own object pixel at the agent's tile + the strip's flag
         g2 = st['grid'][0].copy()
@@ -1508,7 +1511,7 @@ def test_altobs_facade_render_of_a_supplied_state():
         g2[tuple(where[0])] = 0
         if hold == 1:                                        # ... and sticks held OVER sticks: 2 x (45, 82, 160) = (90, 164, 320)
             g2[tuple(st['agent_rc'][0])] = 1
-        env._vec.set_state(grid=g2[None], init_grid=st['init_grid'], agent_rc=st['agent_rc'], hold=np.array([hold]))
+        env.set_state(grid=g2[None], init_grid=st['init_grid'], agent_rc=st['agent_rc'], hold=np.array([hold]))
         oh = env.obs_one_hot
         want = _reference_alt_render_of_any_state(oh)
         assert oh[:, :, 8 + hold].sum() == 1 and (want.max() == 320) == (hold == 1)
@@ -1866,8 +1869,7 @@ def test_flat_and_onehot_facades_replay_their_own_reference_fixtures(name):
     env = (cw.CraftingWorldEnvFlat if flat else cw.CraftingWorldEnvOneHot)(**ck)
     env.np_random = rs                                   # the reference user's way of pinning a stream
     if ck.get('fixed_init_state'):                        # the pool is drawn at construction (ray.py:116-118): redo it on that stream
-        from gym_craftingworld_amd import _lib as L
-        L.check(env._vec._lib.cw_generate_fixed_states(env._vec._h, env._vec._stream()), 'pool')
+        env.generate_fixed_states()
     assert (env.STATE_W, env.MAX_STEPS) == (kw['size'][0], kw['max_steps'])
     if flat:
         assert env.observation_space.shape == (4 * env.STATE_W, 4 * env.STATE_W, 3)
@@ -1891,7 +1893,8 @@ def test_flat_and_onehot_facades_replay_their_own_reference_fixtures(name):
                 assert np.array_equal(o['desired_goal'], g['img_desired'][ri]) and np.array_equal(o['observation'], g['img_obs'][ri])
         bits = sum(int(b) << i for i, b in enumerate(env.desired_goal_vector[0]))
         assert bits == g['r_desired'][ri] and env.ep_no == g['r_ep_no'][ri]
-        assert env.get_rng_state()[1] % 624 == g['r_rng_pos'][ri] % 624, (name, 'rng position', ri)
+        st_ = rs.get_state()                             # the caller's own RandomState IS the env's generator: it stands where the reference's stood
+        assert st_[2] == g['r_rng_pos'][ri] and crc(np.asarray(st_[1], np.uint32)) == g['r_rng_crc'][ri], (name, 'rng state', ri)
         ri += 1
 
     check_reset(env.reset(), 0)

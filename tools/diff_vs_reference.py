@@ -154,6 +154,46 @@ def check_facade_helpers():
     print('facade helpers == reference on %d goal-vector pairs and 72 one-hot rows' % (len(vecs) ** 2))
 
 
+def check_facade_aliasing(n_seeds):
+    """The N=1 facade's OBJECT behaviour against the reference's, op by op (tests/golden_util.py: run_alias_script): the committed script of
+    tests/golden/ray5_alias.npz and randomised ones -- a kept terminal `info` across reset(), draws from / seed / set_state on env.np_random,
+    an assigned RandomState, env.seed(), negative action ids -- on BOTH sides.  The facade runs on tests/fake_engine.py here (no GPU in the
+    build container: the oracle steps; the GPU tier replays the fixture through the HIP engine), with both of its step paths and both dtypes."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import fake_engine
+    import golden_util as G
+    import gym_craftingworld_amd as cw
+    ref_cls = import_reference()['ray']
+
+    configs = [dict(size=(5, 5), max_steps=30), dict(size=(6, 6), max_steps=20, reward_style='subset', fixed_init_state=3),
+               dict(size=(8, 8), max_steps=40, stacking=False, selected_tasks=T[::-1])]
+    n_ops = n_runs = 0
+    for resident in (True, False):
+        fake_engine.install(None, resident=resident)
+        for ref_dt in (False, True):
+            for seed in range(n_seeds + 1):
+                kw = configs[seed % len(configs)]
+                ops, args = G.alias_script() if seed == 0 else G.random_alias_script(np.random.RandomState(900 + seed), 90)
+                rng = np.random.RandomState(7000 + seed)
+                st = rng.get_state()
+                ref = make_ref_env(ref_cls, rng, **kw)
+                want = G.run_alias_script(ref, ops, args, seed)
+                mine = cw.CraftingWorldEnv(reference_dtypes=ref_dt, **kw)
+                mine.set_rng_state(st[1], int(st[2]))
+                if kw.get('fixed_init_state'):
+                    mine.generate_fixed_states()        # (the constructor drew the pool from its own seed: redraw it from the injected stream, as the reference's did)
+                got = G.run_alias_script(mine, ops, args, seed)
+                if not ref_dt:                          # uint8 frames are the engine's live buffers: a kept observation does not survive reset() (documented)
+                    got[ops == G.A_CHECK_KEPT, G.ALIAS_KEPT_OBS_COL] = want[ops == G.A_CHECK_KEPT, G.ALIAS_KEPT_OBS_COL]
+                bad = np.nonzero((got != want).any(axis=1))[0]
+                assert bad.size == 0, (resident, ref_dt, seed, int(bad[0]), int(ops[bad[0]]), int(args[bad[0]]), got[bad[0]].tolist(), want[bad[0]].tolist())
+                mine.close()
+                n_ops += len(ops)
+                n_runs += 1
+    print('facade aliasing == reference on %d ops in %d scripts (committed + randomised; resident / launch step paths, uint8 / int64 dtypes)' % (n_ops, n_runs))
+
+
 if __name__ == '__main__':
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 12)
     check_facade_helpers()
+    check_facade_aliasing(int(sys.argv[1]) if len(sys.argv) > 1 else 12)

@@ -208,9 +208,42 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
     return out, n_success
 
 
+ALIAS_SCENARIOS = [
+    # name, env kwargs, rng seed, policy seed: the op script of tests/golden_util.py (alias_script) run through the reference class -- what a caller sees
+    # of the env's OBJECTS (np_random as the live generator, goal vectors rebound by reset(), negative action ids)
+    ('ray5_alias', dict(size=(5, 5), max_steps=30), 4711, 37),
+]
+
+
+def capture_alias(cls, kwargs, seed, policy_seed):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    from golden_util import A_CHECK_KEPT, A_KEEP, alias_script, run_alias_script
+    rng = np.random.RandomState(seed)
+    st = rng.get_state()
+    env = make_ref_env(cls, rng, **kwargs)
+    ops, args = alias_script()
+    rows = run_alias_script(env, ops, args, policy_seed)
+    kept = rows[ops == A_KEEP]
+    assert (kept[:, 0] != 0).all(), 'a kept terminal info with an achieved bit set: pick another seed'
+    chk = rows[ops == A_CHECK_KEPT]
+    assert (chk[:, 2:4] == 0).all() and np.array_equal(chk[:, :2], kept[:, :2]), 'the reference rebinds the goal vectors at reset (ray.py:170, 176)'
+    kw = dict(kwargs)
+    kw['size'] = list(kw['size'])
+    meta = dict(kwargs=kw, seed=seed, policy_seed=policy_seed, env='CraftingWorldEnvRay', kind='alias')
+    return dict(meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), key0=st[1].astype(np.uint32), pos0=np.int32(st[2]),
+                ops=ops, args=args, rows=rows)
+
+
 def main():
     classes = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    for name, kwargs, seed, pseed in ALIAS_SCENARIOS:
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
+        out = capture_alias(classes['ray'], kwargs, seed, pseed)
+        path = os.path.join(OUT, name + '.npz')
+        np.savez_compressed(path, **out)
+        print('%-18s ops=%4d  %6.1f KB' % (name, len(out['ops']), os.path.getsize(path) / 1024))
     todo = ([(sc, 'ray', 'CraftingWorldEnvRay') for sc in SCENARIOS] + [(sc, 'altobs', 'CraftingWorldEnvAltObs') for sc in ALT_SCENARIOS] +
             [(sc, 'flat', 'CraftingWorldEnvFlat') for sc in FLAT_SCENARIOS] + [(sc, 'onehot', 'CraftingWorldEnvOneHot') for sc in ONEHOT_SCENARIOS])
     only = set(sys.argv[1:])
