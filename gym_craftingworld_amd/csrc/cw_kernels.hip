@@ -1103,9 +1103,14 @@ struct CwPaintJob { uint4 pos; uint32_t codes, agent_hold_kind, env, pad; };    
 enum { CW_JOB_INIT = 0, CW_JOB_GOAL = 1, CW_JOB_TERMINAL = 2 };
 // One workgroup's share of a step: wave `wave` (global index) steps the envs [wave * epw, wave * epw + epw), finished envs take their records, the workgroup
 // paints the frames a reset changes.
-__device__ __forceinline__ void fused_step(const CwParams &P, const void *actions, int act_dtype, int paint, int epw, int wave, uint32_t *s_mt_wave,
+// PAINT (0 state-only, 1 dirty-cell frames, 2 full frames) and TERM (keep_terminal_obs) are compile-time: the state-only engine's kernel holds no job
+// queue (24.5 KB of LDS), no barrier and no frame code at all -- it ran at occupancy 4 with 50 SGPR spills for branches it never takes (round 5) --
+// and the pixel kernels lose the branches of the other mode.
+template <int PAINT, bool TERM>
+__device__ __forceinline__ void fused_step(const CwParams &P, const void *actions, int act_dtype, int epw, int wave, uint32_t *s_mt_wave,
                                            CwPaintJob *s_jobs, int *s_njobs)
 {
+    constexpr int paint = PAINT;
     const int lane = threadIdx.x & (CW_WAVE - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int env0 = wave * epw;
@@ -1121,7 +1126,7 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
     const uint4 ip = P.init_pos[e];                  // (asked for with the rest: a second memory round trip only for lanes that hold something costs the wave the same)
-    if (paint) {
+    if constexpr (PAINT != 0) {
         if (threadIdx.x == 0) *s_njobs = 0;
         __syncthreads();                             // (behind the loads' issue)
     }
@@ -1133,17 +1138,19 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         P.achieved_out[env] = (uint16_t)o.achieved;
         P.desired_out[env] = (uint16_t)o.desired;
         if (o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
-        if (paint == 1 && o.changed && !o.done) paint_changed_cells(P, env, h, sp, o);      // render_edit, :358 (a finished env is repainted whole below)
+        if constexpr (PAINT == 1) { if (o.changed && !o.done) paint_changed_cells(P, env, h, sp, o); }      // render_edit, :358 (a finished env is repainted whole below)
     }
     // auto-reset, look-ahead first: a finished env takes its next episode's record over in its own lane ...
     const uint4 h_last = h;                          // (the finished episode's last state: keep_terminal_obs paints it below)
     uint32_t sp_last[8];
+    if constexpr (TERM) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
+        for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
+    }
     bool popped = false;
     CwGoalState goal;
     goal.pos = make_uint4(0, 0, 0, 0); goal.codes = 0; goal.agent = 0;
-    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true, &goal);
+    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true, PAINT != 0 ? &goal : nullptr);
     const unsigned long long m_all = CW_BALLOT(done), m_pop = CW_BALLOT(popped);
     const unsigned long long m_succ = CW_BALLOT(live && o.success);
     const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
@@ -1161,16 +1168,16 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
     }
     // ---- the jobs of this wave's finished envs (pixel modes): INIT_OBS (with the observation itself in the dirty-cell mode), desired_goal, and with
     //      keep_terminal_obs the finished episode's last frame.  Envs that took a record: by their own lanes.
-    const int jpe = P.terminal_img ? 3 : 2;
+    constexpr int jpe = TERM ? 3 : 2;
     int jmine = 0;
-    if (paint) {
+    if constexpr (PAINT != 0) {
         int jbase = 0;
         if (m_all) {
             if (lane == 0) jbase = atomicAdd(s_njobs, jpe * __popcll(m_all));
             jbase = __shfl(jbase, 0);
         }
         jmine = jbase + jpe * __popcll(m_all & ((1ull << lane) - 1ull));
-        if (done && P.terminal_img) {
+        if constexpr (TERM) if (done) {
             CwPaintJob &j = s_jobs[jmine + 2];
             j.pos = pack_pos(sp_last);
             j.codes = h_last.w;
@@ -1203,7 +1210,7 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         if (lane == l) {
             h = reset_header(P, r, menu_id);
             unpack_pos(r.init_pos, sp);
-            if (paint) {
+            if constexpr (PAINT != 0) {
                 CwPaintJob &j0 = s_jobs[jmine], &j1 = s_jobs[jmine + 1];
                 j0.pos = r.init_pos; j0.codes = CW_CODES_INITIAL; j0.agent_hold_kind = r.init_agent | (CW_JOB_INIT << 24); j0.env = (uint32_t)env_l;
                 j1.pos = r.goal_pos; j1.codes = r.goal_codes; j1.agent_hold_kind = r.goal_agent | (CW_JOB_GOAL << 24); j1.env = (uint32_t)env_l;
@@ -1214,7 +1221,7 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         P.hdr[env] = h;
         P.pos[env] = pack_pos(sp);
     }
-    if (!paint) return;
+    if constexpr (PAINT == 0) return;
     __syncthreads();
     const int n_jobs = *s_njobs;
     for (int jq = wave_in_block; jq < n_jobs; jq += CW_RESET_WAVES) {
@@ -1232,14 +1239,21 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         paint_state_frame(P, d0, jp, codes, ahk & 0xFFFFu, (ahk >> 16) & 0xFFu, lane, d1);
     }
 }
-__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype,
-                                                                                int paint, int epw)
+template <int PAINT, bool TERM>
+__global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(CwParams P, const void *actions, int act_dtype, int epw)
 {
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
-    __shared__ CwPaintJob s_jobs[CW_RESET_WAVES * CW_WAVE * 3];
+    __shared__ CwPaintJob s_jobs[PAINT != 0 ? CW_RESET_WAVES * CW_WAVE * (TERM ? 3 : 2) : 1];      // (state-only: no queue -- one unused entry, optimised away)
     __shared__ int s_njobs;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    fused_step(P, actions, act_dtype, paint, epw, blockIdx.x * CW_RESET_WAVES + wave_in_block, s_mt[wave_in_block], s_jobs, &s_njobs);
+    fused_step<PAINT, TERM>(P, actions, act_dtype, epw, blockIdx.x * CW_RESET_WAVES + wave_in_block, s_mt[wave_in_block], s_jobs, &s_njobs);
+}
+typedef void (*CwStepFusedKernel)(CwParams, const void *, int, int);
+static CwStepFusedKernel cw_step_fused_variant(int paint, bool term)
+{
+    if (paint == 0) return cw_step_fused_kernel<0, false>;
+    if (paint == 1) return term ? cw_step_fused_kernel<1, true> : cw_step_fused_kernel<1, false>;
+    return term ? cw_step_fused_kernel<2, true> : cw_step_fused_kernel<2, false>;
 }
 
 // generate_fixed_states, ray.py:149-154: K placements per env from the env's stream
@@ -1921,8 +1935,9 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     if (auto_reset) {
         const int epw = cw_envs_per_wave(n, tn.step_envs_per_wave);
         const int waves = (n + epw - 1) / epw;
-        hipLaunchKernelGGL(cw_step_fused_kernel, dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES), dim3(CW_RESET_WAVES * CW_WAVE), 0, st,
-                           *P, actions, act_dtype, obs_mode == 2 ? 1 : obs_mode == 1 ? 2 : 0, epw);
+        const int paint = obs_mode == 2 ? 1 : obs_mode == 1 ? 2 : 0;
+        hipLaunchKernelGGL(cw_step_fused_variant(paint, paint != 0 && P->terminal_img != nullptr), dim3((waves + CW_RESET_WAVES - 1) / CW_RESET_WAVES),
+                           dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, actions, act_dtype, epw);
     } else {
         hipLaunchKernelGGL(cw_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *P, actions, act_dtype, obs_mode == 2 ? 1 : 0);
     }

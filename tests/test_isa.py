@@ -1,5 +1,5 @@
 """CPU tier: what THIS toolchain makes of the HIP kernels -- registers, spills, LDS (tools/isa_report.py; the table of the committed build is
-profiles/r05_isa_resources.txt)."""
+profiles/r06_isa_resources.txt)."""
 import importlib.util
 import os
 
@@ -15,7 +15,7 @@ def _report():
 
 def test_no_kernel_spills_vector_registers_or_uses_scratch():
     """Hard assertions are structural only (a hipcc bump must not fail the CPU tier): no kernel spills VGPRs or touches scratch memory.  The
-    committed table (profiles/r05_isa_resources.txt) is compared for information: a difference is printed, not failed."""
+    committed table (profiles/r06_isa_resources.txt) is compared for information: a difference is printed, not failed."""
     import warnings
     mod, text = _report()
     rows = {l.split()[0]: l.split() for l in text.splitlines() if l and not l.startswith('#') and not l.startswith('kernel')}

@@ -2,7 +2,7 @@
 """Per-kernel resource table of the HIP engine as built by THIS toolchain.
 
     python tools/isa_report.py            print the table
-    python tools/isa_report.py --write    ... and rewrite profiles/r05_isa_resources.txt (tests/test_isa.py prints a warning when a build differs)
+    python tools/isa_report.py --write    ... and rewrite profiles/r06_isa_resources.txt (tests/test_isa.py prints a warning when a build differs)
 
 Source: hipcc -Rpass-analysis=kernel-resource-usage (registers, spills, scratch, occupancy, LDS)."""
 import os
@@ -13,13 +13,13 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gym_craftingworld_amd', 'csrc')
-RECORD = os.path.join(ROOT, 'profiles', 'r05_isa_resources.txt')
+RECORD = os.path.join(ROOT, 'profiles', 'r06_isa_resources.txt')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '--cuda-device-only', '-x', 'hip']
 
 
 def demangle(names):
-    """_Z23cw_render_pieces_kernelILi0ELi2EEv8CwParamsPhiiiii -> cw_render_pieces_kernel<0,2> (Itanium names of plain / int-templated functions)"""
+    """_Z23cw_render_pieces_kernelILi0ELi2EEv8CwParamsPhiiiii -> cw_render_pieces_kernel<0,2> (Itanium names of plain / int- and bool-templated functions)"""
     out = []
     for n in names:
         m = re.match(r'_Z(\d+)', n)
@@ -28,8 +28,8 @@ def demangle(names):
             continue
         k = int(m.group(1))
         base, rest = n[m.end():m.end() + k], n[m.end() + k:]
-        t = re.match(r'I((?:Li\d+E)+)E', rest)
-        out.append(base + ('<%s>' % ','.join(re.findall(r'Li(\d+)E', t.group(1))) if t else ''))
+        t = re.match(r'I((?:L[ib]\d+E)+)E', rest)
+        out.append(base + ('<%s>' % ','.join(re.findall(r'L[ib](\d+)E', t.group(1))) if t else ''))
     return out
 
 
