@@ -101,7 +101,18 @@ ABI = {
     'cw_abi_version': (C.c_int, []),
     'cw_last_error': (C.c_char_p, []),
 }
-# host-only helpers (MT19937 state conversion), exported for tests of the host logic
+class cwh_guard(C.Structure):
+    """the sweep clock's guard as a pure state machine (csrc/cw_host.h)"""
+    _fields_ = [('rate', C.c_double), ('rate_top', C.c_double), ('ms_sum', C.c_double), ('prev_mean', C.c_double), ('ref_ms', C.c_double),
+                ('ref_prev', C.c_double), ('ms_n', C.c_int32), ('late', C.c_int32), ('good', C.c_int32), ('slowdowns', C.c_int32),
+                ('probes', C.c_int32), ('probe_need', C.c_int32), ('recover_need', C.c_int32), ('probing', C.c_int32), ('recovering', C.c_int32)]
+
+
+CWH_GUARD_NONE, CWH_GUARD_SLOWDOWN, CWH_GUARD_TRIAL_UP, CWH_GUARD_TRIAL_KEPT, CWH_GUARD_TRIAL_UNDONE = range(5)
+CWH_CKPT_SECTIONS = 23
+
+# the engine's HIP-free host logic (csrc/cw_host.h: MT19937 state conversion, DLPack, dense views, checkpoint sizes, the guard's decisions), exported for
+# the tests of the host logic -- the same table binds libcw_host_asan.so, the ASAN/UBSAN build of cw_host.cpp alone (bind_host_helpers)
 HOST_HELPERS = {
     'cwh_mt_from_numpy': (C.c_int, [_VP, C.c_int]),
     'cwh_mt_to_numpy': (None, [_VP, C.c_int, _VP]),
@@ -109,7 +120,22 @@ HOST_HELPERS = {
     'cwh_mt_untwist': (None, [_VP]),
     'cwh_mt_rewind': (None, [_VP, C.POINTER(C.c_int32), C.c_uint32]),
     'cwh_dlpack_make': (_VP, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    'cwh_slots_to_grid': (None, [_VP, C.c_uint32, C.c_int, _VP]),
+    'cwh_ckpt_section_bytes': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    'cwh_guard_init': (None, [C.POINTER(cwh_guard), C.c_double]),
+    'cwh_guard_step': (C.c_int, [C.POINTER(cwh_guard), C.c_double, C.c_double]),
+    'cwh_sweep_periods': (None, [C.c_double, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'cwh_guard_scheduled_ms': (C.c_double, [C.c_double, C.c_int32, C.c_int32, C.c_double]),
 }
+
+
+def bind_host_helpers(lib):
+    """argtypes / restype of every cwh_* symbol on `lib` (the product, or the sanitizer build of cw_host.cpp)"""
+    for name, (res, args) in HOST_HELPERS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 _libs = {}      # path -> loaded library (a process may hold the product and another build side by side)
 _lib = None     # the one loaded (or asked for) last: check() takes its error text

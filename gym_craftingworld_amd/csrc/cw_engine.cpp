@@ -13,6 +13,7 @@
 
 #include "../../include/craftingworld.h"
 #include "cw_layout.h"
+#include "cw_host.h"
 
 extern "C" {
 hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *actions, int act_dtype, int obs_mode, int auto_reset, hipStream_t st,
@@ -97,19 +98,14 @@ struct cw_engine {
     bool in_step_many = false;         // (cw_step_many decides about the refill of a captured sequence itself)
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
     int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
-    double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;
+    double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;      // (sweep_rate: cw_create's choice; the live one is guard.rate)
     bool guard_on = false;
     // the guard's samples in flight: the host runs up to ~1 000 steps ahead of the card, so a sample recorded now is read a dozen samples later
     enum { GUARD_RING = 32 };
     struct GuardSample { hipEvent_t ev[6]; int period16; } guard_ring[GUARD_RING] = {};
     unsigned guard_head = 0, guard_tail = 0;      // next slot to record into / oldest slot not read yet
     unsigned guard_step = 0;
-    int guard_late = 0, guard_good = 0, guard_slowdowns = 0;
-    double sweep_rate_top = 0;          // the best rate known to hold: cw_create's choice, raised by a probe that paid (sweep_guard_tick)
-    double guard_ms_sum = 0, guard_prev_mean = 0;   // sweep times sampled at the current rate; their mean at the rate a probe left
-    double guard_ref_ms = 0, guard_ref_prev = 0;    // what the current rate delivered when a trial ACCEPTED it (its yardstick if that is more than its schedule); the one of the rate a trial left
-    int guard_ms_n = 0, guard_probe_need = 0, guard_probes = 0, guard_recover_need = 64;
-    bool guard_probing = false, guard_recovering = false;   // a TRIAL is running: one notch up, its verdict due after CW_PROBE_SAMPLES samples / ... and it is a step back towards the best rate known, not beyond it
+    cwh_guard guard{};                  // its decisions (cw_host.cpp: cwh_guard_step): rate, best rate known, trials, back-off
     int prof_cap = 0, prof_n = 0;
     // the engine's OWN work: the streams it was handed since its last wait (at most 4 are remembered) and a private stream for the synchronous
     // entry points' copies and kernels (cw_seed_*, cw_get_mt, cw_get/set_state, checkpoints): none of them waits for anybody else's work
@@ -159,125 +155,7 @@ static int resident_park(cw_engine *e)
 }
 #define PARK(e) do { if ((e)->res_running) { const int _rc = resident_park(e); if (_rc != CW_OK) return _rc; } } while (0)
 
-// ------------------------------------------------------------------------------ MT19937 (host)
-// numpy RandomState (key, pos)  <->  the engine's consume-and-replace form (cw_mt.h).
-static inline uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far)
-{
-    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
-    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-extern "C" {
-
-// in place: words < pos become next-generation (numpy's twist loop, first `pos` iterations);
-// returns the engine index (pos mod 624)
-int cwh_mt_from_numpy(uint32_t *s, int pos)
-{
-    if (pos < 0) pos = 0;
-    if (pos > CW_MT_N) pos = CW_MT_N;
-    for (int k = 0; k < pos; k++)
-        s[k] = mt_twist(s[k], s[(k + 1) % CW_MT_N], s[(k + 397) % CW_MT_N]);
-    return pos % CW_MT_N;
-}
-
-// inverse: from engine form (s, idx) recover a numpy key whose stream from position idx is
-// identical.  Words < idx are un-twisted; key[0]'s low 31 bits are not part of the MT19937 state and
-// cannot be un-twisted ...
-void cwh_mt_to_numpy(const uint32_t *s, int idx, uint32_t *key)
-{
-    for (int j = idx; j < CW_MT_N; j++) key[j] = s[j];
-    for (int j = 0; j < idx; j++) key[j] = 0;
-    for (int j = idx - 1; j >= 0; j--) {
-        const uint32_t m = (j < CW_MT_N - 397) ? key[j + 397] : s[j - (CW_MT_N - 397)];
-        uint32_t t = s[j] ^ m;
-        const uint32_t odd = t >> 31;
-        if (odd) t ^= 0x9908b0dfu;
-        const uint32_t y = (t << 1) | odd;     // (G[j] & UPPER) | (G[j+1] & LOWER)
-        key[j] |= y & 0x80000000u;
-        if (j + 1 < idx) key[j + 1] |= y & 0x7fffffffu;
-    }
-    if (idx > 0) {     // ... but they are what the generation's word 623 was made with: key[623] = key[396] ^ T(previous[623].hi, key[0].lo)
-        uint32_t t = key[CW_MT_N - 1] ^ key[396];
-        const uint32_t odd = t >> 31;
-        if (odd) t ^= 0x9908b0dfu;
-        key[0] |= ((t << 1) | odd) & 0x7fffffffu;      // (exact for every key a twist produced; a rewind to position 0 reads this word again)
-    }
-}
-
-// One generation back: key = all 624 words of a generation as numpy holds them after its twist -> the generation before (whose twist
-// produced it).  The twist is a bijection on the 19 937 state bits (word 0 counts with its top bit only): word k >= 227 of the new
-// generation is new[k-227] ^ T(old[k].hi, old[k+1].lo), word 623 new[396] ^ T(old[623].hi, new[0].lo), word k < 227 old[k+397] ^ T(...);
-// T(y) = (y >> 1) ^ (y odd ? 0x9908b0df : 0) is undone through its top bit.  The low 31 bits of key[0] (not part of the state; the export
-// above restores them from words 623 and 396) are REPAIRED on the way in -- the step for word 227 needs them -- and restored in the result.
-void cwh_mt_untwist(uint32_t *key)
-{
-    uint32_t prev[CW_MT_N];
-    memset(prev, 0, sizeof(prev));
-    for (int k = CW_MT_N - 1; k >= 0; k--) {
-        uint32_t t = key[k] ^ (k == CW_MT_N - 1 ? key[396] : k >= CW_MT_N - 397 ? key[k - (CW_MT_N - 397)] : prev[k + 397]);
-        const uint32_t odd = t >> 31;
-        if (odd) t ^= 0x9908b0dfu;
-        const uint32_t y = (t << 1) | odd;
-        prev[k] |= y & 0x80000000u;
-        if (k == CW_MT_N - 1) key[0] = (key[0] & 0x80000000u) | (y & 0x7fffffffu);
-        else prev[k + 1] |= y & 0x7fffffffu;
-    }
-    uint32_t t = prev[CW_MT_N - 1] ^ prev[396];          // prev[0]'s own low bits, the same way (cwh_mt_to_numpy): a rewind may stop at position 0
-    const uint32_t odd = t >> 31;
-    if (odd) t ^= 0x9908b0dfu;
-    prev[0] |= ((t << 1) | odd) & 0x7fffffffu;
-    memcpy(key, prev, sizeof(prev));
-}
-// numpy state (key, pos) -> the state n raw draws earlier (a look-ahead record's draws, cw_get_mt); pos stays in 0..623 like the export's
-void cwh_mt_rewind(uint32_t *key, int32_t *pos, uint32_t n)
-{
-    while (n > 0) {
-        if ((uint32_t)*pos >= n) { *pos -= (int32_t)n; n = 0; }
-        else { n -= (uint32_t)*pos; cwh_mt_untwist(key); *pos = CW_MT_N; }
-    }
-}
-
-// ------------------------------------------------------------------------------ DLPack producer
-// Non-owning DLManagedTensor over engine memory (DLPack ABI v0: the struct layout below is the
-// published one).  Produced and freed in C so that no Python callback is involved when a consumer
-// (torch) drops its last view -- possibly during interpreter shutdown.
-struct CwDLDevice { int32_t device_type, device_id; };
-struct CwDLDataType { uint8_t code, bits; uint16_t lanes; };
-struct CwDLTensor { void *data; CwDLDevice device; int32_t ndim; CwDLDataType dtype; int64_t *shape, *strides; uint64_t byte_offset; };
-struct CwDLManagedTensor { CwDLTensor dl_tensor; void *manager_ctx; void (*deleter)(CwDLManagedTensor *); };
-
-static void cw_dl_deleter(CwDLManagedTensor *m)
-{
-    if (!m) return;
-    free(m->dl_tensor.shape);
-    free(m);
-}
-
-// device_type 10 = kDLROCM; code 0 int / 1 uint; returns a malloc'ed DLManagedTensor* (or NULL)
-void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, const int64_t *shape)
-{
-    CwDLManagedTensor *m = (CwDLManagedTensor *)calloc(1, sizeof(CwDLManagedTensor));
-    int64_t *shp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ndim > 0 ? ndim : 1));
-    if (!m || !shp) { free(m); free(shp); return nullptr; }
-    for (int i = 0; i < ndim; i++) shp[i] = shape[i];
-    m->dl_tensor.data = data;
-    m->dl_tensor.device = CwDLDevice{10, device_id};
-    m->dl_tensor.ndim = ndim;
-    m->dl_tensor.dtype = CwDLDataType{(uint8_t)code, (uint8_t)bits, 1};
-    m->dl_tensor.shape = shp;
-    m->dl_tensor.strides = nullptr;
-    m->dl_tensor.byte_offset = 0;
-    m->deleter = cw_dl_deleter;
-    return m;
-}
-
-void cwh_mt_init_genrand(uint32_t *s, uint32_t seed)   // numpy RandomState(int): init_genrand
-{
-    s[0] = seed;
-    for (int i = 1; i < CW_MT_N; i++) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
-}
-
-}  // extern "C"
+// (MT19937 state conversion, the DLPack producer, the dense view of a slot record, the checkpoint sections' sizes and the guard's decisions: cw_host.cpp)
 
 // ------------------------------------------------------------------------------ helpers
 template <typename T>
@@ -352,16 +230,12 @@ static int timed_render_stats(cw_engine *e, double *median, double *p90, double 
 // (sweep_guard_tick): a sweep that does not keep its schedule any more is slowed down a notch.
 // CW_TUNE_PERIOD_NS forces a period (0: unclocked, every wave as fast as it can).
 static double sweep_period_ns(const cw_engine *e, double tb_per_s) { return (double)e->sweep_waves * 4096.0 / (tb_per_s * 1e12) * 1e9; }
-// the clock's three periods from one rate: a launch's first CW_HEAD_JOBS jobs run CW_HEAD_NOTCH slower, after a step on which envs finished
-// CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
-static const double CW_RATE_FLOOR = 5.0;
+// the clock's three periods from one rate (cwh_sweep_periods): a launch's first CWH_HEAD_JOBS jobs run CW_HEAD_NOTCH slower, after a step on which envs
+// finished CW_BUSY_NOTCH slower (cw_render_pieces_kernel)
 static double CW_HEAD_NOTCH = 0.4, CW_BUSY_NOTCH = 0.75;      // (TB/s; CW_TUNE_HEAD_NOTCH / CW_TUNE_BUSY_NOTCH for experiments: profiles/r05_experiments.txt J)
-static const int CW_HEAD_JOBS_HOST = 64;
 static void set_sweep_rate(cw_engine *e, double tb_per_s)
 {
-    e->tune.period16 = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s) * 1.6 + 0.5) : 0;
-    e->tune.period16_head = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s - CW_HEAD_NOTCH > CW_RATE_FLOOR ? tb_per_s - CW_HEAD_NOTCH : CW_RATE_FLOOR) * 1.6 + 0.5) : 0;
-    e->tune.period16_busy = tb_per_s > 0 ? (int)(sweep_period_ns(e, tb_per_s - CW_BUSY_NOTCH > CW_RATE_FLOOR ? tb_per_s - CW_BUSY_NOTCH : CW_RATE_FLOOR) * 1.6 + 0.5) : 0;
+    cwh_sweep_periods(tb_per_s, e->sweep_waves, CW_HEAD_NOTCH, CW_BUSY_NOTCH, &e->tune.period16, &e->tune.period16_head, &e->tune.period16_busy);
 }
 
 static int calibrate_sweep(cw_engine *e)
@@ -404,8 +278,7 @@ static int calibrate_sweep(cw_engine *e)
         if (rc == CW_OK && (best_p90 == 0 || p90 < 0.995 * best_p90)) { best_p90 = p90; e->sweep_rate = rates[i]; }
     }
     set_sweep_rate(e, e->sweep_rate);
-    e->sweep_rate_top = e->sweep_rate;
-    e->guard_probe_need = 64;                       // (CW_GUARD_RECOVER, below)
+    cwh_guard_init(&e->guard, e->sweep_rate);
     e->guard_on = rc == CW_OK && e->sweep_rate > 0 && e->auto_reset && !(getenv("CW_TUNE_GUARD") && atoi(getenv("CW_TUNE_GUARD")) == 0);
     if (e->guard_on)
         for (auto &smp : e->guard_ring)
@@ -417,33 +290,11 @@ static int calibrate_sweep(cw_engine *e)
     return rc;
 }
 
-// The GUARD of the sweep's clock.  Every CW_GUARD_EVERY-th step's sweep is bracketed by two events on the caller's stream; when they have completed
-// (read at the next sampled step, however far the host runs ahead) the sweep's time is held against its schedule, jobs x period + the busy head + what
-// a launch costs beside its jobs (measured at cw_create).  A sweep in the memory system's saturated regime misses that by 10-16 % launch after launch; at
-// the edge (7.7 TB/s) one launch in ten is 7-12 % late and the rest on time.  Three samples in a row more than 6 % late: the rate goes down by
-// 0.2 TB/s (a SLOWDOWN: the only move that is not a trial).
-// TRIALS (round 5).  cw_create's choice is a measurement of one moment: an engine created while the card was in a worse state settles a notch or two
-// under what the card takes an hour later (7.4 instead of 7.7 TB/s: 2.7 % of every sweep), and round 4's guard only ever went down -- or came back by
-// its schedule alone.  Now every move UP is a trial: after enough samples on time (guard_recover_need below the best rate known, guard_probe_need at it:
-// a PROBE, never beyond CW_RATE_CEILING, the write path's edge) the guard tries ONE notch more and keeps it only if it PAYS -- the mean of
-// CW_PROBE_SAMPLES sweeps at the new rate must be under the mean at the old one; "on time" is not enough (a clock a little too fast is on time and
-// slower) and not needed either: with something else between the sweeps (another engine's step kernel: profiles/r05_experiments.txt M) every sweep is a
-// constant late, a rate judged by its schedule alone comes to rest a notch or two under the one with the shortest sweeps, and so a rate a trial has
-// accepted is from then on measured against what it delivered then (guard_ref_ms).  A trial that does not pay is undone and the next one of its kind
-// waits twice as long: a disturbance that has passed -- another process on the card, a thermal excursion -- does not slow the engine for the rest of
-// its life, and a clock that moves once in thousands of steps does not hunt.
-// -> the event array for this step's launch, or null.
-enum { CW_GUARD_EVERY = 64, CW_GUARD_RECOVER = 64, CW_PROBE_SAMPLES = 32, CW_PROBE_NEED_MAX = 2048 };
-static const double CW_RATE_CEILING = 7.7;
-static void guard_set_rate(cw_engine *e, double rate)
-{
-    e->sweep_rate = rate;
-    set_sweep_rate(e, rate);
-    e->guard_ms_sum = 0;
-    e->guard_ms_n = 0;
-    e->guard_good = e->guard_late = 0;
-    e->guard_ref_ms = 0;
-}
+// The GUARD of the sweep's clock, the plumbing: every CW_GUARD_EVERY-th step's sweep is bracketed by two events on the caller's stream; when they have
+// completed (read at the next sampled step, however far the host runs ahead) the sweep's time and its schedule go to cwh_guard_step (cw_host.cpp: the
+// decisions -- slowdowns, trials one notch up, back-off -- as a pure state machine, tested on synthetic traces in tests/test_host_logic.py), and a
+// changed rate is programmed into the clock.  -> the event array for this step's launch, or null.
+enum { CW_GUARD_EVERY = 64 };
 static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
 {
     if (++e->guard_step % CW_GUARD_EVERY) return nullptr;
@@ -454,54 +305,16 @@ static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
     while (e->guard_tail != e->guard_head && hipEventQuery(e->guard_ring[e->guard_tail % cw_engine::GUARD_RING].ev[5]) == hipSuccess) {
         cw_engine::GuardSample &smp = e->guard_ring[e->guard_tail++ % cw_engine::GUARD_RING];
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, smp.ev[4], smp.ev[5]) == hipSuccess && ms > 0.f && smp.period16 == e->tune.period16) {      // (a sample of another rate says nothing)
-            const double scheduled = (e->sweep_jobs * (e->tune.period16 / 1.6) + CW_HEAD_JOBS_HOST * ((e->tune.period16_busy - e->tune.period16) / 1.6)) * 1e-6 +
-                                     e->sweep_beside_ms;                 // (as after a step on which envs finished: a quiet step is 4 us early)
-            // the yardstick: the schedule, or what this rate delivered when a trial accepted it (a loop with something else between the sweeps -- another
-            // engine's step kernel -- runs every sweep a constant late, and the best clock is the one with the shortest sweeps, not the one on schedule).
-            // While a trial runs only sweeps FAR off -- 15 % over the schedule AND over what the rate it left delivered -- end it early: its verdict is the mean.
-            const double ref = std::max(scheduled, e->guard_probing ? e->guard_prev_mean : e->guard_ref_ms);
-            const bool late = ms > (e->guard_probing ? 1.15 : 1.06) * ref;
-            e->guard_late = late ? e->guard_late + 1 : 0;
-            // ("in a row" for the way up means MOSTLY: at the edge one launch in ten is late by itself, and 64 strictly in a row would never come)
-            e->guard_good = late ? std::max(0, e->guard_good - 8) : e->guard_good + 1;
-            if (e->guard_ms_n >= 128) { e->guard_ms_sum *= 0.5; e->guard_ms_n /= 2; }             // (the mean is of the last ~100 samples, not of the rate's whole past)
-            e->guard_ms_sum += ms;
-            e->guard_ms_n++;
-            const bool verdict_due = e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES;
-            const double mean = e->guard_ms_sum / e->guard_ms_n;
-            if (e->guard_probing && (e->guard_late >= 3 || (verdict_due && mean >= 0.998 * e->guard_prev_mean))) {      // ---- a trial that does not pay: undone
-                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %s %.1f TB/s does not pay (%.4f ms against %.4f%s): undone\n", e->guard_recovering ? "the way back to" : "probe",
-                                     e->sweep_rate, mean, e->guard_prev_mean, verdict_due ? "" : "; three sweeps far off");
-                const double ref_prev = e->guard_ref_prev;
-                guard_set_rate(e, e->sweep_rate - 0.2);
-                e->guard_ref_ms = ref_prev;
-                int &need = e->guard_recovering ? e->guard_recover_need : e->guard_probe_need;     // the next attempt of its kind waits twice as long (no see-saw between two notches)
-                need = std::min(2 * need, (int)CW_PROBE_NEED_MAX);
-                e->guard_probing = e->guard_recovering = false;
-            } else if (verdict_due) {                                                             // ---- a trial that PAYS: kept, and its mean is this rate's yardstick
-                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: %s %.1f TB/s pays (%.4f ms against %.4f): kept\n", e->guard_recovering ? "the way back to" : "probe", e->sweep_rate, mean, e->guard_prev_mean);
-                if (e->guard_recovering) e->guard_recover_need = CW_GUARD_RECOVER;
-                else { e->sweep_rate_top = e->sweep_rate; e->guard_probe_need = CW_GUARD_RECOVER / 4; }      // (the next notch is tried sooner)
-                e->guard_ref_ms = mean;
-                e->guard_probing = e->guard_recovering = false;
-            } else if (!e->guard_probing && e->guard_late >= 3 && e->sweep_rate > CW_RATE_FLOOR + 0.1) {      // ---- not keeping its schedule: a notch down
-                guard_set_rate(e, e->sweep_rate - 0.2);
-                e->guard_slowdowns++;
-                if (verbose)
-                    fprintf(stderr, "[craftingworld] sweep clock: %.4f ms against %.4f, three samples in a row -> %.1f TB/s (%.0f ns)\n", ms, ref, e->sweep_rate, e->tune.period16 / 1.6);
-            } else if (!e->guard_probing && e->guard_ms_n >= CW_PROBE_SAMPLES && e->sweep_rate + 0.05 < CW_RATE_CEILING &&
-                       e->guard_good >= (e->sweep_rate + 0.1 < e->sweep_rate_top ? e->guard_recover_need : e->guard_probe_need)) {
-                // ---- a trial: one notch up -- back towards the best rate known after a slowdown, or beyond it (a probe)
-                e->guard_recovering = e->sweep_rate + 0.1 < e->sweep_rate_top;
-                e->guard_prev_mean = mean;
-                e->guard_ref_prev = e->guard_ref_ms;
-                guard_set_rate(e, std::min(e->sweep_rate + 0.2, CW_RATE_CEILING));
-                e->guard_probing = true;
-                if (!e->guard_recovering) e->guard_probes++;
-                if (verbose) fprintf(stderr, "[craftingworld] sweep clock: trying %.1f TB/s (%.0f ns; %.4f ms so far)%s\n", e->sweep_rate, e->tune.period16 / 1.6, e->guard_prev_mean,
-                                     e->guard_recovering ? " on the way back" : "");
-            }
+        if (hipEventElapsedTime(&ms, smp.ev[4], smp.ev[5]) != hipSuccess || ms <= 0.f || smp.period16 != e->tune.period16) continue;      // (a sample of another rate says nothing)
+        const double scheduled = cwh_guard_scheduled_ms(e->sweep_jobs, e->tune.period16, e->tune.period16_busy, e->sweep_beside_ms);
+        const double rate_before = e->guard.rate, prev_mean = e->guard.prev_mean;
+        const int recovering = e->guard.recovering;
+        const int action = cwh_guard_step(&e->guard, ms, scheduled);
+        if (e->guard.rate != rate_before) set_sweep_rate(e, e->guard.rate);
+        if (verbose && action != CWH_GUARD_NONE) {
+            static const char *what[] = {"", "three samples in a row late: a notch down", "trying a notch up", "the trial pays: kept", "the trial does not pay: undone"};
+            fprintf(stderr, "[craftingworld] sweep clock: %s%s -- %.4f ms against %.4f scheduled (mean at the rate left %.4f): %.1f -> %.1f TB/s (%.0f ns)\n", what[action],
+                    recovering ? " (on the way back to the best rate known)" : "", ms, scheduled, prev_mean, rate_before, e->guard.rate, e->tune.period16 / 1.6);
         }
     }
     if (e->guard_head - e->guard_tail >= (unsigned)cw_engine::GUARD_RING) return nullptr;      // (every slot in flight: this step goes unsampled)
@@ -1094,7 +907,7 @@ int cw_tuner(const cw_engine *e, cw_tuner_state *out)
     out->period16_busy = e->tune.period16_busy;
     out->lookahead = e->P.lookahead;
     out->resident = e->res ? 1 : 0;
-    out->guard_slowdowns = e->guard_on ? e->guard_slowdowns : -1;
+    out->guard_slowdowns = e->guard_on ? e->guard.slowdowns : -1;
     return CW_OK;
 }
 
@@ -1149,13 +962,6 @@ int cw_get_fixed_states(cw_engine *e, uint16_t *out)
 }
 
 // ------------------------------------------------------------------------------ state get/set
-static void slots_to_grid(const uint16_t *pos, uint32_t codes, int ncell, uint8_t *grid)
-{
-    memset(grid, 0, (size_t)ncell);
-    for (int k = 0; k < 8; k++)
-        if (pos[k] < (uint32_t)ncell) grid[pos[k]] = (uint8_t)((codes >> (4 * k)) & 15u);
-}
-
 int cw_get_state(cw_engine *e, cw_state_view *v)
 {
     if (!e || !v) return fail(CW_ERR_INVALID, "cw_get_state: null argument");
@@ -1179,9 +985,9 @@ int cw_get_state(cw_engine *e, cw_state_view *v)
     HIP_TRY(hipStreamSynchronize(e->aux));
     for (size_t i = 0; i < N; i++) {
         const uint32_t *h = &hdr[i * 4];
-        if (v->grid) slots_to_grid(&pos[i * 8], h[3], nc, v->grid + i * nc);
-        if (v->init_grid) slots_to_grid(&ipos[i * 8], CW_CODES_INITIAL, nc, v->init_grid + i * nc);
-        if (v->goal_grid) slots_to_grid(&gpos[i * 8], goal_codes[i], nc, v->goal_grid + i * nc);
+        if (v->grid) cwh_slots_to_grid(&pos[i * 8], h[3], nc, v->grid + i * nc);
+        if (v->init_grid) cwh_slots_to_grid(&ipos[i * 8], CW_CODES_INITIAL, nc, v->init_grid + i * nc);
+        if (v->goal_grid) cwh_slots_to_grid(&gpos[i * 8], goal_codes[i], nc, v->goal_grid + i * nc);
         if (v->agent_rc) { v->agent_rc[i * 2] = h[0] & 0xFF; v->agent_rc[i * 2 + 1] = (h[0] >> 8) & 0xFF; }
         if (v->init_agent_rc) { v->init_agent_rc[i * 2] = (uint8_t)(iagent[i] / S); v->init_agent_rc[i * 2 + 1] = (uint8_t)(iagent[i] % S); }
         if (v->goal_agent_rc) { v->goal_agent_rc[i * 2] = (uint8_t)(gagent[i] / S); v->goal_agent_rc[i * 2 + 1] = (uint8_t)(gagent[i] % S); }
@@ -1338,15 +1144,15 @@ struct CkptSection { void *dev; size_t bytes; };
 static std::vector<CkptSection> ckpt_sections(cw_engine *e)
 {
     const CwParams &P = e->P;
-    const size_t N = (size_t)e->n;
-    return {{P.hdr, N * 16}, {P.pos, N * 16}, {P.init_pos, N * 16}, {P.goal_pos, N * 16}, {P.goal_codes, N * 4},
-            {P.init_agent, N * 2}, {P.goal_agent, N * 2}, {P.ep_no, N * 4}, {P.mt, N * CW_MT_N * 4}, {P.mt_idx, N * 4},
-            {P.pool, N * (size_t)e->K * 9 * 2}, {P.reward, N * 4}, {P.done, N}, {P.achieved_out, N * 2}, {P.desired_out, N * 2},
-            {P.episode_length, N * 4}, {P.episode_return, N * 4},
-            {P.counters, 5 * 8},     // (the four public counters and the sweep's private word: a resumed engine's first sweep sees what it would have seen)
-            // the look-ahead records, verbatim (the RNG streams above are one reset ahead wherever one waits)
-            {P.nx_init_pos, P.lookahead ? N * 16 : 0}, {P.nx_goal_pos, P.lookahead ? N * 16 : 0}, {P.nx_misc, P.lookahead ? N * 16 : 0},
-            {P.refill_list, P.lookahead ? N * 4 : 0}, {P.refill_count, P.lookahead ? (size_t)8 : 0}};
+    // (file order; the sizes are cw_host.cpp's: cwh_ckpt_section_bytes -- the RNG streams are one reset ahead wherever a look-ahead record waits)
+    void *dev[CWH_CKPT_SECTIONS] = {P.hdr, P.pos, P.init_pos, P.goal_pos, P.goal_codes, P.init_agent, P.goal_agent, P.ep_no, P.mt, P.mt_idx, P.pool, P.reward, P.done,
+                                    P.achieved_out, P.desired_out, P.episode_length, P.episode_return, P.counters, P.nx_init_pos, P.nx_goal_pos, P.nx_misc,
+                                    P.refill_list, P.refill_count};
+    size_t bytes[CWH_CKPT_SECTIONS];
+    const int n = cwh_ckpt_section_bytes(e->n, e->K, e->P.lookahead, bytes, nullptr);
+    std::vector<CkptSection> out;
+    for (int i = 0; i < n; i++) out.push_back({dev[i], bytes[i]});
+    return out;
 }
 static uint64_t menus_hash(const cw_engine *e)
 {

@@ -155,8 +155,8 @@ from hypothesis import given, settings, strategies as st  # noqa: E402
 def test_mt_conversion_property(seed, burn, draws):
     """For any numpy RandomState state: to engine form, consume `draws` words with the engine's
     recurrence, export back -> numpy continues with the identical stream (and the raw words match)."""
-    from gym_craftingworld_amd import _lib
-    lib = _lib.load()
+    from hostlib import host_lib
+    lib = host_lib()[1]
     rs = np.random.RandomState(seed)
     if burn:
         rs.randint(0, 2**32, size=burn, dtype=np.uint32)
@@ -182,8 +182,8 @@ def test_mt_rewind_property(seed, burn, ahead):
     by the record's draws (cwh_mt_rewind: within the generation, and through cwh_mt_untwist across any number of generations).  For any state:
     export `ahead` draws later (through the engine form, as cw_get_mt does), rewind by `ahead` -> the stream from the state `burn` draws in,
     the same position modulo 624 and the same key words from there on."""
-    from gym_craftingworld_amd import _lib
-    lib = _lib.load()
+    from hostlib import host_lib
+    lib = host_lib()[1]
     rs = np.random.RandomState(seed)
     if burn:
         rs.randint(0, 2**32, size=burn, dtype=np.uint32)
