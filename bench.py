@@ -129,10 +129,12 @@ def cpu_baseline(size, max_steps, seconds=12.0, spare_cores=0):
                               'other_obs_modes_1gpu.pixels_dirty)',
                 reference_note='the reference itself (pure Python) cannot travel to the GPU box; BASELINE.md §2 has it at '
                                '64-78 k env-steps/s on one 2.1 GHz Xeon core (measured in the build container)',
-                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset), %.1f s on %d OpenMP threads (the cgroup CPU share, minus one for the '
-                       'thread that keeps the GPU soak leg going beside it) '
+                sample='%d envs x %d steps (%dx%d, max_steps=%d, auto-reset), %.1f s on %d OpenMP threads (%s) '
                        'with a full render() per step -> value; x %d steps, %.1f s with the reference\'s dirty-cell repaint -> '
-                       'dirty_cell_value' % (n, T0 * reps_full, size, size, max_steps, dt_full, cores, T0 * reps, dt))
+                       'dirty_cell_value' % (n, T0 * reps_full, size, size, max_steps, dt_full, cores,
+                                             'the whole cgroup CPU share, nothing else running in this process' if spare_cores == 0 else
+                                             'the cgroup CPU share minus %d for the thread that keeps the GPU soak leg going beside it' % spare_cores,
+                                             T0 * reps, dt))
 
 
 def single_env_latency(device, steps=200, repeats=5):
@@ -297,6 +299,10 @@ def main():
                          'the final frames and the reward / done of every step of this rank\'s shard to --shard-out/rank<r>.npz and exit '
                          '(tests: shards of self-launched ranks == the single-batch run)')
     ap.add_argument('--shard-out', default='gpurun_out/shard_check')
+    ap.add_argument('--inject-sleep-ms', type=float, default=0.0,
+                    help='test hook: the rank named by --inject-sleep-rank sleeps this long on the HOST between its last launch of a timed region and the '
+                         'closing barrier (a late rank at the barrier must show in value_wall only, not in value: the region is timed on the device)')
+    ap.add_argument('--inject-sleep-rank', type=int, default=1)
     ap.add_argument('--quick', action='store_true',
                     help='profiling runs (rocprofv3 / PMC passes serialise kernels): only the contract regions -- no repeats, no metric '
                          'window, no other modes, no single env, no CPU baseline')
@@ -469,18 +475,40 @@ def main():
     run(W, 0)
     red_dev = dev if args.dist_backend == 'nccl' else 'cpu'
 
+    # The timed region: barrier + synchronize on both sides, as the contract says -- and INSIDE it two events on the launch stream, one right after
+    # the opening barrier (the stream is idle then), one behind the last step's launches.  `value` is computed from the slowest rank's DEVICE span
+    # between the two: the k steps themselves.  The wall clock around the whole bracket also holds the closing barrier (100-200 us of RCCL at N > 1, nothing
+    # at N = 1: at the driver's K = 20 that is 2-5 % of a 4-ms region read as scaling loss) and the host's wake-up after the last kernel; it is kept
+    # beside it as value_wall.  SURVEY 8e: the scaling limit of this path is host launch overhead, not the interconnect -- so the barrier is not measured.
     def timed_region(k, t_off):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
+        e0.record()
         run(k, t_off)
+        e1.record()
+        if args.inject_sleep_ms > 0 and rank == args.inject_sleep_rank:
+            time.sleep(args.inject_sleep_ms * 1e-3)
         barrier()
-        timed_region.mine = time.perf_counter() - t0
+        timed_region.mine_wall = time.perf_counter() - t0
+        timed_region.mine = e0.elapsed_time(e1) * 1e-3
+        timed_region.wall = max_over_ranks(timed_region.mine_wall, device=red_dev, group=timing_group)
         return max_over_ranks(timed_region.mine, device=red_dev, group=timing_group)
 
     elapsed = timed_region(K, W)                     # THE timed region of the contract: exactly K steps after W warm-up steps
+    elapsed_wall = timed_region.wall
+    timed_region_first = (timed_region.mine, timed_region.mine_wall)
     per_rank_s = gather_over_ranks(timed_region.mine, device=red_dev, group=timing_group)      # (once, after the region: who was the slowest?)
+    per_rank_wall_s = gather_over_ranks(timed_region.mine_wall, device=red_dev, group=timing_group)
+    barrier()                                        # what an empty barrier pair costs this rank (control plane; explains value_wall - value at N > 1)
+    tb = time.perf_counter()
+    barrier()
+    barrier_ms = (time.perf_counter() - tb) * 1e3
     # ... and twice more (the driver's K may be tiny: 20 steps are 5 ms); `value` stays the first region
-    repeats_s = [elapsed] + ([] if args.quick else [timed_region(K, W + (r + 1) * K) for r in range(2)])
+    repeats_s, repeats_wall_s = [elapsed], [elapsed_wall]
+    for r in range(0 if args.quick else 2):
+        repeats_s.append(timed_region(K, W + (r + 1) * K))
+        repeats_wall_s.append(timed_region.wall)
     t_next = W + 3 * K
 
     # second, identical K-step region with the library's HIP events around each kernel (eager launches:
@@ -506,7 +534,8 @@ def main():
         'rank': rank, 'device': local_rank, 'envs': [lo, hi], 'tuner': tuner, 'numa': numa,
         'sweep_ms': prof['ms_render_kernel'] or None, 'sweep_ms_median': prof['ms_render_kernel_median'] or None,
         'roofline_frac': (own_bytes / (prof['ms_render_kernel'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.obs_mode == 'pixels' and prof['ms_render_kernel'] > 0 else None,
-        'ms_per_step_with_events': elapsed_prof / K * 1e3})
+        'ms_per_step_with_events': elapsed_prof / K * 1e3, 'barrier_ms': barrier_ms,
+        'region_ms_device': timed_region_first[0] * 1e3, 'region_ms_wall': timed_region_first[1] * 1e3})
     episodes = int(env.counters[1].item())
     resets_in_prof = episodes - episodes_before_prof      # envs reset (and repainted: 3 frames each) inside the profiled launches
 
@@ -518,6 +547,7 @@ def main():
         KW_ = 2 * args.max_steps
         ep0 = int(env.counters[1].item())
         win_elapsed = timed_region(KW_, t_next)
+        win_wall = timed_region.wall
         win_episodes = int(env.counters[1].item()) - ep0
         t_next += KW_
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(KW_ + 1)]
@@ -532,7 +562,7 @@ def main():
         t_next += KW_
         step_ms = sorted((evs[t].elapsed_time(evs[t + 1]) for t in range(KW_)), reverse=True)
         window = {'steps': KW_, 'value': float(N) * world * KW_ / win_elapsed, 'unit': 'env-steps/s',
-                  'ms_per_step': win_elapsed / KW_ * 1e3, 'episodes_finished': win_episodes,
+                  'ms_per_step': win_elapsed / KW_ * 1e3, 'value_wall': float(N) * world * KW_ / win_wall, 'episodes_finished': win_episodes,
                   'slowest_step_ms': step_ms[:2], 'median_step_ms': step_ms[KW_ // 2],
                   'render_kernel_ms_avg': win_prof['ms_render_kernel'] or None,
                   'launch': 'eager',
@@ -550,6 +580,7 @@ def main():
         torch.cuda.synchronize(dev)
         ep0 = int(env.counters[1].item())
         wd_elapsed = timed_region(KW_, t_next)
+        wd_wall = timed_region.wall
         wd_episodes = int(env.counters[1].item()) - ep0
         t_next += KW_
         env.profile_begin(KW_)
@@ -564,6 +595,7 @@ def main():
         wd_bytes = float(N) * (S_ * S_ + frame_)        # (the bracketed kernel is the sweep of the observation array alone)
         wd_ms = wd_prof['ms_render_kernel']
         window_desync = {'steps': KW_, 'value': float(N) * world * KW_ / wd_elapsed, 'unit': 'env-steps/s', 'ms_per_step': wd_elapsed / KW_ * 1e3,
+                         'value_wall': float(N) * world * KW_ / wd_wall,
                          'episodes_finished': wd_episodes, 'resets_per_step': wd_episodes / KW_,
                          'roofline': {'kernel': render_kernel, 'avg_launch_ms': wd_ms, 'median_launch_ms': wd_prof['ms_render_kernel_median'] or None,
                                       'achieved': wd_bytes / (wd_ms * 1e-3) / 1e9 if wd_ms > 0 else None,
@@ -653,18 +685,22 @@ def main():
                         'library\'s events around the sweep and torch events around the consumer; episode phases as the regions above left '
                         'them (%s)' % (KC, 'spread out' if (window_desync or args.desync) else 'in step')}
 
-    # THE CPU BASELINE, and beside it a GPU SOAK.  The oracle's ~12 s of OpenMP work used to close the run with the card idle (round 4: the driver's
-    # gpu_busy sampler saw 0 of 3 samples busy in a 15-s run with ~2 s of GPU work).  Now it runs in a thread (ctypes drops the GIL; one core is left
-    # to this thread) while this thread keeps stepping the headline batch: a 10-s soak -- ~45 000 consecutive steps, episode phases as the regions above
-    # left them, the clock's guard on -- whose own rate, sweep time and guard moves are worth having (the tuned constants outside a 600-step window).
+    # THE CPU BASELINE -- ALONE: the oracle on the whole CPU share with this process doing nothing else (round 5 timed it beside the soak's Python launch
+    # loop, which contends for the GIL around every ctypes call and for memory bandwidth: 6.7-6.9 M env-steps/s on 15 threads against 7.7-8.0 M on 16
+    # in round 4 -- a GPU/CPU ratio inflated by 13 %).  `cpu_baseline.value` is this uncontended figure.
+    # Then a GPU SOAK beside a SECOND, shorter oracle run (reported as cpu_baseline.beside_gpu_soak, never as the baseline): ~6 s of consecutive steps of the
+    # headline batch, episode phases as the regions above left them, the clock's guard on -- the tuned constants outside a 600-step window, and a busy host
+    # beside the card as a training loop would have it.
     cpu_result, soak = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import threading
+        torch.cuda.synchronize(dev)
+        cpu_result = cpu_baseline(args.size, args.max_steps, args.cpu_seconds, spare_cores=0)
         box = {}
 
         def _cpu():
             try:
-                box['r'] = cpu_baseline(args.size, args.max_steps, args.cpu_seconds, spare_cores=1)
+                box['r'] = cpu_baseline(args.size, args.max_steps, max(0.5 * args.cpu_seconds, 0.25), spare_cores=1)
             except Exception as exc:  # noqa: BLE001
                 box['e'] = exc
         th = threading.Thread(target=_cpu, daemon=True)
@@ -686,7 +722,10 @@ def main():
         th.join()
         if 'e' in box:
             raise box['e']
-        cpu_result = box['r']
+        cpu_result['beside_gpu_soak'] = {k: box['r'][k] for k in ('value', 'dirty_cell_value', 'cores', 'sample')}
+        cpu_result['beside_gpu_soak']['single_env_one_core'] = box['r']['single_env_one_core']['value']
+        cpu_result['beside_gpu_soak']['note'] = ('the same oracle run again while this process keeps the GPU soak leg going (a Python launch loop: GIL and memory '
+                                                 'bandwidth shared): NOT the baseline')
         t_next += n_soak
         tuner1 = env.tuner_state()
         if args.obs_mode == 'pixels':                    # the sweep's own time at the end of the soak (library events, 300 steps)
@@ -706,7 +745,7 @@ def main():
                 'tuner_before': tuner0, 'tuner_after': tuner1, 'guard_moves': tuner1['guard_slowdowns'] - tuner0['guard_slowdowns'],
                 'sweep_after': ({'avg_launch_ms': sp['ms_render_kernel'], 'median_launch_ms': sp['ms_render_kernel_median'],
                                  'frac': float(N) * (S_ * S_ + frame_) / (sp['ms_render_kernel'] * 1e-3) / 1e9 / HBM_PEAK_GBS} if sp and sp['ms_render_kernel'] > 0 else None),
-                'note': 'eager steps of the headline batch for as long as the CPU baseline ran beside it (one thread of the CPU share left to this loop); the '
+                'note': 'eager steps of the headline batch for as long as a second run of the CPU oracle ran beside it (one thread of the CPU share left to this loop); the '
                         'host waits for the card every 4 096 steps; episode phases %s' % ('spread out' if (window_desync or args.desync) else 'in step')}
 
     # side measurements (rank 0's GPU only, short): the same batch in the two cheaper observation modes.
@@ -850,6 +889,11 @@ def main():
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u8', 'data': 'synthetic',
+            # the same K steps by the wall clock around the whole bracket (opening barrier ... closing barrier + synchronize), max over ranks
+            'value_wall': total_steps / elapsed_wall, 'ms_per_step_wall': elapsed_wall / K * 1e3,
+            'timing': 'value / ms_per_step: the slowest rank\'s DEVICE time for the K steps -- two events on the launch stream inside the barrier + synchronize '
+                      'bracket, the first right behind the opening barrier, the second behind the last step; value_wall: the wall clock around the bracket, '
+                      'which also holds the closing barrier (per_rank[].barrier_ms) and the host\'s wake-up',
             'config': {'workload': 'BASELINE configs[2]: %d envs/GPU, %dx%d grid, %s obs, auto-reset, uniform random '
                                    'actions, max_steps=%d' % (N, S, S, {'pixels': 'full-frame 4x4-cell uint8 pixel',
                                                                         'pixels_dirty': 'dirty-cell-repaint pixel',
@@ -893,11 +937,12 @@ def main():
             'episodes_finished': episodes, 'prewarm_steps': prewarm_steps,
             'warmup_total': prewarm_steps + W,           # untimed steps before the timed region: `warmup` is the contract's W
             'per_rank_ms_per_step': [x / K * 1e3 for x in per_rank_s],
+            'per_rank_ms_per_step_wall': [x / K * 1e3 for x in per_rank_wall_s],
             'per_rank_tuner': [r_['tuner'] for r_ in per_rank],
             'per_rank_roofline_frac': [r_['roofline_frac'] for r_ in per_rank],
             'per_rank': per_rank,
             'repeats': {'n': len(repeats_s), 'ms_per_step': [x / K * 1e3 for x in repeats_s],
-                        'value': [total_steps / x for x in repeats_s], 'value_min': total_steps / max(repeats_s),
+                        'value': [total_steps / x for x in repeats_s], 'value_wall': [total_steps / x for x in repeats_wall_s], 'value_min': total_steps / max(repeats_s),
                         'value_median': total_steps / sorted(repeats_s)[len(repeats_s) // 2],
                         'note': 'the K-step region three times back to back; `value` is the first'},
             'metric_window': window,

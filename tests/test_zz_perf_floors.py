@@ -94,8 +94,10 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    # (rank 1 sleeps 30 ms on the host between its last launch and the closing barrier: a late rank at the barrier must not show in `value`)
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-on-one-gpu', '--dist-backend', 'gloo',
-                        '--quick', '--steps', '12', '--warmup', '3', '--envs-per-gpu', '4096', '--max-steps', '20'],
+                        '--quick', '--steps', '12', '--warmup', '3', '--envs-per-gpu', '4096', '--max-steps', '20', '--inject-sleep-ms', '30',
+                        '--inject-sleep-rank', '1'],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith('{')]
@@ -104,11 +106,18 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert d['n_gpus'] == 2 and d['steps'] == 12 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['dist_backend'] == 'gloo'
     assert d['config']['envs_per_gpu'] == 4096 and d['value'] > 0
     assert abs(d['value'] - 2 * 4096 * 12 / (d['ms_per_step'] * 12e-3)) < 1e-6 * d['value']      # whole-job rate over both ranks
+    # multi-rank regions are timed ON THE DEVICE (two events inside the barrier bracket): the 30 ms rank 1 spent asleep before the closing barrier are in
+    # value_wall (the wall clock around the bracket, max over ranks) and nowhere in value
+    assert abs(d['value_wall'] - 2 * 4096 * 12 / (d['ms_per_step_wall'] * 12e-3)) < 1e-6 * d['value_wall'] and 'DEVICE' in d['timing']
+    assert d['ms_per_step_wall'] * 12 >= 30.0 > d['ms_per_step'] * 12, (d['ms_per_step_wall'], d['ms_per_step'])
+    assert d['per_rank_ms_per_step_wall'][1] * 12 >= 30.0 and max(d['per_rank_ms_per_step']) * 12 < 30.0
+    assert abs(max(d['per_rank_ms_per_step']) - d['ms_per_step']) < 1e-9
     # every rank explains itself on rank 0's line: its shard, its clock and guard, its sweep time against the roof, its NUMA binding (or why not)
     pr = d['per_rank']
     assert [r['rank'] for r in pr] == [0, 1] and [r['envs'] for r in pr] == [[0, 4096], [4096, 8192]]
     assert all(r['tuner']['guard_slowdowns'] in (-1, 0) and 'period16' in r['tuner'] for r in pr)
     assert all(0 < r['roofline_frac'] < 1 and r['sweep_ms'] > 0 for r in pr) and d['per_rank_roofline_frac'] == [r['roofline_frac'] for r in pr]
+    assert all(r['barrier_ms'] > 0 and r['region_ms_wall'] >= r['region_ms_device'] > 0 for r in pr)
     assert all('skipped' in r['numa'] and 'rehearsal' in r['numa']['skipped'] for r in pr) and len(d['per_rank_tuner']) == 2
     assert d['policy_in_loop'] is None                   # (--quick)
 
@@ -159,6 +168,12 @@ def test_bench_json_line_carries_the_contract():
     for b in pl.values():
         assert b['consumer_ms'] > 0 and b['ms_per_step'] > b['consumer_ms'] and 0 < b['sweep']['frac'] < 1 and b['guard_moves'] >= 0
         assert abs(b['env_ms_per_step'] - (b['ms_per_step'] - b['consumer_ms'])) < 1e-9 and 'tuner_after' in b
+    # round 6: the region timed on the device (value) beside the wall clock around the bracket (value_wall); the CPU baseline measured ALONE on the whole CPU
+    # share, the soak beside a second run of it
+    assert d['value_wall'] > 0 and d['ms_per_step_wall'] >= d['ms_per_step'] * 0.999 and 'timing' in d and d['per_rank'][0]['barrier_ms'] >= 0
+    assert len(d['repeats']['value_wall']) == 3 and d['metric_window']['value_wall'] > 0 and wd['value_wall'] > 0
+    bs = c['beside_gpu_soak']
+    assert bs['cores'] == max(1, c['cores'] - 1) and bs['value'] > 0 and 'nothing else running' in c['sample'] and 'minus 1' in bs['sample']
     sk = d['soak_beside_cpu_baseline']
     assert sk['steps'] >= 256 and sk['value'] > 0 and sk['guard_moves'] >= 0 and c['cores'] >= 1 and c['single_env_one_core']['value'] > 0
     assert len(d['per_rank']) == 1 and d['per_rank'][0]['numa'] == {'skipped': 'single rank'} and d['per_rank_roofline_frac'] == [r['frac']]
