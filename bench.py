@@ -358,8 +358,9 @@ def main():
         # on whether RCCL works.  RCCL (backend "nccl") is a second group for the two timing collectives; no data-path collective exists.
         # sharding.agree_on_rccl: every rank publishes its status over gloo after creating the group and again after one all-reduce on it --
         # everybody uses RCCL or nobody does, whatever subset of ranks saw a failure.  The RCCL group waits in blocking mode
-        # (TORCH_NCCL_BLOCKING_WAIT=1, set there): a rank whose peers never arrive in the probe gets an exception after the group's 60-s timeout
-        # and joins the agreement; torch's asynchronous error handling keeps its default, so a collective that hangs later ends the rank non-zero.
+        # (TORCH_NCCL_BLOCKING_WAIT=1 while it is created, restored afterwards): a rank whose peers never arrive in the probe gets an exception after
+        # the group's 60-s timeout and joins the agreement; a timing collective that hangs later raises from its wait() after the same timeout (blocking
+        # wait switches the watchdog's asynchronous error handling off for this group), the rank ends non-zero and launch.py stops the others.
         dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         backend_used = args.dist_backend
         if args.dist_backend == 'nccl':

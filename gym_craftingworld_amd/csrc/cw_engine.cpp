@@ -96,6 +96,7 @@ struct cw_engine {
     unsigned la_steps = 0;
     unsigned la_period = 16;
     bool in_step_many = false;         // (cw_step_many decides about the refill of a captured sequence itself)
+    bool capturing_now = false;        // ... and asks once whether its stream is capturing, for all of its steps
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
     int sweep_waves = 1024;            // waves of a sweep's launch, jobs (4-KiB pieces) per wave over all of its launches
     double sweep_jobs = 0, sweep_rate = 0, sweep_beside_ms = 0;      // (sweep_rate: cw_create's choice; the live one is guard.rate)
@@ -113,8 +114,16 @@ struct cw_engine {
     hipStream_t work[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_work = 0;
     bool work_overflow = false;        // more than 4 distinct streams since the last wait: a device-wide wait is the only safe one
+    bool captured = false;             // STICKY: a step / rollout of this engine has been captured into a HIP graph.  Replays run on whatever stream the caller
+                                       // launches the graph on, which the engine never sees: from then on every synchronous entry point waits for the DEVICE
 };
-// every entry point that ENQUEUES on a caller's stream notes it ...
+// is `st` recording a graph right now?  (an error counts as no: the launch that follows reports it)
+static inline bool stream_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+}
+// every entry point that ENQUEUES on a caller's stream notes it (NOT a capturing stream: nothing runs on it, and it may be gone when the graph is replayed) ...
 static inline void note_work(cw_engine *e, hipStream_t st)
 {
     for (int i = 0; i < e->n_work; i++) if (e->work[i] == st) return;
@@ -125,7 +134,7 @@ static inline void note_work(cw_engine *e, hipStream_t st)
 // wait: then, and only then, the whole device is waited for.
 static hipError_t quiesce(cw_engine *e)
 {
-    bool all = e->work_overflow;
+    bool all = e->work_overflow || e->captured;
     for (int i = 0; i < e->n_work && !all; i++)
         if (hipStreamSynchronize(e->work[i]) != hipSuccess) { (void)hipGetLastError(); all = true; }
     e->n_work = 0;
@@ -133,6 +142,13 @@ static hipError_t quiesce(cw_engine *e)
     if (all) return hipDeviceSynchronize();
     return e->aux ? hipStreamSynchronize(e->aux) : hipSuccess;
 }
+// The synchronous entry points copy with hipMemcpyAsync on e->aux into / out of vectors and stack buffers of their own: whatever way such a function
+// is left -- an early return on an error included -- nothing may still be in flight against storage that dies with its frame.
+struct AuxDrain {
+    cw_engine *e;
+    explicit AuxDrain(cw_engine *e_) : e(e_) {}
+    ~AuxDrain() { if (e && e->aux) (void)hipStreamSynchronize(e->aux); }
+};
 static inline hipError_t aux_copy(cw_engine *e, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
     return bytes ? hipMemcpyAsync(dst, src, bytes, kind, e->aux) : hipSuccess;
@@ -298,8 +314,6 @@ enum { CW_GUARD_EVERY = 64 };
 static hipEvent_t *sweep_guard_tick(cw_engine *e, hipStream_t st)
 {
     if (++e->guard_step % CW_GUARD_EVERY) return nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;     // (a captured graph keeps the rate it was captured with)
     const bool verbose = getenv("CW_TUNE_VERBOSE") != nullptr;
     // the samples whose sweeps have run by now, oldest first (the host may be a thousand steps ahead of the card: a sample is read long after it was recorded)
     while (e->guard_tail != e->guard_head && hipEventQuery(e->guard_ring[e->guard_tail % cw_engine::GUARD_RING].ev[5]) == hipSuccess) {
@@ -562,6 +576,7 @@ int cw_seed_mt(cw_engine *e, const uint32_t *keys, const int32_t *pos)
     for (size_t i = 0; i < N; i++)
         if (pos[i] < 0 || pos[i] > CW_MT_N) return fail(CW_ERR_INVALID, "cw_seed_mt: pos[%zu]=%d outside 0..624", i, pos[i]);
     HIP_TRY(quiesce(e));                              // (the engine's own work, not the card's)
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, e->P.mt, keys, N * CW_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(aux_copy(e, e->P.mt_idx, pos, N * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, nullptr, e->aux));
@@ -577,6 +592,7 @@ int cw_seed_int(cw_engine *e, const uint32_t *seeds)
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, e->seed_scratch, seeds, (size_t)e->n * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(cwk_launch_seed(&e->P, e->seed_scratch, e->aux));
     HIP_TRY(lookahead_drop(e));
@@ -594,6 +610,7 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     std::vector<uint32_t> words(N * CW_MT_N);
     std::vector<uint32_t> misc(e->P.lookahead ? N * 4 : 0);
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(aux_copy(e, pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (e->P.lookahead) HIP_TRY(aux_copy(e, misc.data(), e->P.nx_misc, N * 16, hipMemcpyDeviceToHost));
@@ -656,15 +673,14 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
-    if (e->n_work != 1 || e->work[0] != (hipStream_t)stream) note_work(e, (hipStream_t)stream);
+    const bool capturing = e->in_step_many ? e->capturing_now : stream_capturing((hipStream_t)stream);
+    if (capturing) e->captured = true;
+    else if (e->n_work != 1 || e->work[0] != (hipStream_t)stream) note_work(e, (hipStream_t)stream);
     hipEvent_t *ev = (e->prof_n < e->prof_cap) ? &e->prof_ev[(size_t)e->prof_n * 6] : nullptr;
     const bool profiled = ev != nullptr;
-    if (e->guard_on && !ev) ev = sweep_guard_tick(e, (hipStream_t)stream);
-    if (e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < e->la_period && !e->in_step_many) {
-        // a step captured into a HIP graph on its own carries the refill with it: a replayed graph would otherwise never refill
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = e->la_period;
-    }
+    if (e->guard_on && !ev && !capturing) ev = sweep_guard_tick(e, (hipStream_t)stream);       // (a captured graph keeps the rate it was captured with)
+    // a step captured into a HIP graph on its own carries the refill with it: a replayed graph would otherwise never refill
+    if (capturing && e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < e->la_period && !e->in_step_many) e->la_steps = e->la_period;
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= e->la_period)) {      // look-ahead refill, between two steps
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -684,8 +700,8 @@ int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_
     if (!e || !actions) return fail(CW_ERR_INVALID, "cw_step_many: null argument");
     if (n_steps < 1) return fail(CW_ERR_INVALID, "cw_step_many: n_steps must be >= 1");
     if (action_dtype < CW_ACT_I32 || action_dtype > CW_ACT_U8) return fail(CW_ERR_INVALID, "cw_step_many: bad action dtype %d", action_dtype);
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (e->P.lookahead && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) e->la_steps = e->la_period;
+    e->capturing_now = stream_capturing((hipStream_t)stream);
+    if (e->P.lookahead && e->capturing_now) e->la_steps = e->la_period;
     const size_t row = (size_t)e->n * (action_dtype == CW_ACT_I32 ? 4 : action_dtype == CW_ACT_I64 ? 8 : 1);
     e->in_step_many = true;
     int rc = CW_OK;
@@ -772,7 +788,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     DeviceGuard guard(e->device);
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
-    note_work(e, (hipStream_t)stream);
+    if (stream_capturing((hipStream_t)stream)) e->captured = true; else note_work(e, (hipStream_t)stream);
     if (e->P.lookahead) {
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
@@ -956,6 +972,7 @@ int cw_get_fixed_states(cw_engine *e, uint16_t *out)
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, out, e->P.pool, (size_t)e->n * e->K * 9 * sizeof(uint16_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipStreamSynchronize(e->aux));
     return CW_OK;
@@ -974,6 +991,7 @@ int cw_get_state(cw_engine *e, cw_state_view *v)
     std::vector<uint16_t> pos(N * 8), ipos(N * 8), gpos(N * 8), iagent(N), gagent(N);
     std::vector<int32_t> epno(N);
     HIP_TRY(quiesce(e));                              // (the engine's own work; copies on its private stream)
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, hdr.data(), e->P.hdr, N * 16, hipMemcpyDeviceToHost));
     HIP_TRY(aux_copy(e, pos.data(), e->P.pos, N * 16, hipMemcpyDeviceToHost));
     HIP_TRY(aux_copy(e, ipos.data(), e->P.init_pos, N * 16, hipMemcpyDeviceToHost));
@@ -1015,6 +1033,7 @@ int cw_set_state(cw_engine *e, const cw_state_view *v)
     std::vector<int32_t> epno(N);
     const bool restore_episode = v->goal_grid || v->goal_agent_rc || v->init_agent_rc;
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     if (restore_episode) {                           // the episode records: goal state (imagine_obs' result) and the agent's start cell
         gpos.resize(N * 8); gagent.resize(N); iagent.resize(N); gcodes.resize(N);
         HIP_TRY(aux_copy(e, gpos.data(), e->P.goal_pos, N * 16, hipMemcpyDeviceToHost));
@@ -1190,6 +1209,7 @@ int cw_checkpoint_save(cw_engine *e, void *buf, size_t capacity)
     const CwCkptHeader h = ckpt_header(e);
     if (capacity < h.total_bytes) return fail(CW_ERR_INVALID, "cw_checkpoint_save: buffer of %zu bytes, %llu needed", capacity, (unsigned long long)h.total_bytes);
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     unsigned char *p = (unsigned char *)buf;
     memcpy(p, &h, sizeof(h));
     p += sizeof(h);
@@ -1226,11 +1246,13 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     // other way round: the records are not state, only work done ahead -- where one waits, the env's stream is rewound by the draws it took
     // (cwh_mt_rewind) and the record dropped; an engine that keeps records recomputes them at its next refill.
     const size_t N = (size_t)e->n;
+    std::vector<uint32_t> key(CW_MT_N), words(CW_MT_N);      // (scratch of the rewind below; declared ahead of the drain guard: it outlives every copy)
     const size_t la_bytes = N * 16 * 3 + N * 4 + 8;
     const unsigned long long expect = mine.total_bytes + (h.lookahead && !mine.lookahead ? la_bytes : 0) - (!h.lookahead && mine.lookahead ? la_bytes : 0);
     if (h.total_bytes != expect || length < h.total_bytes)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
     HIP_TRY(quiesce(e));
+    AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     const unsigned char *p = (const unsigned char *)buf + sizeof(h);
     const unsigned char *blob_mt = nullptr, *blob_idx = nullptr;
     for (const CkptSection &sec : ckpt_sections(e)) {
@@ -1243,16 +1265,17 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
         p += sec.bytes;
     }
     if (h.lookahead && !mine.lookahead) {            // p: the file's look-ahead sections (nx_init_pos, nx_goal_pos, nx_misc, list, count)
-        const uint32_t *misc = (const uint32_t *)(p + N * 32);
-        std::vector<uint32_t> key(CW_MT_N), words(CW_MT_N);
+        const unsigned char *misc_bytes = p + N * 32;     // (nx_misc of the file: 4 words per env at an offset that need not be 4-byte aligned -- the 'done' section is N bytes)
         HIP_TRY(hipStreamSynchronize(e->aux));
         for (size_t i = 0; i < N; i++) {
-            if (!(misc[i * 4 + 2] >> 31)) continue;
+            uint32_t misc[4];
+            memcpy(misc, misc_bytes + i * 16, 16);
+            if (!(misc[2] >> 31)) continue;
             int32_t pos = 0;
             memcpy(&pos, blob_idx + i * 4, 4);
             memcpy(words.data(), blob_mt + i * CW_MT_N * 4, CW_MT_N * 4);
             cwh_mt_to_numpy(words.data(), pos, key.data());
-            cwh_mt_rewind(key.data(), &pos, misc[i * 4 + 3]);
+            cwh_mt_rewind(key.data(), &pos, misc[3]);
             const int32_t idx = cwh_mt_from_numpy(key.data(), pos);
             HIP_TRY(aux_copy(e, e->P.mt + i * CW_MT_N, key.data(), CW_MT_N * 4, hipMemcpyHostToDevice));
             HIP_TRY(aux_copy(e, e->P.mt_idx + i, &idx, 4, hipMemcpyHostToDevice));

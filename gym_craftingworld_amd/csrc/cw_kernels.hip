@@ -318,13 +318,16 @@ struct CwStepOut {
     uint32_t dirty0, dirty1;       // cells to repaint (render_edit): dirty1 = 0xFFFFFFFF if only one
     bool mark0, mark1;             // only the agent's mark came or went in that cell (a move that left the cell's object as it was): pixel rows 1, 2 suffice
     uint32_t step_num, achieved, desired;
+    uint32_t n_success;            // steps of this episode that returned MAX_STEPS so far, this one included (header flags bits 2-15)
 };
 
-// The finished episode's RETURN as the reference's loop sums it (ray.py:361-367: every step returns -1 except a successful last one, which
-// returns MAX_STEPS and ends the episode): MAX_STEPS - (step_num - 1) after a success, -step_num after a time-out.
+// The episode's RETURN so far as the reference's loop sums it (ray.py:361-367: a step returns MAX_STEPS when it leaves the goal satisfied, else -1):
+// n_success x MAX_STEPS - (step_num - n_success).  An engine that resets by itself ends the episode at its first done: MAX_STEPS - (step_num - 1)
+// after a success, -step_num after a time-out.  One WITHOUT auto-reset keeps stepping a finished env, as the reference does (ray.py:367), and a goal
+// that stays satisfied pays again on every step that changes the state: the header counts those steps (14 bits, saturating).
 __device__ __forceinline__ int32_t episode_return_of(const CwParams &P, const CwStepOut &o)
 {
-    return o.success ? P.max_steps - (int32_t)o.step_num + 1 : -(int32_t)o.step_num;
+    return (int32_t)o.n_success * (P.max_steps + 1) - (int32_t)o.step_num;
 }
 
 template <typename InitPosFn>
@@ -441,10 +444,11 @@ __device__ __forceinline__ CwStepOut step_env(const CwParams &P, uint4 &h, uint3
     o.step_num = step_num;
     o.achieved = achieved;
     o.desired = desired;
+    o.n_success = min((flags >> 2) + (o.success ? 1u : 0u), 0x3FFFu);
 
     h.x = (uint32_t)ar | ((uint32_t)ac << 8) | (hold << 16) | (h.x & 0xFF000000u);
     h.y = achieved | (desired << 16);
-    h.z = step_num | (flags << 16);
+    h.z = step_num | (((flags & 3u) | (o.n_success << 2)) << 16);
     h.w = codes;
     return o;
 }

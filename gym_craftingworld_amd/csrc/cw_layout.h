@@ -18,6 +18,8 @@
 // hdr.flags
 #define CW_FLAG_RESET 0x1u    // env was (re)set by the last cw_reset / auto-reset (render: also write desired/init frames)
 #define CW_FLAG_SUBSET 0x2u   // reward_style is not None (compute_reward_subset, ray.py:763-767)
+//   flags bits 2-15: steps of the running episode that returned MAX_STEPS (saturating at 16 383): the episode's return so far is a closed form of this count
+//   and step_num (episode_return_of) -- exact also where an env WITHOUT auto-reset is stepped on after its first done, as the reference allows (ray.py:367)
 
 // Packed header, one uint4 per env:
 //   x = agent_r | agent_c << 8 | hold << 16 | menu << 24

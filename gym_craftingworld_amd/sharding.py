@@ -63,12 +63,15 @@ def agree_on_rccl(device, timeout_s=60, new_group=None, log=None):
     by a MIN-reduce of the ranks' "ok" flags over gloo BEFORE anybody depends on the other ranks having got as far: (1) creating the group (nothing is
     sent yet: a rank that fails here keeps its peers out of RCCL's first collective, where they would otherwise wait out the group's timeout);
     (2) one all-reduce on it.  A group that failed is destroyed.  -> (group or None, None or the reason as text).  Needs the default (gloo) group.
-    The group is created with TORCH_NCCL_BLOCKING_WAIT=1 (unless the caller's environment says otherwise): a rank whose peers never arrive in the
+    THIS group is created with TORCH_NCCL_BLOCKING_WAIT=1 (unless the caller's environment says otherwise): a rank whose peers never arrive in the
     probe -- theirs threw -- gets an exception after `timeout_s` instead of a kernel that spins until somebody kills the job, reaches the second
-    round and lands on gloo with everybody else.  torch's asynchronous error handling stays at its default: should a later timing collective
-    hang, the watchdog ends the rank (non-zero) after the group's timeout and launch.py stops the others."""
+    round and lands on gloo with everybody else.  The variable is read when a group is created and is put back as it was right after: this is
+    library code, and the NCCL groups the host application creates later keep torch's own defaults.  For THIS group blocking wait also means
+    (ProcessGroupNCCL switches asynchronous error handling off with it) that a timing collective which hangs later does not end the rank through
+    the watchdog: it raises from the collective's wait() after the group's timeout -- bench.py's timing collectives are all waited on."""
     import datetime
     import os
+    had = os.environ.get('TORCH_NCCL_BLOCKING_WAIT')
     os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')      # (read when the group is created)
     new_group = new_group or dist.new_group
     world = dist.get_world_size()
@@ -83,6 +86,11 @@ def agree_on_rccl(device, timeout_s=60, new_group=None, log=None):
         group = new_group(backend='nccl', timeout=datetime.timedelta(seconds=timeout_s))
     except Exception as exc:  # noqa: BLE001
         why = 'creating the group: %s: %s' % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '')
+    finally:                                                    # (the process's environment as the caller left it)
+        if had is None:
+            os.environ.pop('TORCH_NCCL_BLOCKING_WAIT', None)
+        else:
+            os.environ['TORCH_NCCL_BLOCKING_WAIT'] = had
     if agreed(group is not None):
         try:
             probe = torch.ones(1, device=device)

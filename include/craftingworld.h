@@ -107,13 +107,16 @@ typedef struct cw_buffer_table {
     uint16_t *achieved;      /* [N]  achieved_goal_vector as a bit mask AFTER the step, BEFORE auto-reset */
     uint16_t *desired;       /* [N]  desired_goal_vector of the episode the step belonged to       */
     int32_t *episode_length; /* [N]  step_num at done (valid where done==1)                        */
-    int32_t *episode_return; /* [N]  sum of the rewards of the episode that just ended (valid where done==1), as the reference's loop sums
-                              *      them (ray.py:361-367: -1 per step, MAX_STEPS on a successful last step): max_steps - (length - 1)
-                              *      after a success, -length after a time-out                         */
+    int32_t *episode_return; /* [N]  sum of the episode's rewards up to a step that returned done==1 (valid where done==1), as the reference's
+                              *      loop sums them (ray.py:361-367: -1 per step, MAX_STEPS on a step that leaves the goal satisfied).  With
+                              *      auto_reset the episode ends there: max_steps - (length - 1) after a success, -length after a time-out.
+                              *      WITHOUT auto_reset a finished env keeps stepping until cw_reset (ray.py:367) and every later done step
+                              *      rewrites episode_length / episode_return with the sums up to that step, repeated success rewards included.
+                              *      cw_rollout writes both at EVERY done step of its n_steps, like n_steps calls of cw_step. */
     uint8_t *hdr;            /* [N][16] packed per-env header of the CURRENT state (after auto-reset):
                               *   byte 0 agent row, 1 agent col, 2 hold (0 none,1 sticks,2 axe,3 hammer), 3 menu id,
                               *   bytes 4-5 achieved mask (LE u16), 6-7 desired mask, 8-9 step_num, 10-11 flags (bit 0: no step
-                              *   taken yet in this episode, bit 1: subset reward rule),
+                              *   taken yet in this episode, bit 1: subset reward rule, bits 2-15: steps of this episode that returned max_steps),
                               *   bytes 12-15 the 8 object slots' codes, 4 bits each (slot k in bits 4k..4k+3)      */
     uint16_t *slot_pos;      /* [N][8] cell index (row*S+col) of object slot k; 0xFFFF gone, 0xFFFE held          */
     uint64_t *counters;      /* [4]  {env-steps, episodes finished, successes (reward==max_steps), invalid actions}; the allocation holds

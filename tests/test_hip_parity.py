@@ -1348,6 +1348,43 @@ def test_frames_do_not_depend_on_the_sweeps_clock(rate, monkeypatch):
     e.close(); dirty.close()
 
 
+@pytest.mark.parametrize('obs_mode,reward_style', [('state', None), ('pixels_dirty', 'subset')])
+def test_episode_statistics_of_envs_stepped_past_done_without_auto_reset(obs_mode, reward_style):
+    """An engine WITHOUT auto-reset keeps stepping a finished env until reset(), as the reference does (ray.py:367): a goal that stays satisfied pays
+    MAX_STEPS again on every step that changes the state, time-outs stay done.  info['episode'] = {'r', 'l'} at every done step must be the SUM of
+    the rewards the oracle returned since the reset, and the step count -- not the closed form of an episode that stopped at its first done."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleEnv
+    N, T, kw = 384, 70, dict(size=(5, 5), max_steps=14, reward_style=reward_style, selected_tasks=['MoveAxe', 'MoveSticks', 'GoToHouse', 'EatBread'], number_of_tasks=1)
+    keys, pos = _np_states(N, 31000)
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, auto_reset=False, **kw)
+    env.set_rng_states(keys, pos)
+    env.reset()
+    oras = [OracleEnv(rng_state=(keys[i], int(pos[i])), **kw) for i in range(N)]
+    for o in oras:
+        o.reset()
+    acts = np.random.RandomState(5).randint(0, 6, size=(T, N))
+    ret = np.zeros(N, np.int64)
+    repeated = checked = 0
+    n_succ = np.zeros(N, np.int64)
+    for t in range(T):
+        _, rew, done, info = env.step(torch.as_tensor(acts[t], device=env.device))
+        o_r = np.empty(N, np.int64)
+        o_d = np.empty(N, bool)
+        for i, o in enumerate(oras):
+            _, o_r[i], o_d[i], _ = o.step(int(acts[t, i]))
+        ret += o_r
+        n_succ += o_r == kw['max_steps']
+        assert np.array_equal(rew.cpu().numpy(), o_r) and np.array_equal(done.cpu().numpy(), o_d), t
+        if o_d.any():
+            assert np.array_equal(info['episode']['r'].cpu().numpy()[o_d], ret[o_d]), ('episode return', t)
+            assert np.array_equal(info['episode']['l'].cpu().numpy()[o_d], np.full(N, t + 1)[o_d]), ('episode length', t)
+            checked += int(o_d.sum())
+            repeated += int((n_succ[o_d] >= 2).sum())
+    assert checked > N * (T - 14) and repeated > 50          # (every env is done from step 14 on; many were paid more than once)
+    env.close()
+
+
 @pytest.mark.gpu
 def test_full_frame_soak_equals_dirty_cell_engine(monkeypatch):
     """3 000 steps of 65 536 full-frame envs with the episode phases spread out (~220 envs finish on every step and take their look-ahead
@@ -2194,6 +2231,40 @@ def test_synchronous_calls_wait_for_the_engines_own_streams_only():
     b.reset()
     torch.cuda.synchronize()
     assert torch.equal(a.hdr, b.hdr) and torch.equal(a._obs, b._obs) and torch.equal(a.counters, b.counters)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_synchronous_calls_after_a_graph_replay_wait_for_the_device():
+    """A HIP graph captured from cw_step_many replays on whatever stream the caller launches it on -- one the engine was never handed.  Since round 5 the
+    synchronous entry points wait for the engine's OWN streams only; an engine whose steps have ever been captured therefore falls back to a device-wide
+    wait (a sticky flag, set at capture): get_state / get_rng_states / save_checkpoint right behind replays on a side stream, with the Python layer's own
+    wait switched off, must see every replayed step."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    N, K, R = 30000, 16, 40
+    kw = dict(size=(21, 21), max_steps=23, obs_mode='pixels', seed=9)
+    a, b = CraftingWorldVecEnv(N, **kw), CraftingWorldVecEnv(N, **kw)
+    acts = torch.randint(0, 6, (K, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(4))
+    a.reset(), b.reset()
+    graph = a.capture_steps(acts)
+    torch.cuda.synchronize()
+    a._settle = lambda: None                             # (only the library's own wait is under test)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(R):
+            graph.replay()                               # R x K sweeps of 30 000 frames queued on `side`: ~60 ms of work
+    sa = a.get_state()                                   # ... and no wait by the caller
+    ka, pa = a.get_rng_states()
+    for _ in range(R):
+        b.step_many(acts)
+    torch.cuda.synchronize()
+    sb = b.get_state()
+    kb, pb = b.get_rng_states()
+    assert int(sa['step_num'].max()) > 0
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(pa, pb) and np.array_equal(ka, kb)
+    assert torch.equal(a._obs, b._obs) and torch.equal(a.counters, b.counters)
     a.close(); b.close()
 
 

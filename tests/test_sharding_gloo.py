@@ -87,7 +87,10 @@ def _rccl_worker(rank, world, port, q, failing_rank, fail_at):
 
     # stands in for dist.new_group(backend='nccl') -- there is no GPU here -- with RCCL's semantics: creating the group sends nothing (the
     # communicator is built lazily, by the group's first collective); collectives "on" it go over the default gloo group
+    seen_at_create = []
+
     def new_group(backend, timeout):
+        seen_at_create.append(os.environ.get('TORCH_NCCL_BLOCKING_WAIT'))      # (what torch reads when it creates the group)
         if rank == failing_rank and fail_at == 'create':
             raise RuntimeError('injected: ncclCommInitRank failed')
         return 'fake-rccl'
@@ -106,7 +109,13 @@ def _rccl_worker(rank, world, port, q, failing_rank, fail_at):
 
     dist.all_reduce = all_reduce
     t0 = time.time()
+    os.environ.pop('TORCH_NCCL_BLOCKING_WAIT', None)
+    if rank % 2:
+        os.environ['TORCH_NCCL_BLOCKING_WAIT'] = '0'              # (a caller who set it: kept for the group, and still there afterwards)
     group, why = agree_on_rccl('cpu', timeout_s=20, new_group=new_group)
+    # library code: the variable is in force while THIS group is created and the process's environment is as the caller left it afterwards
+    assert seen_at_create == ['0' if rank % 2 else '1'], seen_at_create
+    assert os.environ.get('TORCH_NCCL_BLOCKING_WAIT') == ('0' if rank % 2 else None)
     q.put((rank, group is not None, why, time.time() - t0))
     dist.barrier()
     dist.destroy_process_group()
