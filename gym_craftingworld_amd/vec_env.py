@@ -439,6 +439,13 @@ class CraftingWorldVecEnv:
         L.check(self._lib.cw_render(self._h, C.c_void_p(out.data_ptr()), self._stream()), 'cw_render', self._lib)
         return out
 
+    def render_exact(self):
+        """The reference's INT image of every env's current state, exactly: int16 [N, ...frame_shape].  The uint8 frames of the engine hold it
+        modulo 256, which differs in ONE reachable pixel of the AltObs raster (sticks held over a sticks cell: (90, 164, 320),
+        craftingworld_altobs.py:527-543) and nowhere in the Ray raster; this is the batch counterpart of the N=1 classes' reference_dtypes=True.
+        Two kernels (cw_export_onehot, cw_render_onehot): a side view for checks and logging, not a per-step observation."""
+        return self.render_states(self.one_hot())
+
     def render_states(self, one_hot):
         """render(state) of ray.py:442-486 for caller-supplied one-hot states [M,S,S,12] of any content (several objects in a
         cell, any number of objects): -> int16 tensor [M,4S,4S,3] holding the reference's int image (sums of colours; the

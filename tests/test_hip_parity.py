@@ -1802,6 +1802,37 @@ def test_checkpoint_resume_is_bit_identical(obs_mode, raster, pool, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['alt4_double', 'ray5_scripted'])
+def test_batch_render_exact_is_the_references_int_image(name):
+    """CraftingWorldVecEnv.render_exact(): the reference's int image of the current state through the BATCH class -- for the AltObs raster including the
+    one pixel the uint8 frames cannot hold (alt4_double: sticks held over sticks on 9 steps, values up to 320; the fixture's int16 CRCs are the
+    reference's own), for the Ray raster simply the uint8 frame."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    meta, kw, g = load(name)
+    alt = meta['env'] == 'CraftingWorldEnvAltObs'
+    env = CraftingWorldVecEnv(1, obs_mode='pixels_dirty', auto_reset=False, raster='alt' if alt else 'ray', **kw)
+    env.set_rng_states(g['key0'][None], np.array([int(g['pos0'])]))
+    env.reset()
+    over = 0
+    T = len(g['action']) if alt else 1200
+    for t in range(T):
+        _, r, d, _ = env.step(torch.as_tensor(g['action'][t:t + 1].astype(np.int32), device=env.device))
+        assert int(r[0]) == g['reward'][t]
+        img = env.render_exact()[0].cpu().numpy()
+        assert img.dtype == np.int16
+        if alt:
+            assert crc(img) == g['obs_crc16'][t] and int(img.max()) == g['obs_max'][t], (name, t)
+            over += int(img.max() > 255)
+        else:
+            assert crc(img.astype(np.uint8)) == g['obs_crc'][t] and img.max() <= 255, (name, t)
+        assert np.array_equal(img.astype(np.uint8), env._obs[0].cpu().numpy())        # (the engine's frame is this image modulo 256)
+        if bool(d[0]):
+            env.reset()
+    assert over == (int((g['obs_max'] > 255).sum()) if alt else 0) and over == (9 if alt else 0)
+    env.close()
+
+
+@pytest.mark.gpu
 def test_facade_render_of_states_with_duplicated_objects():
     """render(state=...) of reachable states that hold an object TWICE (after ChopTree: two sticks; MakeBread: two breads;
     BuildHouse: two houses) -- every imagine_obs goal state for those tasks, e.g. the OneHot env's desired_goal.  The

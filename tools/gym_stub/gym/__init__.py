@@ -1,10 +1,12 @@
 """Minimal stand-in for the `gym` package (gym is not installed in this image, no network).
 
-Used ONLY by tools/gen_golden.py and tools/diff_vs_reference.py, in the build container, to
-import the read-only reference under /root/reference and capture golden vectors.  It provides
-exactly the names the reference touches and no environment logic: GoalEnv,
-spaces.{Box,Dict,Discrete}, utils.seeding.np_random, envs.registration.register, make.
-Nothing in the product, the tests or bench.py imports this package.
+Used by tools/gen_golden.py and tools/diff_vs_reference.py, in the build container, to
+import the read-only reference under /root/reference and capture golden vectors, and by
+tests/test_registration.py (in a subprocess) as the registry the product's three ids are
+registered in and resolved from.  It provides exactly the names the reference touches
+ and no environment logic: GoalEnv, spaces.{Box,Dict,Discrete},
+utils.seeding.np_random, envs.registration.register / registry, make (gym <= 0.21's entry-point
+resolution).  Nothing in the product or bench.py imports this package.
 """
 import importlib
 
