@@ -20,7 +20,9 @@ stats)
     rm -rf $OUT/rocprof_$tag
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_$tag -o p -- python bench.py --quick $(shape_args $tag) > $OUT/bench_under_rocprof_$tag.json 2> $OUT/rocprof_$tag.err
     cp $(ls $OUT/rocprof_$tag/p_kernel_stats.csv $OUT/rocprof_$tag/*/p_kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats_$tag.csv
-    echo "== $tag"; cut -c1-150 $OUT/kernel_stats_$tag.csv | head -5
+    # (the --stats table averages cw_create's calibration launches too: the per-launch trace, over the timed launches only)
+    python tools/summarize_trace.py $OUT/rocprof_$tag $OUT/bench_under_rocprof_$tag.json > $OUT/kernel_trace_timed_$tag.json || echo "trace summary $tag failed"
+    echo "== $tag"; cut -c1-150 $OUT/kernel_stats_$tag.csv | head -5; python -c "import json;print(json.load(open('$OUT/kernel_trace_timed_$tag.json')).get('against_bench_line'))"
   done;;
 consumer)
   rm -rf $OUT/rocprof_consumer
