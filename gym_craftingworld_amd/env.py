@@ -111,7 +111,7 @@ class CraftingWorldEnv:
         self.achieved_goal_vector = np.zeros((1, len(self.task_list)), dtype=int)
         # np_random (ray.py:145-147): the host mirror of the device-resident stream (_EnvRandomState), or the caller's own RandomState once one was assigned
         self._np_random = _EnvRandomState(self)
-        self._rng_stale, self._rng_dirty, self._rng_foreign = True, False, None
+        self._rng_stale, self._rng_dirty, self._rng_foreign, self._rng_foreign_seen = True, False, None, None
         if not fixed_init_state:                    # (else the constructor has drawn the pool from the stream already: the mirror follows at its first use)
             key, pos = seeding.mt_state_from_seed(v._seeds[0])
             np.random.RandomState.set_state(self._np_random, ('MT19937', key, pos, 0, 0.0))   # the seeded state as numpy holds it, ray.py:70
@@ -306,7 +306,7 @@ class CraftingWorldEnv:
             plain.set_state(rs.get_state())
             rs = plain
         self._rng_detach()
-        self._np_random, self._rng_foreign = _EnvRandomState(self), rs
+        self._np_random, self._rng_foreign, self._rng_foreign_seen = _EnvRandomState(self), rs, None
         self._rng_stale, self._rng_dirty = True, False
         self._rng_flush()
 
@@ -332,8 +332,11 @@ class CraftingWorldEnv:
     def _rng_flush(self):
         """before the engine draws (reset, generate_fixed_states) or its stream is read: what the host did to the generator goes to the device"""
         if self._rng_foreign is not None:
-            st = self._rng_foreign.get_state()
-            self._vec.set_rng_states(np.asarray(st[1])[None], np.asarray([st[2]]))
+            st = self._rng_foreign.get_state()       # (a plain RandomState cannot be hooked: look at it; upload only if the caller has moved it since our last look)
+            seen = self._rng_foreign_seen
+            if seen is None or st[2] != seen[1] or not np.array_equal(st[1], seen[0]):
+                self._vec.set_rng_states(np.asarray(st[1])[None], np.asarray([st[2]]))
+                self._rng_foreign_seen = (np.array(st[1], np.uint32), int(st[2]))
         elif self._rng_dirty:
             self._rng_dirty = False
             st = np.random.RandomState.get_state(self._np_random)
@@ -345,6 +348,7 @@ class CraftingWorldEnv:
             k, p = self._vec.get_rng_states()
             st = self._rng_foreign.get_state()
             self._rng_foreign.set_state(('MT19937', k[0], int(p[0]), st[3], st[4]))
+            self._rng_foreign_seen = (k[0].copy(), int(p[0]))
         else:
             self._rng_stale = True
 
@@ -353,6 +357,7 @@ class CraftingWorldEnv:
         self._vec.set_rng_states(np.asarray(key)[None], np.asarray([pos]))
         np.random.RandomState.set_state(self.np_random, ('MT19937', np.asarray(key, np.uint32), int(pos), 0, 0.0))   # (the host object shows it verbatim)
         self._rng_stale, self._rng_dirty = False, False
+        self._rng_foreign_seen = (np.array(key, np.uint32), int(pos)) if self._rng_foreign is not None else None
 
     def get_rng_state(self):
         self._rng_flush()

@@ -194,3 +194,31 @@ def test_obs_one_hot_is_one_live_array_per_episode(monkeypatch):
             assert env.INIT_OBS_VECTOR is not init
             assert (env.obs_one_hot is oh) == (not ref_dt)                   # int64 copies are per-episode arrays like the reference's; the uint8 view is the engine's buffer
             env.close()
+
+
+def test_an_assigned_generator_is_uploaded_only_when_the_caller_moved_it(monkeypatch):
+    """a plain RandomState assigned to env.np_random cannot be hooked: the env looks at it before every draw of the engine and writes it back after --
+    one download per reset(), and an upload only when the caller has drawn from it (or set it) since"""
+    fake_engine.install(monkeypatch)
+    import gym_craftingworld_amd as cw
+    env = cw.CraftingWorldEnv(size=(5, 5), max_steps=10, seed=3)
+    v = env._vec
+    rs = np.random.RandomState(77)
+    env.np_random = rs
+    assert env.np_random is rs
+    up0, down0 = v.n_rng_uploads, v.n_rng_downloads
+    for i in range(4):
+        env.reset()
+        assert (v.n_rng_uploads, v.n_rng_downloads) == (up0, down0 + i + 1)
+    ref = np.random.RandomState()
+    ref.set_state(rs.get_state())
+    a = rs.randint(1000)                                 # the caller draws: the env's next reset() starts behind that draw
+    assert a == ref.randint(1000)
+    env.reset()
+    assert v.n_rng_uploads == up0 + 1
+    k, p = env.get_rng_state()
+    assert p == rs.get_state()[2] and np.array_equal(k, rs.get_state()[1])
+    rs.seed(5)
+    env.reset()
+    assert v.n_rng_uploads == up0 + 2
+    env.close()
