@@ -64,21 +64,25 @@ def run_alias_script(env, ops, args, policy_seed=0):
     pol = np.random.RandomState(policy_seed)
     kept = foreign = held = last = None
     u8 = lambda a: crc(np.asarray(a).astype(np.uint8))  # noqa: E731
+    # what the class returns: the Ray / OneHot classes a dict of four arrays (images, or one-hot states), the Flat class the bare frame
+    ob = lambda o: o['observation'] if isinstance(o, dict) else o  # noqa: E731
+    part = lambda o, k, dflt: o[k] if isinstance(o, dict) else dflt  # noqa: E731
+    same = lambda o: isinstance(o, dict) and o['achieved_goal'] is o['observation']  # noqa: E731
 
     def one_step(a):
         o, r, d, info = env.step(a)
         ap = env.agent_pos
-        return (o, info, d), [int(r), int(bool(d)), _bits(info['achieved_goal']), u8(o['observation']), int(env.step_num), ap.row * 256 + ap.col,
-                              int(info['task_success'] is info['achieved_goal']) + 2 * int(o['achieved_goal'] is o['observation']), 0]
+        return (o, info, d), [int(r), int(bool(d)), _bits(info['achieved_goal']), u8(ob(o)), int(env.step_num), ap.row * 256 + ap.col,
+                              int(info['task_success'] is info['achieved_goal']) + 2 * int(same(o)), 0]
     for i, (op, arg) in enumerate(zip(ops, args)):
         op, arg = int(op), int(arg)
         if op == A_RESET:
             before = (env.desired_goal_vector, env.achieved_goal_vector)
             o = env.reset()
             st = env.np_random.get_state()
-            row = [_bits(env.desired_goal_vector), u8(o['observation']), u8(o['desired_goal']), u8(o['init_observation']), int(st[2]),
+            row = [_bits(env.desired_goal_vector), u8(ob(o)), u8(part(o, 'desired_goal', env.desired_goal)), u8(part(o, 'init_observation', env.INIT_OBS)), int(st[2]),
                    crc(np.asarray(st[1], np.uint32)), int(env.ep_no),
-                   int(env.desired_goal_vector is before[0]) + 2 * int(env.achieved_goal_vector is before[1]) + 4 * int(o['achieved_goal'] is o['observation'])]
+                   int(env.desired_goal_vector is before[0]) + 2 * int(env.achieved_goal_vector is before[1]) + 4 * int(same(o))]
         elif op == A_STEP:
             last, row = one_step(arg)
         elif op == A_RUN_TO_DONE:                   # random actions (ids -6..5) until done; arg caps the number of steps; row = the last step's
@@ -108,7 +112,7 @@ def run_alias_script(env, ops, args, policy_seed=0):
         elif op == A_CHECK_KEPT:
             ko, ki, _ = kept
             row = [_bits(ki['achieved_goal']), _bits(ki['desired_goal']), int(ki['achieved_goal'] is env.achieved_goal_vector),
-                   int(ki['desired_goal'] is env.desired_goal_vector), int(ki['task_success'] is ki['achieved_goal']), u8(ko['observation'])]
+                   int(ki['desired_goal'] is env.desired_goal_vector), int(ki['task_success'] is ki['achieved_goal']), u8(ob(ko))]
         elif op == A_ASSIGN:
             foreign = np.random.RandomState(arg)
             env.np_random = foreign

@@ -17,13 +17,15 @@ def _alias_env(cls, g, kw, **extra):
 
 @pytest.mark.parametrize('reference_dtypes', [False, True])
 @pytest.mark.parametrize('resident', [True, False])
-def test_alias_fixture_replays_through_the_facade(monkeypatch, resident, reference_dtypes):
+@pytest.mark.parametrize('name', ['ray5_alias', 'flat5_alias', 'onehot5_alias'])
+def test_alias_fixture_replays_through_the_facade(monkeypatch, name, resident, reference_dtypes):
+    """each fixture was captured from the reference class of that name (Ray: a dict of images; Flat: the bare frame; OneHot: a dict of one-hot states)"""
     fake_engine.install(monkeypatch, resident=resident)
     import gym_craftingworld_amd as cw
-    meta, kw, g = load('ray5_alias')
+    meta, kw, g = load(name)
     ops, args = alias_script()
     assert np.array_equal(ops, g['ops']) and np.array_equal(args, g['args']), 'the fixture was captured with another script: regenerate it'
-    env = _alias_env(cw.CraftingWorldEnv, g, kw, reference_dtypes=reference_dtypes)
+    env = _alias_env(getattr(cw, meta['env']), g, kw, reference_dtypes=reference_dtypes)
     rows = run_alias_script(env, ops, args, meta['policy_seed'])
     want = g['rows'].copy()
     if not reference_dtypes:          # default uint8 frames are the engine's live buffers: a kept observation shows the NEW episode after reset() (documented)

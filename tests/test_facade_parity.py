@@ -21,12 +21,14 @@ def _explain(ops, args, got, want):
 
 @pytest.mark.parametrize('reference_dtypes', [False, True])
 @pytest.mark.parametrize('resident', [True, False])
-def test_alias_fixture_replays_through_the_hip_engine(resident, reference_dtypes):
+@pytest.mark.parametrize('name', ['ray5_alias', 'flat5_alias', 'onehot5_alias'])
+def test_alias_fixture_replays_through_the_hip_engine(name, resident, reference_dtypes):
+    """each fixture was captured from the reference class of that name (Ray: a dict of images; Flat: the bare frame; OneHot: a dict of one-hot states)"""
     import gym_craftingworld_amd as cw
-    meta, kw, g = load('ray5_alias')
+    meta, kw, g = load(name)
     ops, args = alias_script()
     assert np.array_equal(ops, g['ops']) and np.array_equal(args, g['args'])
-    env = cw.CraftingWorldEnv(reference_dtypes=reference_dtypes, resident=resident, **kw)
+    env = getattr(cw, meta['env'])(reference_dtypes=reference_dtypes, resident=resident, **kw)
     assert env._resident == resident
     env.set_rng_state(g['key0'], int(g['pos0']))
     rows = run_alias_script(env, ops, args, meta['policy_seed'])

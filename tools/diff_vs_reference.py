@@ -163,7 +163,8 @@ def check_facade_aliasing(n_seeds):
     import fake_engine
     import golden_util as G
     import gym_craftingworld_amd as cw
-    ref_cls = import_reference()['ray']
+    refs = import_reference()
+    variants = [('ray', cw.CraftingWorldEnv), ('flat', cw.CraftingWorldEnvFlat), ('onehot', cw.CraftingWorldEnvOneHot)]      # each against the reference class of its name
 
     configs = [dict(size=(5, 5), max_steps=30), dict(size=(6, 6), max_steps=20, reward_style='subset', fixed_init_state=3),
                dict(size=(8, 8), max_steps=40, stacking=False, selected_tasks=T[::-1])]
@@ -172,13 +173,16 @@ def check_facade_aliasing(n_seeds):
         fake_engine.install(None, resident=resident)
         for ref_dt in (False, True):
             for seed in range(n_seeds + 1):
-                kw = configs[seed % len(configs)]
+                key, mine_cls = variants[(seed // len(configs)) % len(variants)] if seed else variants[0]
+                kw = dict(configs[seed % len(configs)])
+                if key == 'flat':
+                    kw.pop('fixed_init_state', None)    # (craftingworld_flat.py:52-55 has no such kwarg)
                 ops, args = G.alias_script() if seed == 0 else G.random_alias_script(np.random.RandomState(900 + seed), 90)
                 rng = np.random.RandomState(7000 + seed)
                 st = rng.get_state()
-                ref = make_ref_env(ref_cls, rng, **kw)
+                ref = make_ref_env(refs[key], rng, **kw)
                 want = G.run_alias_script(ref, ops, args, seed)
-                mine = cw.CraftingWorldEnv(reference_dtypes=ref_dt, **kw)
+                mine = mine_cls(reference_dtypes=ref_dt, **kw)
                 mine.set_rng_state(st[1], int(st[2]))
                 if kw.get('fixed_init_state'):
                     mine.generate_fixed_states()        # (the constructor drew the pool from its own seed: redraw it from the injected stream, as the reference's did)
@@ -190,7 +194,7 @@ def check_facade_aliasing(n_seeds):
                 mine.close()
                 n_ops += len(ops)
                 n_runs += 1
-    print('facade aliasing == reference on %d ops in %d scripts (committed + randomised; resident / launch step paths, uint8 / int64 dtypes)' % (n_ops, n_runs))
+    print('facade aliasing == reference on %d ops in %d scripts (committed + randomised; Ray / Flat / OneHot classes, resident / launch step paths, uint8 / int64 dtypes)' % (n_ops, n_runs))
 
 
 if __name__ == '__main__':

@@ -211,7 +211,9 @@ def capture(cls, kwargs, seed, steps, policy, keep_images, env_name='CraftingWor
 ALIAS_SCENARIOS = [
     # name, env kwargs, rng seed, policy seed: the op script of tests/golden_util.py (alias_script) run through the reference class -- what a caller sees
     # of the env's OBJECTS (np_random as the live generator, goal vectors rebound by reset(), negative action ids)
-    ('ray5_alias', dict(size=(5, 5), max_steps=30), 4711, 37),
+    ('ray5_alias', 'ray', dict(size=(5, 5), max_steps=30), 4711, 37),
+    ('flat5_alias', 'flat', dict(size=(5, 5), max_steps=30), 4722, None),          # (the bare frame returned; policy seed searched for below)
+    ('onehot5_alias', 'onehot', dict(size=(5, 5), max_steps=30), 4733, None),      # (observations are one-hot states; desired_goal the un-rendered goal state)
 ]
 
 
@@ -222,6 +224,14 @@ def capture_alias(cls, kwargs, seed, policy_seed):
     st = rng.get_state()
     env = make_ref_env(cls, rng, **kwargs)
     ops, args = alias_script()
+    if policy_seed is None:                        # the first policy seed whose three kept terminal infos all have an achieved bit set
+        for policy_seed in range(400):
+            rng = np.random.RandomState(seed)
+            env = make_ref_env(cls, rng, **kwargs)
+            if (run_alias_script(env, ops, args, policy_seed)[ops == A_KEEP][:, 0] != 0).all():
+                break
+        rng = np.random.RandomState(seed)
+        env = make_ref_env(cls, rng, **kwargs)
     rows = run_alias_script(env, ops, args, policy_seed)
     kept = rows[ops == A_KEEP]
     assert (kept[:, 0] != 0).all(), 'a kept terminal info with an achieved bit set: pick another seed'
@@ -229,7 +239,7 @@ def capture_alias(cls, kwargs, seed, policy_seed):
     assert (chk[:, 2:4] == 0).all() and np.array_equal(chk[:, :2], kept[:, :2]), 'the reference rebinds the goal vectors at reset (ray.py:170, 176)'
     kw = dict(kwargs)
     kw['size'] = list(kw['size'])
-    meta = dict(kwargs=kw, seed=seed, policy_seed=policy_seed, env='CraftingWorldEnvRay', kind='alias')
+    meta = dict(kwargs=kw, seed=seed, policy_seed=policy_seed, env=cls.__name__, kind='alias')
     return dict(meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), key0=st[1].astype(np.uint32), pos0=np.int32(st[2]),
                 ops=ops, args=args, rows=rows)
 
@@ -237,10 +247,10 @@ def capture_alias(cls, kwargs, seed, policy_seed):
 def main():
     classes = import_reference()
     os.makedirs(OUT, exist_ok=True)
-    for name, kwargs, seed, pseed in ALIAS_SCENARIOS:
+    for name, key, kwargs, seed, pseed in ALIAS_SCENARIOS:
         if sys.argv[1:] and name not in sys.argv[1:]:
             continue
-        out = capture_alias(classes['ray'], kwargs, seed, pseed)
+        out = capture_alias(classes[key], kwargs, seed, pseed)
         path = os.path.join(OUT, name + '.npz')
         np.savez_compressed(path, **out)
         print('%-18s ops=%4d  %6.1f KB' % (name, len(out['ops']), os.path.getsize(path) / 1024))
