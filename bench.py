@@ -514,7 +514,7 @@ def main():
 
     # second, identical K-step region with the library's HIP events around each kernel (eager launches:
     # events cannot be re-recorded from inside a replayed graph)
-    launch_desc = ('one persistent kernel for all K steps (cw_rollout)' if args.rollout else
+    launch_desc = ('persistent launches of max_steps steps for the K steps (cw_rollout)' if args.rollout else
                    ('eager' if G == 0 else 'hip graph of %d steps' % G))
     graph = None
     args.rollout = False
@@ -825,7 +825,7 @@ def main():
                 e2.rollout(block, record=False)
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tt
-                rec['rollout'] = {'value': n_envs * kb / dt, 'us_per_step': dt / kb * 1e6, 'launch': 'cw_rollout: %d steps in one persistent kernel' % kb}
+                rec['rollout'] = {'value': n_envs * kb / dt, 'us_per_step': dt / kb * 1e6, 'launch': 'cw_rollout: %d steps in persistent launches of max_steps steps, a look-ahead refill ahead of each' % kb}
             out_[mode] = rec
             e2.close()
         return out_

@@ -789,12 +789,25 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     if (!guard.ok) return fail(CW_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     PARK(e);
     if (stream_capturing((hipStream_t)stream)) e->captured = true; else note_work(e, (hipStream_t)stream);
-    if (e->P.lookahead) {
-        HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
-        e->la_refill_all = false;
-        e->la_steps = 0;
+    // Engines with look-ahead records: the n_steps go out in SEGMENTS of max_steps steps (64 at least), a refill kernel ahead of each -- a persistent launch
+    // cannot refill, and an env that finishes a second time inside it finds no record and is reset the slow way by its whole wave (~12 us per env: the second
+    // all-env time-out of a 600-step launch cost 64 envs x 12 us per wave, as much as the 600 steps themselves).  An episode lasts max_steps steps at most, so
+    // with one segment per max_steps steps every time-out finds its record; shorter segments cost more in launches than they save (a segment start is ~20 us:
+    // the refill, the launch, the state's round trip): 65 536 envs, T = 600: one launch 2.2e10 env-steps/s, segments of 64 / 128 / 300 steps 2.0 / 2.7 / 2.9e10
+    // (2^20 envs: 4.1 -> 6.0e10; profiles/r06_experiments.txt C).  Same results, the same stream order.  CW_TUNE_ROLLOUT_SEGMENT=n: segments of n steps, 0: one launch.
+    static const int seg_env = getenv("CW_TUNE_ROLLOUT_SEGMENT") ? atoi(getenv("CW_TUNE_ROLLOUT_SEGMENT")) : -1;
+    const int32_t seg = !e->P.lookahead || seg_env == 0 ? n_steps : seg_env > 0 ? seg_env : (e->P.max_steps > 64 ? e->P.max_steps : 64);
+    const size_t N = (size_t)e->n;
+    for (int32_t t0 = 0; t0 < n_steps; t0 += seg) {
+        if (e->P.lookahead) {
+            HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
+            e->la_refill_all = false;
+            e->la_steps = 0;
+        }
+        const int32_t n = n_steps - t0 < seg ? n_steps - t0 : seg;
+        HIP_TRY(cwk_launch_rollout(&e->P, actions + (size_t)t0 * N, n, rewards ? rewards + (size_t)t0 * N : nullptr, dones ? dones + (size_t)t0 * N : nullptr,
+                                   (hipStream_t)stream));
     }
-    HIP_TRY(cwk_launch_rollout(&e->P, actions, n_steps, rewards, dones, (hipStream_t)stream));
     return CW_OK;
 }
 

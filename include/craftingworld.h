@@ -198,7 +198,8 @@ int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_
  * array [n_steps][N] of uint8 action ids; rewards [n_steps][N] int32 and dones [n_steps][N] uint8 are
  * DEVICE arrays or NULL.  The result (state, RNG streams, counters, the reward/done/achieved buffers of
  * the last step) is bit-identical to n_steps calls of cw_step.  CW_OBS_STATE engines with auto_reset
- * only: no frames are painted (use cw_render afterwards). */
+ * only: no frames are painted (use cw_render afterwards).  A call longer than max_steps steps is issued as several launches of max_steps steps
+ * (64 at least) with a look-ahead refill ahead of each, in stream order: every env's time-out then finds its next episode's record waiting. */
 int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *rewards, uint8_t *dones,
                cw_stream_t stream);
 
