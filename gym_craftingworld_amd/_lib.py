@@ -109,7 +109,7 @@ class cwh_guard(C.Structure):
 
 
 CWH_GUARD_NONE, CWH_GUARD_SLOWDOWN, CWH_GUARD_TRIAL_UP, CWH_GUARD_TRIAL_KEPT, CWH_GUARD_TRIAL_UNDONE = range(5)
-CWH_CKPT_SECTIONS = 23
+CWH_CKPT_SECTIONS = 22
 
 # the engine's HIP-free host logic (csrc/cw_host.h: MT19937 state conversion, DLPack, dense views, checkpoint sizes, the guard's decisions), exported for
 # the tests of the host logic -- the same table binds libcw_host_asan.so, the ASAN/UBSAN build of cw_host.cpp alone (bind_host_helpers)
@@ -126,6 +126,7 @@ HOST_HELPERS = {
     'cwh_guard_step': (C.c_int, [C.POINTER(cwh_guard), C.c_double, C.c_double]),
     'cwh_sweep_periods': (None, [C.c_double, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'cwh_guard_scheduled_ms': (C.c_double, [C.c_double, C.c_int32, C.c_int32, C.c_double]),
+    'cwh_la_adapt': (C.c_int32, [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_int32)]),
 }
 
 

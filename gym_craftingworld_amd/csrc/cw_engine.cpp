@@ -94,7 +94,12 @@ struct cw_engine {
     // look-ahead (cw_layout.h): the refill kernel is launched every e->la_period steps, ahead of the step, on the step's stream
     bool la_refill_all = false;        // the next refill covers every env without a record (after cw_reset / a re-seed / a checkpoint load)
     unsigned la_steps = 0;
-    unsigned la_period = 16;
+    unsigned la_period = 16;           // the CURRENT refill period: la_period_max, or shorter while envs finish twice between two refills (la_adapt)
+    unsigned la_period_max = 16;       // la_period_for(max_steps), or CW_TUNE_LA_PERIOD
+    bool la_adaptive = true;
+    unsigned long long *la_feedback = nullptr;     // pinned: counters[5] as the last refill kernel saw it
+    unsigned long long la_slow_seen = 0;
+    int32_t la_quiet = 0;              // refills in a row with (nearly) no slow-path reset
     bool in_step_many = false;         // (cw_step_many decides about the refill of a captured sequence itself)
     bool capturing_now = false;        // ... and asks once whether its stream is capturing, for all of its steps
     // the sweep's clock (calibrate_sweep) and its guard (sweep_guard_tick)
@@ -156,6 +161,21 @@ static inline hipError_t aux_copy(cw_engine *e, void *dst, const void *src, size
 // look-ahead refill: every la_period-th step.  A refill costs one reset's latency (~15 us) whatever the list holds, so rarely is cheap -- but an env
 // that finishes twice between two refills is reset the slow way: a quarter of the episode length, 8..64 steps
 static int la_period_for(int max_steps) { const int p = max_steps / 4; return p < 8 ? 8 : p > 64 ? 64 : p; }
+// THE REFILL PERIOD FOLLOWS THE EPISODES (round 6).  la_period_for() assumes episodes of about max_steps steps -- a random policy's.  A policy that SUCCEEDS ends
+// its episodes much earlier: an env then finishes two or three times between two refills, finds no record the second time and is reset the slow way by its
+// whole wave -- ~12 us on the step kernel's critical path, and the kernel ends with its slowest wave (a walker on 8x8 grids under max_steps 300, episodes of
+// ~140 steps: 98 slow resets per step at the static period of 64, state-only step 21 us instead of 6; profiles/r06_experiments.txt D).  Every refill kernel
+// leaves the count of slow resets in a pinned word; the host reads it when it enqueues the next refill -- stale by a period or more, never waited for -- and
+// halves the period (8 at least) while a period brings more slow resets than an eighth of its steps (what a refill launch costs), doubles it back after eight
+// quiet refills in a row.  Results do not depend on the period; a captured graph keeps the period it was captured with.
+static void la_adapt(cw_engine *e)
+{
+    const unsigned long long slow = __atomic_load_n(e->la_feedback, __ATOMIC_RELAXED);
+    const unsigned long long delta = slow >= e->la_slow_seen ? slow - e->la_slow_seen : 0;      // (a loaded checkpoint brings its own counters)
+    e->la_slow_seen = slow;
+    e->la_period = (unsigned)cwh_la_adapt((int32_t)e->la_period, (int32_t)e->la_period_max, delta, &e->la_quiet);      // (cw_host.cpp: the rule, tested on the CPU)
+}
+
 // ------------------------------------------------------------------------------ resident stepper (host side)
 // Every entry point that reads or writes the engine's state first makes sure no resident kernel holds it in registers.
 static int resident_park(cw_engine *e)
@@ -408,6 +428,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     P.ncell = e->ncell;
     P.max_steps = cfg->max_steps;
     e->la_period = (unsigned)la_period_for(cfg->max_steps);
+    if (const char *v = getenv("CW_TUNE_LA_PERIOD")) if (atoi(v) >= 1) { e->la_period = (unsigned)atoi(v); e->la_adaptive = false; }      // (a forced period: profiles/r06_experiments.txt D)
+    e->la_period_max = e->la_period;
     P.task_mask = (1u << cfg->n_task_list) - 1u;
     P.pool_k = e->K;
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
@@ -428,6 +450,8 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
         tn.small_blocks_per_cu = geti("CW_TUNE_SMALL_BLOCKS", tn.small_blocks_per_cu);
         if (tn.small_blocks_per_cu < 1 || tn.small_blocks_per_cu > 8) tn.small_blocks_per_cu = 1;
         tn.small_launch_bytes = (long long)geti("CW_TUNE_SMALL_LAUNCH_MB", (int)(tn.small_launch_bytes >> 20)) << 20;
+        tn.reset_blocks_per_cu = geti("CW_TUNE_RESET_BLOCKS", tn.reset_blocks_per_cu);
+        if (tn.reset_blocks_per_cu < 1 || tn.reset_blocks_per_cu > 16) tn.reset_blocks_per_cu = 2;
     }
 
     int rc = CW_OK;
@@ -474,11 +498,18 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     // look-ahead records: every engine that resets by itself and lives in device memory (CW_TUNE_LOOKAHEAD=0: the slow path only, for A/B runs
     // and the test that both give the same results)
     P.lookahead = (cfg->auto_reset && !cfg->host_outputs && !(getenv("CW_TUNE_LOOKAHEAD") && atoi(getenv("CW_TUNE_LOOKAHEAD")) == 0)) ? 1 : 0;
-    ALLOC(nx_init_pos, P.lookahead ? N : 1);
-    ALLOC(nx_goal_pos, P.lookahead ? N : 1);
-    ALLOC(nx_misc, P.lookahead ? N : 1);
-    ALLOC(refill_list, P.lookahead ? N : 1);
-    ALLOC(refill_count, 2);
+    ALLOC(nx_init_pos, P.lookahead ? N * CW_LA_DEPTH : 1);      // (a queue of CW_LA_DEPTH records per env, one array per slot: cw_layout.h)
+    ALLOC(nx_goal_pos, P.lookahead ? N * CW_LA_DEPTH : 1);
+    ALLOC(nx_misc, P.lookahead ? N * CW_LA_DEPTH : 1);
+    ALLOC(nx_ctl, P.lookahead ? N : 1);
+    if (rc == CW_OK && P.lookahead && e->la_adaptive) {      // (no pinned word: a fixed period)
+        void *fb = nullptr;
+        if (hipHostMalloc(&fb, 64, hipHostMallocCoherent) == hipSuccess) {
+            memset(fb, 0, 64);
+            e->host_allocs.push_back(fb);
+            e->la_feedback = P.la_feedback = (unsigned long long *)fb;
+        }
+    }
 #undef ALLOC_OUT
 #undef ALLOC
     CwMenuDev *dmenus = nullptr;
@@ -558,8 +589,8 @@ int cw_destroy(cw_engine *e)
 static hipError_t lookahead_drop(cw_engine *e)
 {
     if (!e->P.lookahead) return hipSuccess;
-    hipError_t rc = hipMemsetAsync(e->P.nx_misc, 0, (size_t)e->n * sizeof(uint4), e->aux);
-    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.refill_count, 0, 2 * sizeof(int32_t), e->aux);
+    hipError_t rc = hipMemsetAsync(e->P.nx_misc, 0, (size_t)e->n * CW_LA_DEPTH * sizeof(uint4), e->aux);
+    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.nx_ctl, 0, (size_t)e->n * sizeof(uint32_t), e->aux);
     e->la_refill_all = true;
     return rc;
 }
@@ -608,17 +639,21 @@ int cw_get_mt(cw_engine *e, uint32_t *keys, int32_t *pos)
     PARK(e);
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> words(N * CW_MT_N);
-    std::vector<uint32_t> misc(e->P.lookahead ? N * 4 : 0);
+    std::vector<uint32_t> misc(e->P.lookahead ? N * 4 * CW_LA_DEPTH : 0);
     HIP_TRY(quiesce(e));
     AuxDrain drain(e);                               // (every exit waits for the private stream: the copies below target this frame's buffers)
     HIP_TRY(aux_copy(e, words.data(), e->P.mt, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(aux_copy(e, pos, e->P.mt_idx, N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (e->P.lookahead) HIP_TRY(aux_copy(e, misc.data(), e->P.nx_misc, N * 16, hipMemcpyDeviceToHost));
+    if (e->P.lookahead) HIP_TRY(aux_copy(e, misc.data(), e->P.nx_misc, N * 16 * CW_LA_DEPTH, hipMemcpyDeviceToHost));
     HIP_TRY(hipStreamSynchronize(e->aux));
     for (size_t i = 0; i < N; i++) cwh_mt_to_numpy(&words[i * CW_MT_N], pos[i], keys + i * CW_MT_N);
-    if (e->P.lookahead) {                            // the engine's streams are one reset ahead where a record waits: report the position BEFORE it
-        for (size_t i = 0; i < N; i++)
-            if (misc[i * 4 + 2] >> 31) cwh_mt_rewind(keys + i * CW_MT_N, &pos[i], misc[i * 4 + 3]);
+    if (e->P.lookahead) {                            // the engine's streams are as many resets ahead as records wait: report the position BEFORE the first of them
+        for (size_t i = 0; i < N; i++) {
+            uint32_t ahead = 0;
+            for (size_t d = 0; d < CW_LA_DEPTH; d++)
+                if (misc[(d * N + i) * 4 + 2] >> 31) ahead += misc[(d * N + i) * 4 + 3];
+            if (ahead) cwh_mt_rewind(keys + i * CW_MT_N, &pos[i], ahead);
+        }
     }
     // numpy's own form of a stream that stands at a generation's end: it regenerates lazily, so after the 624th draw RandomState.get_state() shows
     // (the generation just used up, 624), never (the next one, 0) -- the engine's consume-and-replace form holds the next one already
@@ -682,6 +717,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
     // a step captured into a HIP graph on its own carries the refill with it: a replayed graph would otherwise never refill
     if (capturing && e->P.lookahead && !e->la_refill_all && e->la_steps + 1 < e->la_period && !e->in_step_many) e->la_steps = e->la_period;
     if (e->P.lookahead && (e->la_refill_all || ++e->la_steps >= e->la_period)) {      // look-ahead refill, between two steps
+        if (e->la_feedback && !capturing) la_adapt(e);
         HIP_TRY(cwk_launch_refill(&e->P, &e->tune, e->la_refill_all ? 1 : 0, (hipStream_t)stream));
         e->la_refill_all = false;
         e->la_steps = 0;
@@ -1170,7 +1206,7 @@ struct CwCkptHeader {
     uint64_t menus_hash, total_bytes;
 };
 static const char CW_CKPT_MAGIC[8] = {'C', 'W', 'C', 'K', 'P', 'T', 0, 1};
-enum { CW_CKPT_VERSION = 3 };      // 2: look-ahead records; 3: episode_return, the sweep's private counter word, the QUEUED bit of nx_misc
+enum { CW_CKPT_VERSION = 4 };      // 2: look-ahead records; 3: episode_return, the sweep's private counter word, the QUEUED bit of nx_misc; 4: a queue of CW_LA_DEPTH records per env
 
 struct CkptSection { void *dev; size_t bytes; };
 static std::vector<CkptSection> ckpt_sections(cw_engine *e)
@@ -1179,9 +1215,9 @@ static std::vector<CkptSection> ckpt_sections(cw_engine *e)
     // (file order; the sizes are cw_host.cpp's: cwh_ckpt_section_bytes -- the RNG streams are one reset ahead wherever a look-ahead record waits)
     void *dev[CWH_CKPT_SECTIONS] = {P.hdr, P.pos, P.init_pos, P.goal_pos, P.goal_codes, P.init_agent, P.goal_agent, P.ep_no, P.mt, P.mt_idx, P.pool, P.reward, P.done,
                                     P.achieved_out, P.desired_out, P.episode_length, P.episode_return, P.counters, P.nx_init_pos, P.nx_goal_pos, P.nx_misc,
-                                    P.refill_list, P.refill_count};
+                                    P.nx_ctl};
     size_t bytes[CWH_CKPT_SECTIONS];
-    const int n = cwh_ckpt_section_bytes(e->n, e->K, e->P.lookahead, bytes, nullptr);
+    const int n = cwh_ckpt_section_bytes(e->n, e->K, e->P.lookahead ? CW_LA_DEPTH : 0, bytes, nullptr);
     std::vector<CkptSection> out;
     for (int i = 0; i < n; i++) out.push_back({dev[i], bytes[i]});
     return out;
@@ -1260,7 +1296,7 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     // (cwh_mt_rewind) and the record dropped; an engine that keeps records recomputes them at its next refill.
     const size_t N = (size_t)e->n;
     std::vector<uint32_t> key(CW_MT_N), words(CW_MT_N);      // (scratch of the rewind below; declared ahead of the drain guard: it outlives every copy)
-    const size_t la_bytes = N * 16 * 3 + N * 4 + 8;
+    const size_t la_bytes = N * 16 * 3 * CW_LA_DEPTH + N * 4;
     const unsigned long long expect = mine.total_bytes + (h.lookahead && !mine.lookahead ? la_bytes : 0) - (!h.lookahead && mine.lookahead ? la_bytes : 0);
     if (h.total_bytes != expect || length < h.total_bytes)
         return fail(CW_ERR_INVALID, "cw_checkpoint_load: truncated checkpoint (%zu of %llu bytes)", length, (unsigned long long)h.total_bytes);
@@ -1271,18 +1307,21 @@ int cw_checkpoint_load(cw_engine *e, const void *buf, size_t length)
     for (const CkptSection &sec : ckpt_sections(e)) {
         if (sec.dev == (void *)e->P.mt) blob_mt = p;
         if (sec.dev == (void *)e->P.mt_idx) blob_idx = p;
-        const bool la_section = sec.dev == (void *)e->P.nx_init_pos || sec.dev == (void *)e->P.nx_goal_pos || sec.dev == (void *)e->P.nx_misc ||
-                                sec.dev == (void *)e->P.refill_list || sec.dev == (void *)e->P.refill_count;
+        const bool la_section = sec.dev == (void *)e->P.nx_init_pos || sec.dev == (void *)e->P.nx_goal_pos || sec.dev == (void *)e->P.nx_misc || sec.dev == (void *)e->P.nx_ctl;
         if (la_section && h.lookahead != mine.lookahead) continue;           // (handled below)
         if (sec.bytes) HIP_TRY(aux_copy(e, sec.dev, p, sec.bytes, hipMemcpyDefault));
         p += sec.bytes;
     }
     if (h.lookahead && !mine.lookahead) {            // p: the file's look-ahead sections (nx_init_pos, nx_goal_pos, nx_misc, list, count)
-        const unsigned char *misc_bytes = p + N * 32;     // (nx_misc of the file: 4 words per env at an offset that need not be 4-byte aligned -- the 'done' section is N bytes)
+        const unsigned char *misc_bytes = p + N * 32 * CW_LA_DEPTH;     // (nx_misc of the file: 4 words per record at an offset that need not be 4-byte aligned -- the 'done' section is N bytes)
         HIP_TRY(hipStreamSynchronize(e->aux));
         for (size_t i = 0; i < N; i++) {
-            uint32_t misc[4];
-            memcpy(misc, misc_bytes + i * 16, 16);
+            uint32_t misc[4] = {0, 0, 0, 0};         // [3]: the draws of every record that waited, summed
+            for (size_t d = 0; d < CW_LA_DEPTH; d++) {
+                uint32_t md[4];
+                memcpy(md, misc_bytes + (d * N + i) * 16, 16);
+                if (md[2] >> 31) { misc[2] = md[2]; misc[3] += md[3]; }
+            }
             if (!(misc[2] >> 31)) continue;
             int32_t pos = 0;
             memcpy(&pos, blob_idx + i * 4, 4);

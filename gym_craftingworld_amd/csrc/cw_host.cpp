@@ -140,13 +140,14 @@ void cwh_slots_to_grid(const uint16_t *pos, uint32_t codes, int ncell, uint8_t *
 // ------------------------------------------------------------------------------ checkpoint blob sections (cw_engine.cpp: ckpt_sections pairs them with device pointers)
 // hdr, pos, init_pos, goal_pos (16 B / env), goal_codes (4), init_agent, goal_agent (2), ep_no (4), mt (624 x 4), mt_idx (4), pool (k x 9 x 2),
 // reward (4), done (1), achieved_out, desired_out (2), episode_length, episode_return (4), counters (5 x 8: the four public ones + the sweep's
-// private word), then the look-ahead records verbatim: nx_init_pos, nx_goal_pos, nx_misc (16), refill_list (4), refill_count (8 bytes once)
-int cwh_ckpt_section_bytes(int64_t n, int32_t k, int32_t lookahead, size_t *sizes, uint64_t *total)
+// private word), then the look-ahead records verbatim -- la_depth of them per env (0: the engine keeps none): nx_init_pos, nx_goal_pos, nx_misc (16 each per
+// record), nx_ctl (4: the ring's head and the QUEUED bit)
+int cwh_ckpt_section_bytes(int64_t n, int32_t k, int32_t la_depth, size_t *sizes, uint64_t *total)
 {
-    const size_t N = n > 0 ? (size_t)n : 0, K = k > 0 ? (size_t)k : 0, la = lookahead ? 1 : 0;
+    const size_t N = n > 0 ? (size_t)n : 0, K = k > 0 ? (size_t)k : 0, D = la_depth > 0 ? (size_t)la_depth : 0, la = D ? 1 : 0;
     const size_t sz[CWH_CKPT_SECTIONS] = {N * 16, N * 16, N * 16, N * 16, N * 4, N * 2, N * 2, N * 4, N * CWH_MT_N * 4, N * 4, N * K * 9 * 2,
                                           N * 4, N, N * 2, N * 2, N * 4, N * 4, 5 * 8,
-                                          la * N * 16, la * N * 16, la * N * 16, la * N * 4, la * (size_t)8};
+                                          D * N * 16, D * N * 16, D * N * 16, la * N * 4};
     uint64_t sum = 0;
     for (int i = 0; i < CWH_CKPT_SECTIONS; i++) { if (sizes) sizes[i] = sz[i]; sum += sz[i]; }
     if (total) *total = sum;
@@ -244,6 +245,19 @@ int cwh_guard_step(cwh_guard *g, double ms, double scheduled)
         return CWH_GUARD_TRIAL_UP;
     }
     return CWH_GUARD_NONE;
+}
+
+// ------------------------------------------------------------------------------ the look-ahead refill period
+int32_t cwh_la_adapt(int32_t period, int32_t period_max, uint64_t slow_delta, int32_t *quiet)
+{
+    if (slow_delta * 8ull > (uint64_t)period) {          // (what a refill launch costs: ~2 us per step at a period of 8 against 12 us per slow reset)
+        *quiet = 0;
+        if (period > CWH_LA_PERIOD_MIN) period = period / 2 < CWH_LA_PERIOD_MIN ? CWH_LA_PERIOD_MIN : period / 2;
+    } else if (slow_delta * 32ull <= (uint64_t)period && ++*quiet >= CWH_LA_QUIET) {
+        *quiet = 0;
+        if (period < period_max) period = period * 2 > period_max ? period_max : period * 2;
+    }
+    return period;
 }
 
 }  // extern "C"

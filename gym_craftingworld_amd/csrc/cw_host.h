@@ -25,10 +25,10 @@ void *cwh_dlpack_make(void *data, int device_id, int code, int bits, int ndim, c
 // ---- a slot record (8 cell indices u16 + 8 4-bit codes) as the dense grid of cw_state_view: grid[ncell] cell codes (0 empty)
 void cwh_slots_to_grid(const uint16_t *pos, uint32_t codes, int ncell, uint8_t *grid);
 
-// ---- checkpoint blob: byte sizes of its sections, in file order, for n envs / fixed_init_state pool k / look-ahead records or not.
+// ---- checkpoint blob: byte sizes of its sections, in file order, for n envs / fixed_init_state pool k / la_depth look-ahead records per env (0: none kept).
 // Writes at most CWH_CKPT_SECTIONS sizes, returns how many; *total (may be null) = their sum (the blob is header + total).
-#define CWH_CKPT_SECTIONS 23
-int cwh_ckpt_section_bytes(int64_t n, int32_t k, int32_t lookahead, size_t *sizes, uint64_t *total);
+#define CWH_CKPT_SECTIONS 22
+int cwh_ckpt_section_bytes(int64_t n, int32_t k, int32_t la_depth, size_t *sizes, uint64_t *total);
 
 // ---- the GUARD of the sweep's clock as a pure state machine (cw_engine.cpp: sweep_guard_tick feeds it one timed sweep at a time; nothing here
 // touches HIP).  Rates in TB/s, times in ms.  DESIGN.md 4.3; the constants are the ones round 4/5 measured (profiles/r04_clock.txt, r05_experiments.txt).
@@ -68,6 +68,13 @@ int cwh_guard_step(cwh_guard *g, double ms, double scheduled_ms);
 void cwh_sweep_periods(double rate, int32_t sweep_waves, double head_notch, double busy_notch, int32_t *period16, int32_t *period16_head, int32_t *period16_busy);
 // What a sweep of `sweep_jobs` jobs per wave should take with those periods, after a busy step, plus what a launch costs beside its jobs
 double cwh_guard_scheduled_ms(double sweep_jobs, int32_t period16, int32_t period16_busy, double beside_ms);
+
+// ---- the look-ahead refill period follows the episodes (cw_engine.cpp: la_adapt).  `slow_delta` slow-path resets were counted since the last refill was
+// enqueued (read from a pinned word the refill kernels write; stale by a period, never waited for): more than an eighth of the period's steps -> half the
+// period (CWH_LA_PERIOD_MIN at least); at most a 32nd of them for CWH_LA_QUIET refills in a row -> twice the period (period_max at most).  -> the new period.
+#define CWH_LA_PERIOD_MIN 8
+#define CWH_LA_QUIET 8
+int32_t cwh_la_adapt(int32_t period, int32_t period_max, uint64_t slow_delta, int32_t *quiet);
 
 #ifdef __cplusplus
 }

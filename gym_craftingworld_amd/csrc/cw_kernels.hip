@@ -478,21 +478,30 @@ __device__ __forceinline__ void paint_changed_cells(const CwParams &P, int env, 
 // of reset() (ray.py:156-218) as three 16-byte loads and the stores of the episode records, by the lane that stepped the env.  h / sp become
 // the new episode's header and slots (reset_header's values).  -> false: no record (the env finished twice between two refills, or the
 // engine keeps none); the caller hands the env to the slow path, which resets it from the same position of its stream.
+// ctl: the env's nx_ctl word (head slot | CW_CTL_QUEUED), loaded by the caller with the env's state.  A finished env goes on the refill list unless it is
+// there (ctl says): the CALLER appends it -- it knows that from the step and the word alone, so its list ticket (a returning atomic) travels in the same
+// memory round trip as the record's loads here, not behind them.
 struct CwGoalState { uint4 pos; uint32_t codes, agent; };      // imagine_obs' final state of the episode just taken over (the painters of its desired_goal frame)
-__device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint4 &h, uint32_t sp[8], bool count_episode, CwGoalState *goal = nullptr)
+__device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint32_t ctl, uint4 &h, uint32_t sp[8], bool count_episode, CwGoalState *goal = nullptr)
 {
-    const uint4 m = P.nx_misc[env];
+    const uint32_t slot = ctl & 0xFFu;
+    const size_t at = (size_t)slot * P.n_envs + env;
+    // (everything the take-over reads is asked for at once -- the record's three parts and the episode counter: ONE memory round trip; a load issued behind the
+    // valid bit's test would be a second one on the critical path of every wave with a finished env)
+    const uint4 m = P.nx_misc[at];
+    const uint4 ipos = P.nx_init_pos[at];
+    const uint4 gpos = P.nx_goal_pos[at];
+    const int32_t ep_no = count_episode ? P.ep_no[env] : 0;
     if (!(m.z >> 31)) return false;
-    const uint4 ipos = P.nx_init_pos[env];
     P.init_pos[env] = ipos;
-    const uint4 gpos = P.nx_goal_pos[env];
     P.goal_pos[env] = gpos;
     if (goal) { goal->pos = gpos; goal->codes = m.y; goal->agent = m.x >> 16; }
     P.goal_codes[env] = m.y;
     P.init_agent[env] = (uint16_t)(m.x & 0xFFFFu);
     P.goal_agent[env] = (uint16_t)(m.x >> 16);
-    if (count_episode) P.ep_no[env] += 1;                         // ray.py:200-201
-    ((uint32_t *)(P.nx_misc + env))[2] = (m.z & 0x7FFFFFFFu) | CW_NX_QUEUED;   // taken; the caller puts the env on the refill list
+    if (count_episode) P.ep_no[env] = ep_no + 1;                  // ray.py:200-201
+    ((uint32_t *)(P.nx_misc + at))[2] = 0;                        // taken: the slot is free, the next one (if any waits) is the head
+    P.nx_ctl[env] = (slot + 1u == CW_LA_DEPTH ? 0u : slot + 1u) | CW_CTL_QUEUED;      // (on the list: the caller has put it there, or it was there)
     const uint32_t ia = m.x & 0xFFFFu;
     const uint32_t ar = __umulhi(ia, P.div_magic), ac = ia - ar * P.size;
     h.x = ar | (ac << 8) | (h.x & 0xFF000000u);                   // (the menu id stays)
@@ -503,17 +512,14 @@ __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uin
     return true;
 }
 
-// An env reset the SLOW way holds no record for its next episode.  Unless it is on the refill list already (it took its record earlier in this
-// refill period), it goes there now -- otherwise an engine whose host never asks for a whole-batch refill again (a captured graph replayed after a
-// re-seed dropped every record: cw_refill_kernel with all_envs = 0 baked in) would reset the slow way for the rest of its life.  One lane.
-__device__ __forceinline__ void queue_for_refill(const CwParams &P, int env)
+// An env reset the SLOW way holds no record for its next episode: it must be on the refill list -- otherwise an engine whose host never asks for a whole-batch
+// refill again (a captured graph replayed after a re-seed dropped every record: cw_refill_kernel with all_envs = 0 baked in) would reset the slow way for the
+// rest of its life.  The step kernels list every finished env that is not listed yet (ctl) before they know whether a record waits; what is left here is the
+// env's QUEUED bit and the count of slow resets.  One lane.
+__device__ __forceinline__ void note_slow_reset(const CwParams &P, int env, uint32_t ctl)
 {
-    uint32_t *z = (uint32_t *)(P.nx_misc + env) + 2;
-    const uint32_t v = *z;
     atomicAdd(&P.counters[5], 1ull);                  // (private word: resets taken the slow way)
-    if (v & (CW_NX_QUEUED | 0x80000000u)) return;
-    *z = v | CW_NX_QUEUED;
-    P.refill_list[atomicAdd(&P.refill_count[0], 1)] = env;
+    if (!(ctl & CW_CTL_QUEUED)) P.nx_ctl[env] = ctl | CW_CTL_QUEUED;
 }
 
 // step() for engines WITHOUT auto-reset (the single-env loop's launch path, fixture replays): one lane per env, finished envs keep
@@ -553,20 +559,6 @@ __global__ __launch_bounds__(256) void cw_step_kernel(CwParams P, const void *ac
         if (m_done) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_done));
         if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
         if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
-    }
-}
-
-// a list's counter is zeroed for its next use by the LAST workgroup of the kernel that reads it (a ticket in count[1]) -- no host-side
-// parity and no memset node, so a cw_step is a fixed sequence of launches with fixed arguments and can be captured into a hipGraph as is
-__device__ __forceinline__ void release_list(int32_t *count, int n_blocks)
-{
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(&count[1], 1);
-        if (t == n_blocks - 1) {
-            count[0] = 0;
-            count[1] = 0;
-        }
     }
 }
 
@@ -851,11 +843,12 @@ __device__ __forceinline__ void store_episode_records(const CwParams &P, int env
 }
 
 // the record of an episode as the look-ahead arrays hold it (refill) / as the episode arrays hold it after a pop
-__device__ __forceinline__ void store_next_record(const CwParams &P, int env, const CwResetOut &r)
+__device__ __forceinline__ void store_next_record(const CwParams &P, int env, int slot, const CwResetOut &r)
 {
-    P.nx_init_pos[env] = r.init_pos;
-    P.nx_goal_pos[env] = r.goal_pos;
-    P.nx_misc[env] = make_uint4(r.init_agent | (r.goal_agent << 16), r.goal_codes, r.desired | (r.subset << 16) | 0x80000000u, r.draws);
+    const size_t at = (size_t)slot * P.n_envs + env;
+    P.nx_init_pos[at] = r.init_pos;
+    P.nx_goal_pos[at] = r.goal_pos;
+    P.nx_misc[at] = make_uint4(r.init_agent | (r.goal_agent << 16), r.goal_codes, r.desired | (r.subset << 16) | 0x80000000u, r.draws);      // (VALID)
 }
 // reset() of EVERY env (cw_reset, ray.py:156-218), one wavefront per env: a waiting look-ahead record is taken over, any other env is
 // reset here from its stream.  (cw_reset then sweeps the three frame arrays and refills the records.)
@@ -869,11 +862,12 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
         const uint4 v_h = P.hdr[env];                                 // in flight beside the MT state
         const uint32_t menu_id = __builtin_amdgcn_readfirstlane(v_h.x) >> 24;
         const bool count_episode = (__builtin_amdgcn_readfirstlane(v_h.z) & 0xFFFFu) != 0;   // ray.py:200-201
-        if (P.lookahead && (__builtin_amdgcn_readfirstlane(P.nx_misc[env].z) >> 31)) {        // the next episode is waiting
+        const uint32_t ctl = P.lookahead ? __builtin_amdgcn_readfirstlane(P.nx_ctl[env]) : 0u;
+        if (P.lookahead && (__builtin_amdgcn_readfirstlane(P.nx_misc[(size_t)(ctl & 0xFFu) * P.n_envs + env].z) >> 31)) {        // the next episode is waiting
             if (lane == 0) {
                 uint4 h = v_h;
                 uint32_t sp[8];
-                pop_next_episode(P, env, h, sp, count_episode);
+                pop_next_episode(P, env, ctl, h, sp, count_episode);      // (not listed: cw_reset tops every env's ring up right after this kernel)
                 P.pos[env] = pack_pos(sp);
                 P.hdr[env] = h;
                 P.achieved_out[env] = 0;                              // the mask outputs describe the new episode
@@ -903,16 +897,33 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_refill_kernel(CwPa
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
     const int wave = blockIdx.x * CW_RESET_WAVES + wave_in_block;
     const int n_waves = gridDim.x * CW_RESET_WAVES;
-    const int count = all_envs ? P.n_envs : P.refill_count[0];
-    if (count == 0) return;                              // (every workgroup reads the same count: it changes only after all of them have drawn a ticket)
-    for (int job = wave; job < count; job += n_waves) {
-        const int env = __builtin_amdgcn_readfirstlane(all_envs ? job : P.refill_list[job]);
-        const uint32_t v_hx = P.hdr[env].x;
-        if (all_envs && (__builtin_amdgcn_readfirstlane(P.nx_misc[env].z) >> 31)) continue;
-        const CwResetOut r = reset_env_wave(P, env, [&]() { return __builtin_amdgcn_readfirstlane(v_hx) >> 24; }, s_mt[wave_in_block], lane);
-        if (lane == 0) store_next_record(P, env, r);
+    if (P.la_feedback && blockIdx.x == 0 && threadIdx.x == 0)       // (what the host tunes its refill period by: read whenever, never waited for)
+        __hip_atomic_store(P.la_feedback, P.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // No list: the kernel SCANS the envs' control words, 16 envs per wave and round (one coalesced load), and tops up the rings of those that are QUEUED
+    // (all_envs: of every env -- after cw_reset, a re-seed, a checkpoint load).  A list needed a returning atomic per finishing wave of the step kernel
+    // (a ticket: a memory round trip on the step's critical path, and contention on one word); the scan reads 4 bytes per env once per refill.
+    enum { CHUNK = 16 };
+    for (int base = wave * CHUNK; base < P.n_envs; base += n_waves * CHUNK) {
+        const int mine = base + lane;
+        const uint32_t v_ctl = (lane < CHUNK && mine < P.n_envs) ? P.nx_ctl[mine] : 0u;
+        unsigned long long m = CW_BALLOT(lane < CHUNK && mine < P.n_envs && (all_envs || (v_ctl & CW_CTL_QUEUED)));
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int env = base + l;
+            const uint32_t ctl = __builtin_amdgcn_readlane(v_ctl, l);
+            const uint32_t v_hx = P.hdr[env].x;
+            // every free slot behind the waiting records (they follow the head in stream order) gets the next reset() of the env's stream
+            const uint32_t head = ctl & 0xFFu;
+            for (uint32_t k = 0; k < CW_LA_DEPTH; k++) {
+                const uint32_t slot = head + k >= CW_LA_DEPTH ? head + k - CW_LA_DEPTH : head + k;
+                if (__builtin_amdgcn_readfirstlane(P.nx_misc[(size_t)slot * P.n_envs + env].z) >> 31) continue;
+                const CwResetOut r = reset_env_wave(P, env, [&]() { return __builtin_amdgcn_readfirstlane(v_hx) >> 24; }, s_mt[wave_in_block], lane);
+                if (lane == 0) store_next_record(P, env, (int)slot, r);
+            }
+            if ((ctl & CW_CTL_QUEUED) && lane == 0) P.nx_ctl[env] = head;      // (served)
+        }
     }
-    release_list(P.refill_count, (int)gridDim.x);        // (all_envs too: whatever the list held has a record now)
 }
 
 // T consecutive steps of every env in ONE persistent launch (state-only observation mode): each
@@ -938,6 +949,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
     uint4 ip = P.init_pos[e];
+    uint32_t ctl = P.lookahead ? P.nx_ctl[e] : 0u;    // (the ring's head; kept in step with the pops below)
     unsigned long long n_done = 0, n_succ = 0, n_inv = 0;
     int reward = -1;
     bool done = false;
@@ -955,18 +967,13 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
         n_succ += __popcll(CW_BALLOT(live && o.success));
         n_inv += __popcll(CW_BALLOT(live && o.invalid));
         if (m_all && live && o.done) { P.episode_length[env] = (int32_t)o.step_num; P.episode_return[env] = episode_return_of(P, o); }
-        bool popped = false;                         // auto-reset: the look-ahead record if there is one ...
+        bool popped = false;                         // auto-reset: the look-ahead record at the head of the env's ring if one waits ...
+        const uint32_t ctl_was = ctl;
         if (live && o.done && P.lookahead) {
-            popped = pop_next_episode(P, env, h, sp, true);
-            if (popped) ip = pack_pos(sp);
+            popped = pop_next_episode(P, env, ctl, h, sp, true);
+            if (popped) { ip = pack_pos(sp); ctl = ((ctl & 0xFFu) + 1u == CW_LA_DEPTH ? 0u : (ctl & 0xFFu) + 1u) | CW_CTL_QUEUED; }
         }
         const unsigned long long m_pop = CW_BALLOT(popped);
-        if (m_pop) {
-            int rbase = 0;
-            if (lane == 0) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
-            rbase = __shfl(rbase, 0);
-            if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
-        }
         unsigned long long m = m_all & ~m_pop;
         while (m) {                                  // ... else the slow way, one finished env at a time, whole wave
             const int l = __builtin_ctzll(m);
@@ -976,12 +983,13 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_rollout_kernel(CwP
             const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt[wave_in_block], lane);
             if (lane == 0) {
                 store_episode_records(P, env_l, r, true);              // step_num >= 1 here
-                if (P.lookahead) queue_for_refill(P, env_l);
+                if (P.lookahead) note_slow_reset(P, env_l, __builtin_amdgcn_readlane(ctl_was, l));
             }
             if (lane == l) {
                 h = reset_header(P, r, menu_id);
                 unpack_pos(r.init_pos, sp);
                 ip = r.init_pos;
+                ctl |= CW_CTL_QUEUED;                // (note_slow_reset's bit, in this lane's copy of the word)
             }
         }
     }
@@ -1112,7 +1120,7 @@ enum { CW_JOB_INIT = 0, CW_JOB_GOAL = 1, CW_JOB_TERMINAL = 2 };
 // and the pixel kernels lose the branches of the other mode.
 template <int PAINT, bool TERM>
 __device__ __forceinline__ void fused_step(const CwParams &P, const void *actions, int act_dtype, int epw, int wave, uint32_t *s_mt_wave,
-                                           CwPaintJob *s_jobs, int *s_njobs)
+                                           CwPaintJob *s_jobs, int *s_njobs, int *s_cnt /* [3]: finished, successes, invalid actions of this workgroup */)
 {
     constexpr int paint = PAINT;
     const int lane = threadIdx.x & (CW_WAVE - 1);
@@ -1130,10 +1138,9 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
     uint32_t sp[8];
     unpack_pos(P.pos[e], sp);
     const uint4 ip = P.init_pos[e];                  // (asked for with the rest: a second memory round trip only for lanes that hold something costs the wave the same)
-    if constexpr (PAINT != 0) {
-        if (threadIdx.x == 0) *s_njobs = 0;
-        __syncthreads();                             // (behind the loads' issue)
-    }
+    const uint32_t ctl = P.lookahead ? P.nx_ctl[e] : 0u;      // (the head of the env's ring of look-ahead records: 4 more bytes in the same round trip)
+    if (threadIdx.x == 0) { *s_njobs = 0; s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+    __syncthreads();                                 // (behind the loads' issue)
     const CwStepOut o = step_env(P, h, sp, a, [&]() { return ip; });
     const bool done = live && o.done;
     if (live) {
@@ -1151,24 +1158,28 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
 #pragma unroll
         for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
     }
+    // The public counters.  One same-address atomic per WAVE serialises in the L2: with ~480 of 65 536 envs finishing per step (a policy that succeeds) 1 400
+    // atomics on the counters' cache line cost the kernel 4.4 us of its 12.8, and the waves' tickets for the refill list another 2 (profiles/r06_experiments.txt
+    // D).  So the waves add up in LDS and ONE lane per workgroup adds to the counters; the refill list is gone (the refill kernel scans the envs' QUEUED bits).
+    const unsigned long long m_all = CW_BALLOT(done);
+    const unsigned long long m_succ = CW_BALLOT(live && o.success);
+    const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
+    if (lane == 0 && (m_all | m_inv)) {
+        if (m_all) atomicAdd(&s_cnt[0], (int)__popcll(m_all));
+        if (m_succ) atomicAdd(&s_cnt[1], (int)__popcll(m_succ));
+        if (m_inv) atomicAdd(&s_cnt[2], (int)__popcll(m_inv));
+    }
     bool popped = false;
     CwGoalState goal;
     goal.pos = make_uint4(0, 0, 0, 0); goal.codes = 0; goal.agent = 0;
-    if (done && P.lookahead) popped = pop_next_episode(P, env, h, sp, true, PAINT != 0 ? &goal : nullptr);
-    const unsigned long long m_all = CW_BALLOT(done), m_pop = CW_BALLOT(popped);
-    const unsigned long long m_succ = CW_BALLOT(live && o.success);
-    const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
-    int rbase = 0;
-    if (lane == 0 && wave_live) {                    // (one same-address atomic per wave would serialise the grid in L2)
-        if (wave == 0) atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
-        if (m_all) atomicAdd(&P.counters[1], (unsigned long long)__popcll(m_all));
-        if (m_succ) atomicAdd(&P.counters[2], (unsigned long long)__popcll(m_succ));
-        if (m_inv) atomicAdd(&P.counters[3], (unsigned long long)__popcll(m_inv));
-        if (m_pop) rbase = atomicAdd(&P.refill_count[0], __popcll(m_pop));
-    }
-    if (m_pop) {
-        rbase = __shfl(rbase, 0);
-        if (popped) P.refill_list[rbase + __popcll(m_pop & ((1ull << lane) - 1ull))] = env;
+    if (done && P.lookahead) popped = pop_next_episode(P, env, ctl, h, sp, true, PAINT != 0 ? &goal : nullptr);
+    const unsigned long long m_pop = CW_BALLOT(popped);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.n_envs);
+        if (s_cnt[0]) atomicAdd(&P.counters[1], (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&P.counters[2], (unsigned long long)s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&P.counters[3], (unsigned long long)s_cnt[2]);
     }
     // ---- the jobs of this wave's finished envs (pixel modes): INIT_OBS (with the observation itself in the dirty-cell mode), desired_goal, and with
     //      keep_terminal_obs the finished episode's last frame.  Envs that took a record: by their own lanes.
@@ -1209,7 +1220,7 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         const CwResetOut r = reset_env_wave(P, env_l, [&]() { return menu_id; }, s_mt_wave, lane);
         if (lane == 0) {
             store_episode_records(P, env_l, r, true);                       // step_num >= 1 here
-            if (P.lookahead) queue_for_refill(P, env_l);
+            if (P.lookahead) note_slow_reset(P, env_l, __builtin_amdgcn_readlane(ctl, l));
         }
         if (lane == l) {
             h = reset_header(P, r, menu_id);
@@ -1249,8 +1260,9 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_step_fused_kernel(
     __shared__ uint32_t s_mt[CW_RESET_WAVES][CW_MT_WORDS];
     __shared__ CwPaintJob s_jobs[PAINT != 0 ? CW_RESET_WAVES * CW_WAVE * (TERM ? 3 : 2) : 1];      // (state-only: no queue -- one unused entry, optimised away)
     __shared__ int s_njobs;
+    __shared__ int s_cnt[3];
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / CW_WAVE);
-    fused_step<PAINT, TERM>(P, actions, act_dtype, epw, blockIdx.x * CW_RESET_WAVES + wave_in_block, s_mt[wave_in_block], s_jobs, &s_njobs);
+    fused_step<PAINT, TERM>(P, actions, act_dtype, epw, blockIdx.x * CW_RESET_WAVES + wave_in_block, s_mt[wave_in_block], s_jobs, &s_njobs, s_cnt);
 }
 typedef void (*CwStepFusedKernel)(CwParams, const void *, int, int);
 static CwStepFusedKernel cw_step_fused_variant(int paint, bool term)

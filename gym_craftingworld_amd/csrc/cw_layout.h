@@ -30,7 +30,9 @@
 // Slot k initially holds object k (code k+1) -- OBJECTS order, ray.py:21.
 
 #define CW_CODES_INITIAL 0x87654321u  // slot k has code k+1
-#define CW_NX_QUEUED 0x40000000u      // nx_misc.z: the env is on the refill list (its record was taken, or it was reset the slow way)
+#define CW_CTL_QUEUED 0x100u          // nx_ctl: the env is on the refill list (a record was taken, or it was reset the slow way); bits 0-7: the queue's head slot
+#define CW_LA_DEPTH 4                 // look-ahead records kept per env (round 6: a QUEUE -- an env that finishes two, three, four times between two refills
+                                      // still finds a record; rounds 4-5 kept one, and every further finish was reset the slow way on the step's critical path)
 
 // One ordered selected_tasks list, device form (cw_task_menu packed): selected_bits as nibbles.
 struct CwMenuDev {
@@ -56,7 +58,8 @@ struct CwTuning {
     int small_blocks_per_cu = 4;    // (CW_TUNE_SMALL_BLOCKS)
     long long small_launch_bytes = 320ll << 20;   // ... the piece sweep only while a launch writes less than this (the gather painter always); CW_TUNE_SMALL_LAUNCH_MB
     int step_envs_per_wave = 64;    // most envs a wave of cw_step_fused_kernel steps (64: one wave per SIMD at 65 536 envs; CW_TUNE_STEP_ENVS_PER_WAVE: 8 / 16 / 32 / 64)
-    int reset_blocks_per_cu = 2;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and list kernels
+    int reset_blocks_per_cu = 4;    // resetting workgroups (4 waves = 4 envs in flight each) per CU at most: the reset, refill and pool kernels (round 6: 2 -> 4;
+                                    // nothing runs beside the sweep any more, the refill's scan wants the waves: CW_TUNE_RESET_BLOCKS, profiles/r06_experiments.txt D)
 };
 
 // Control block of the RESIDENT stepper (cw_step_resident: the single-env loop, a step without a kernel launch): pinned, coherent host memory
@@ -101,14 +104,17 @@ struct CwParams {
     // episode's placement, goal state and task set are known as soon as the previous reset has been taken: the refill kernel runs them ahead in
     // bulk, off the per-step path, and a finished env just takes the record over inside the step kernel (a POP: three 16-byte loads).  An env
     // that finishes again before the next refill finds no record and is reset the slow way, on the spot, from the same stream position.
-    uint4 *nx_init_pos;      // [N] sample_state placement of the next episode
-    uint4 *nx_goal_pos;      // [N] its imagine_obs final state
-    uint4 *nx_misc;          // [N] x = init_agent | goal_agent << 16, y = goal_codes, z = desired | subset << 16 | QUEUED << 30 | VALID << 31
-                             //     (QUEUED: the env is on the refill list), w = raw 32-bit draws the record consumed (cw_get_mt rewinds the
-                             //     exported stream by them)
-    int32_t *refill_list;    // [N] envs whose record was taken since the last refill (each at most once)
-    int32_t *refill_count;   // [2] entries, release ticket
+    // The records of an env form a RING of CW_LA_DEPTH slots, slot d of env e at [d * N + e] (one coalesced array per slot): nx_ctl[e] names the head slot --
+    // the NEXT episode --, the valid records follow it in stream order, a pop invalidates the head and advances it (one round trip: the three 16-byte loads of
+    // the head slot, as with the single record of rounds 4-5), the refill computes the missing ones behind the last valid one.
+    uint4 *nx_init_pos;      // [D][N] sample_state placement of the episode
+    uint4 *nx_goal_pos;      // [D][N] its imagine_obs final state
+    uint4 *nx_misc;          // [D][N] x = init_agent | goal_agent << 16, y = goal_codes, z = desired | subset << 16 | VALID << 31, w = raw 32-bit draws the
+                             //     record consumed (cw_get_mt rewinds the exported stream by the draws of every waiting record)
+    uint32_t *nx_ctl;        // [N] head slot (bits 0-7) | CW_CTL_QUEUED; read with the env's state when a step begins
     int32_t lookahead;       // 0: no records are kept (engines without auto-reset, host-mapped engines, CW_TUNE_LOOKAHEAD=0)
+    unsigned long long *la_feedback;   // pinned host word or null: every refill kernel leaves counters[5] (resets taken the slow way so far) here -- the host
+                                       // adapts its refill period to it without ever waiting for the card (cw_engine.cpp: cw_step)
     unsigned long long *counters; // [4] public: steps, finished, successes, invalid actions; [4] PRIVATE: the finished count the last sweep of the
                                   // observation array saw (cw_render_pieces_kernel: what kind of step does it follow?), [5] PRIVATE: resets of
                                   // look-ahead engines that found no record and were taken the slow way; 8 words allocated

@@ -179,8 +179,9 @@ int cw_reset(cw_engine *e, cw_stream_t stream);
  * actions: DEVICE pointer to N actions of dtype CW_ACT_*, values 0..5 = Up,Right,Down,Left,
  * PickUp,Drop (ACTIONS, ray.py:130-131).  Out-of-range values are counted in counters[3] and
  * executed as a state-preserving step (step_num += 1, reward -1).  Enqueues the step kernel -- engines with auto_reset: finished envs take
- * over the record of their next episode, computed ahead of time by a refill kernel that rides on every max_steps/4-th call (8 ... 64); an env that finishes twice
- * between two refills is reset on the spot -- and, in CW_OBS_PIXELS_FULL, the sweep that paints the observation array.
+ * over the record of their next episode, computed ahead of time by a refill kernel that rides on every max_steps/4-th call (8 ... 64; fewer steps apart while
+ * envs finish faster than that: the period follows the count of slow resets the card reports, never waited for); every env keeps a queue of four such records,
+ * and one that finishes a fifth time between two refills is reset on the spot -- and, in CW_OBS_PIXELS_FULL, the sweep that paints the observation array.
  * With cw_config.host_outputs `actions` may be cw_buffer_table.host_actions. */
 int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t stream);
 
@@ -188,7 +189,7 @@ int cw_step(cw_engine *e, const void *actions, int action_dtype, cw_stream_t str
  * in one call (a host loop in Python costs more per call than a state-only step takes on the card).  The frames and outputs left behind are
  * the last step's.  Capturable into a HIP graph as one piece (a replay re-reads the action array: refill it in place between replays).
  * A captured sequence carries ONE look-ahead refill at its head (plus the regular one every max_steps/4 steps inside it): a replayed graph must
- * refill by itself.  That launch costs ~15 us whatever its list holds -- capture sequences of a refill period or more (a graph of a single
+ * refill by itself.  That launch costs ~15 us whatever it finds to do -- capture sequences of a refill period or more (a graph of a single
  * cw_step pays it on every replay: three times a 5-us state-only step).  An env that finds no record is reset on the spot and rejoins the list,
  * so a graph replayed after a re-seed has its records back after one episode. */
 int cw_step_many(cw_engine *e, const void *actions, int action_dtype, int32_t n_steps, cw_stream_t stream);

@@ -165,15 +165,42 @@ def test_dense_view_of_a_slot_record(hl):
     assert np.array_equal(grid, want)
 
 
-@pytest.mark.parametrize('n,k,la', [(1, 0, 0), (4096, 0, 1), (65536, 3, 1), (1 << 20, 64, 0)])
+@pytest.mark.parametrize('n,k,la', [(1, 0, 0), (4096, 0, 1), (65536, 3, 4), (1 << 20, 64, 0)])
 def test_checkpoint_section_sizes(hl, n, k, la):
     L, lib = hl
     sizes = (C.c_size_t * L.CWH_CKPT_SECTIONS)()
     total = C.c_uint64()
-    assert lib.cwh_ckpt_section_bytes(n, k, la, sizes, C.byref(total)) == L.CWH_CKPT_SECTIONS == 23
+    assert lib.cwh_ckpt_section_bytes(n, k, la, sizes, C.byref(total)) == L.CWH_CKPT_SECTIONS == 22
     s = list(sizes)
     assert sum(s) == total.value
     per_env = 16 * 4 + 4 + 2 + 2 + 4 + 624 * 4 + 4 + k * 18 + 4 + 1 + 2 + 2 + 4 + 4
-    assert total.value == n * per_env + 40 + (la and (n * (48 + 4) + 8))
-    assert s[8] == n * 2496 and s[10] == n * k * 18 and s[17] == 40 and (s[18:] == [0] * 5) == (not la)
-    assert lib.cwh_ckpt_section_bytes(n, k, la, None, None) == 23        # (sizes and total are optional)
+    assert total.value == n * per_env + 40 + (la and n * (48 * la + 4))                # (la records of 48 bytes per env and the ring's control word)
+    assert s[8] == n * 2496 and s[10] == n * k * 18 and s[17] == 40 and (s[18:] == [0] * 4) == (not la)
+    assert lib.cwh_ckpt_section_bytes(n, k, la, None, None) == 22        # (sizes and total are optional)
+
+
+def test_refill_period_follows_the_slow_resets(hl):
+    """cwh_la_adapt (csrc/cw_host.cpp; cw_engine.cpp feeds it the count of slow-path resets a pinned word reports): a random policy (no slow resets) keeps the
+    static period; a policy whose episodes end early (slow resets every period) halves it down to 8 and holds it there; once they stop it climbs back by
+    doublings, eight quiet refills apart; a few slow resets (under a 32nd of the period's steps) count as quiet, some (between a 32nd and an eighth) hold the period"""
+    L, lib = hl
+    q = C.c_int32(0)
+    p = 64
+    for _ in range(100):
+        p = lib.cwh_la_adapt(p, 64, 0, C.byref(q))
+    assert p == 64
+    seen = []
+    for _ in range(6):
+        p = lib.cwh_la_adapt(p, 64, 100, C.byref(q))
+        seen.append(p)
+    assert seen == [32, 16, 8, 8, 8, 8] and q.value == 0
+    seen = []
+    for i in range(40):
+        p = lib.cwh_la_adapt(p, 64, 0 if i % 9 else 1, C.byref(q))           # (1 slow reset in a period of >= 32 steps is quiet; at 8 and 16 steps it holds the period)
+        seen.append(p)
+    assert seen[-1] == 64 and sorted(seen) == seen and set(seen) == {8, 16, 32, 64}
+    ups = [i for i in range(1, 40) if seen[i] > seen[i - 1]]
+    assert all(b - a >= 8 for a, b in zip(ups, ups[1:])), ups
+    q.value = 0
+    assert lib.cwh_la_adapt(32, 64, 4, C.byref(q)) == 32 and lib.cwh_la_adapt(32, 64, 5, C.byref(q)) == 16        # (an eighth of the period's steps is the line)
+    assert lib.cwh_la_adapt(8, 64, 10 ** 9, C.byref(q)) == 8 and lib.cwh_la_adapt(48, 48, 0, C.byref(q)) == 48
