@@ -830,9 +830,41 @@ def main():
             e2.close()
         return out_
 
-    other, config1 = {}, None
+    # ... and what finishing episodes cost when a policy SUCCEEDS (round 6): the metric's random policy ends an episode every max_steps steps; a
+    # stand-in for a competent one -- 8x8 grids, reward_style='subset', the one task EatBread, a random walker -- ends one every ~140 steps: ~480 of 65 536 envs
+    # finish on every step, many of them twice or more between two look-ahead refills of the static period.
+    def short_episodes(n_envs, modes):
+        out_ = {}
+        walk = torch.randint(0, 4, (256, n_envs), device=dev, dtype=torch.uint8, generator=gen)
+        for mode in modes:
+            e3 = CraftingWorldVecEnv(n_envs, size=(8, 8), max_steps=args.max_steps, obs_mode=mode, device=dev, seed=lo, reward_style='subset',
+                                     selected_tasks=['EatBread'], number_of_tasks=1)
+            e3.reset()
+            for t in range(2 * args.max_steps):
+                e3.step_async(walk[t % 256])
+            torch.cuda.synchronize(dev)
+            c0 = e3._counters_raw.cpu().clone()
+            k3 = 2000
+            tt = time.perf_counter()
+            for t in range(k3):
+                e3.step_async(walk[t % 256])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - tt
+            c1 = e3._counters_raw.cpu()
+            fin = float(c1[1] - c0[1])
+            out_[mode] = {'value': n_envs * k3 / dt, 'unit': 'env-steps/s', 'us_per_step': dt / k3 * 1e6, 'steps': k3,
+                          'episodes_finished_per_step': fin / k3, 'mean_episode_length': n_envs * k3 / max(fin, 1.0),
+                          'slow_path_resets_per_step': float(c1[5] - c0[5]) / k3,
+                          'workload': '%d envs, 8x8, max_steps=%d, reward_style subset, selected_tasks [EatBread], uniform random MOVES: a stand-in for a policy that '
+                                      'succeeds (round 5, one look-ahead record per env and a refill every 64 steps: 21.0 / 26.6 us per step state-only / dirty-cell)'
+                                      % (n_envs, args.max_steps)}
+            e3.close()
+        return out_
+
+    other, config1, short_eps = {}, None, None
     if rank == 0 and world == 1 and not args.no_other_modes and args.obs_mode == 'pixels' and args.raster == 'ray':
         env.close()
+        short_eps = short_episodes(N, ('state', 'pixels_dirty'))
         other = side_modes(N, ('pixels_dirty', 'state'), actions)
         # BASELINE configs[1]: 4 096 envs, default grid, state-only obs, random actions
         config1 = side_modes(4096, ('state',), actions[:, :4096].contiguous())['state']
@@ -951,6 +983,7 @@ def main():
             'dist_backend': backend_used,
             'other_obs_modes_1gpu': other,
             'config1_state_4096': config1,
+            'short_episodes_1gpu': short_eps,
             'policy_in_loop': policy_blocks,
         }
         if cpu_result is not None:                       # rank 0 at N=1 only (task contract); measured above, beside the GPU soak

@@ -170,7 +170,7 @@ def test_bench_json_line_carries_the_contract():
         assert abs(b['env_ms_per_step'] - (b['ms_per_step'] - b['consumer_ms'])) < 1e-9 and 'tuner_after' in b
     # round 6: the region timed on the device (value) beside the wall clock around the bracket (value_wall); the CPU baseline measured ALONE on the whole CPU
     # share, the soak beside a second run of it
-    assert d['value_wall'] > 0 and d['ms_per_step_wall'] >= d['ms_per_step'] * 0.999 and 'timing' in d and d['per_rank'][0]['barrier_ms'] >= 0
+    assert d['value_wall'] > 0 and d['ms_per_step_wall'] >= d['ms_per_step'] * 0.999 and 'timing' in d and d['per_rank'][0]['barrier_ms'] >= 0 and 'short_episodes_1gpu' in d
     assert len(d['repeats']['value_wall']) == 3 and d['metric_window']['value_wall'] > 0 and wd['value_wall'] > 0
     bs = c['beside_gpu_soak']
     assert bs['cores'] == max(1, c['cores'] - 1) and bs['value'] > 0 and 'nothing else running' in c['sample'] and 'minus 1' in bs['sample']
