@@ -478,9 +478,8 @@ __device__ __forceinline__ void paint_changed_cells(const CwParams &P, int env, 
 // of reset() (ray.py:156-218) as three 16-byte loads and the stores of the episode records, by the lane that stepped the env.  h / sp become
 // the new episode's header and slots (reset_header's values).  -> false: no record (the env finished twice between two refills, or the
 // engine keeps none); the caller hands the env to the slow path, which resets it from the same position of its stream.
-// ctl: the env's nx_ctl word (head slot | CW_CTL_QUEUED), loaded by the caller with the env's state.  A finished env goes on the refill list unless it is
-// there (ctl says): the CALLER appends it -- it knows that from the step and the word alone, so its list ticket (a returning atomic) travels in the same
-// memory round trip as the record's loads here, not behind them.
+// ctl: the env's nx_ctl word (head slot | CW_CTL_QUEUED), loaded by the caller with the env's state.  Taking a record marks the env QUEUED: the next refill
+// kernel, which scans these words, tops its ring up (there is no list to append to, and so no ticket to wait for).
 struct CwGoalState { uint4 pos; uint32_t codes, agent; };      // imagine_obs' final state of the episode just taken over (the painters of its desired_goal frame)
 __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uint32_t ctl, uint4 &h, uint32_t sp[8], bool count_episode, CwGoalState *goal = nullptr)
 {
@@ -512,10 +511,9 @@ __device__ __forceinline__ bool pop_next_episode(const CwParams &P, int env, uin
     return true;
 }
 
-// An env reset the SLOW way holds no record for its next episode: it must be on the refill list -- otherwise an engine whose host never asks for a whole-batch
-// refill again (a captured graph replayed after a re-seed dropped every record: cw_refill_kernel with all_envs = 0 baked in) would reset the slow way for the
-// rest of its life.  The step kernels list every finished env that is not listed yet (ctl) before they know whether a record waits; what is left here is the
-// env's QUEUED bit and the count of slow resets.  One lane.
+// An env reset the SLOW way holds no record for its next episode: it must be QUEUED for the next refill -- otherwise an engine whose host never asks for a
+// whole-batch refill again (a captured graph replayed after a re-seed dropped every record: cw_refill_kernel with all_envs = 0 baked in) would reset the slow
+// way for the rest of its life.  Its QUEUED bit and the count of slow resets (what the host's refill period follows).  One lane.
 __device__ __forceinline__ void note_slow_reset(const CwParams &P, int env, uint32_t ctl)
 {
     atomicAdd(&P.counters[5], 1ull);                  // (private word: resets taken the slow way)
@@ -886,7 +884,7 @@ __global__ __launch_bounds__(CW_RESET_WAVES *CW_WAVE) void cw_reset_kernel(CwPar
     }
 }
 
-// LOOK-AHEAD refill: the next reset() of every env of the refill list (all_envs: of every env without a record), run ahead of time from
+// LOOK-AHEAD refill: the next reset()s of every QUEUED env (all_envs: of every env with a free slot in its ring), run ahead of time from
 // the env's stream and parked in the nx_* arrays; the stream is left AFTER that reset (nx_misc.w says by how many draws).  Launched by the
 // host every few steps, between steps: thousands of resets side by side at one wave each cost ~5 ns per reset where ~200 of them beside every
 // sweep cost the step 25 us.  Same device function as the slow path, same stream order: results cannot differ.
@@ -1159,8 +1157,8 @@ __device__ __forceinline__ void fused_step(const CwParams &P, const void *action
         for (int k = 0; k < 8; k++) sp_last[k] = sp[k];
     }
     // The public counters.  One same-address atomic per WAVE serialises in the L2: with ~480 of 65 536 envs finishing per step (a policy that succeeds) 1 400
-    // atomics on the counters' cache line cost the kernel 4.4 us of its 12.8, and the waves' tickets for the refill list another 2 (profiles/r06_experiments.txt
-    // D).  So the waves add up in LDS and ONE lane per workgroup adds to the counters; the refill list is gone (the refill kernel scans the envs' QUEUED bits).
+    // atomics on the counters' cache line cost the kernel 4.4 us of its 12.8, and the waves' tickets for round 5's refill list another 2 (profiles/
+    // r06_experiments.txt D).  So the waves add up in LDS and ONE lane per workgroup adds to the counters; no list: the refill kernel scans the envs' QUEUED bits.
     const unsigned long long m_all = CW_BALLOT(done);
     const unsigned long long m_succ = CW_BALLOT(live && o.success);
     const unsigned long long m_inv = CW_BALLOT(live && o.invalid);
@@ -1964,7 +1962,7 @@ hipError_t cwk_launch_step(const CwParams *P, const CwTuning *T, const void *act
     return hipGetLastError();
 }
 
-// look-ahead refill (cw_refill_kernel): the refill list, or every env without a record
+// look-ahead refill (cw_refill_kernel): the QUEUED envs, or every env with a free slot in its ring
 hipError_t cwk_launch_refill(const CwParams *P, const CwTuning *T, int all_envs, hipStream_t st)
 {
     hipLaunchKernelGGL(cw_refill_kernel, dim3(cw_reset_grid(*T, P->n_envs)), dim3(CW_RESET_WAVES * CW_WAVE), 0, st, *P, all_envs);

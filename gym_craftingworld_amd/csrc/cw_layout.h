@@ -30,7 +30,7 @@
 // Slot k initially holds object k (code k+1) -- OBJECTS order, ray.py:21.
 
 #define CW_CODES_INITIAL 0x87654321u  // slot k has code k+1
-#define CW_CTL_QUEUED 0x100u          // nx_ctl: the env is on the refill list (a record was taken, or it was reset the slow way); bits 0-7: the queue's head slot
+#define CW_CTL_QUEUED 0x100u          // nx_ctl: the env's ring wants a refill (a record was taken, or it was reset the slow way): the refill kernel scans for this bit; bits 0-7: the queue's head slot
 #define CW_LA_DEPTH 4                 // look-ahead records kept per env (round 6: a QUEUE -- an env that finishes two, three, four times between two refills
                                       // still finds a record; rounds 4-5 kept one, and every further finish was reset the slow way on the step's critical path)
 
