@@ -97,6 +97,7 @@ struct cw_engine {
     unsigned la_period = 16;           // the CURRENT refill period: la_period_max, or shorter while envs finish twice between two refills (la_adapt)
     unsigned la_period_max = 16;       // la_period_for(max_steps), or CW_TUNE_LA_PERIOD
     bool la_adaptive = true;
+    int rollout_segment = -1;          // CW_TUNE_ROLLOUT_SEGMENT (read at cw_create like every tuning variable): steps per persistent launch of cw_rollout, 0: one launch, -1: max_steps
     unsigned long long *la_feedback = nullptr;     // pinned: counters[5] as the last refill kernel saw it
     unsigned long long la_slow_seen = 0;
     int32_t la_quiet = 0;              // refills in a row with (nearly) no slow-path reset
@@ -430,6 +431,7 @@ int cw_create(const cw_config *cfg, int device, cw_engine **out)
     e->la_period = (unsigned)la_period_for(cfg->max_steps);
     if (const char *v = getenv("CW_TUNE_LA_PERIOD")) if (atoi(v) >= 1) { e->la_period = (unsigned)atoi(v); e->la_adaptive = false; }      // (a forced period: profiles/r06_experiments.txt D)
     e->la_period_max = e->la_period;
+    if (const char *v = getenv("CW_TUNE_ROLLOUT_SEGMENT")) e->rollout_segment = atoi(v);
     P.task_mask = (1u << cfg->n_task_list) - 1u;
     P.pool_k = e->K;
     P.div_magic = (uint32_t)((1ull << 32) / (uint64_t)e->S) + 1u;
@@ -831,8 +833,7 @@ int cw_rollout(cw_engine *e, const uint8_t *actions, int32_t n_steps, int32_t *r
     // with one segment per max_steps steps every time-out finds its record; shorter segments cost more in launches than they save (a segment start is ~20 us:
     // the refill, the launch, the state's round trip): 65 536 envs, T = 600: one launch 2.2e10 env-steps/s, segments of 64 / 128 / 300 steps 2.0 / 2.7 / 2.9e10
     // (2^20 envs: 4.1 -> 6.0e10; profiles/r06_experiments.txt C).  Same results, the same stream order.  CW_TUNE_ROLLOUT_SEGMENT=n: segments of n steps, 0: one launch.
-    static const int seg_env = getenv("CW_TUNE_ROLLOUT_SEGMENT") ? atoi(getenv("CW_TUNE_ROLLOUT_SEGMENT")) : -1;
-    const int32_t seg = !e->P.lookahead || seg_env == 0 ? n_steps : seg_env > 0 ? seg_env : (e->P.max_steps > 64 ? e->P.max_steps : 64);
+    const int32_t seg = !e->P.lookahead || e->rollout_segment == 0 ? n_steps : e->rollout_segment > 0 ? e->rollout_segment : (e->P.max_steps > 64 ? e->P.max_steps : 64);
     const size_t N = (size_t)e->n;
     for (int32_t t0 = 0; t0 < n_steps; t0 += seg) {
         if (e->P.lookahead) {
