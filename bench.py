@@ -13,16 +13,19 @@ actions, max_steps=300.  One "step" = one cw_step over the whole batch: cw_step_
 the look-ahead record of its next episode and its workgroup's four waves paint the two frames a reset changes), then cw_render_pieces_kernel, the clocked
 sweep that writes the whole observation array; every max_steps/4-th step cw_refill_kernel ahead of them.  Envs shard across
 ranks with no data-path collective (weak scaling: 65 536 envs per GPU); the only collectives
-are the timing barrier and the max-over-ranks of the elapsed time.
+are the timing barrier and the max-over-ranks of the elapsed time.  `value` is computed from the slowest rank's DEVICE time for the K steps (two events
+on the launch stream inside the barrier + synchronize bracket); `value_wall` from the wall clock around the bracket (it also holds the closing barrier).
 
 Prints ONE JSON line on rank 0 (contract in the task prompt), with
   roofline     -- dominant kernel (cw_render_pieces_kernel<raster, frames per job>: the sweep of the observation array) vs the HBM roof, from
                   HIP events recorded by the library on the launch stream (cw_profile_begin/end) over a second, identical
                   K-step region (the first region, without events, gives `value`); step_frac = the WHOLE step against the same roof;
   policy_in_loop -- the same engine with a consumer between two steps that reads every observation byte and produces the next actions;
-  cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) on this host's cores,
+  cpu_baseline -- the CPU oracle (C port of the reference algorithm, oracle/) ALONE on this host's whole CPU share,
                   same workload shape, bounded sample; `value` is like for like with the headline (a full
-                  render() per step), `dirty_cell_value` is the reference's own repaint strategy;
+                  render() per step), `dirty_cell_value` is the reference's own repaint strategy; `beside_gpu_soak`: a second run beside
+                  soak_beside_cpu_baseline (the GPU kept busy meanwhile; never the baseline);
+  short_episodes_1gpu -- what finishing episodes cost when a policy succeeds (episodes of ~140 steps under max_steps 300);
   metric_window -- SURVEY 8d's window whatever --steps says: 2*max_steps consecutive steps (both synchronized
                   time-out steps inside), timed in the same process, with the two slowest steps;
   repeats      -- the K-step region timed three times (value is the first, as the contract says);
