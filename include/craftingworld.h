@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define CW_ABI_VERSION 5   /* 5: cw_buffer_table.episode_return, cw_get_fixed_states; 4: cw_tuner_state, one painter, look-ahead records */
+#define CW_ABI_VERSION 5   /* 5: cw_buffer_table.episode_return, cw_get_fixed_states; 4: cw_tuner_state, one painter, look-ahead records.  Round 6 changed no
+                            * signature or struct: cw_get_mt reports numpy's own (key, pos) form, cw_rollout issues one launch per max_steps steps, checkpoint blobs
+                            * are version 4 (a ring of look-ahead records per env; older blobs are refused with CW_ERR_INVALID), hdr flags bits 2-15 count successes */
 #define CW_MT_N 624        /* MT19937 words per env (numpy RandomState key)        */
 #define CW_MAX_TASKS 16    /* len(task_list) upper bound (bits of the goal masks)  */
 #define CW_MAX_MENUS 256   /* distinct ordered selected_tasks lists per engine     */
