@@ -115,6 +115,66 @@ def test_every_env_of_the_full_size_batches_against_the_oracle(N, size, T, menus
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode', ['pixels_dirty', 'state'])
+def test_every_env_of_a_batch_whose_episodes_end_early_against_the_oracle(obs_mode):
+    """What a policy that SUCCEEDS does to the reset path (round 6): 65 536 envs on 8x8 grids, reward_style='subset', the one task EatBread, a
+    random walker -- episodes of ~140 steps under max_steps = 300, ~480 envs finishing on every step, many of them two, three, four times between two
+    look-ahead refills (the ring of records runs down, the refill period adapts, a few are reset the slow way).  Every reward and done of 450 steps, and at
+    the end every env's state, frames, episode counters and RNG state (key and position, exactly), against the oracle."""
+    from gym_craftingworld_amd import CraftingWorldVecEnv
+    from oracle import OracleBatch
+    N, T, SL, size = 65536, 450, 8192, 8
+    kw = dict(size=(size, size), max_steps=300, reward_style='subset', selected_tasks=['EatBread'], number_of_tasks=1)
+    env = CraftingWorldVecEnv(N, obs_mode=obs_mode, seed=123, **kw)
+    keys, pos = env.get_rng_states()
+    obs = env.reset()
+    acts = torch.randint(0, 4, (T, N), device='cuda', dtype=torch.uint8, generator=torch.Generator(device='cuda').manual_seed(9))
+    rec_r = torch.empty((T, N), dtype=torch.int32, device='cuda')
+    rec_d = torch.empty((T, N), dtype=torch.bool, device='cuda')
+    for t in range(T):
+        obs, r, d, _ = env.step(acts[t])
+        rec_r[t] = r
+        rec_d[t] = d
+    torch.cuda.synchronize()
+    a_host, r_host, d_host = acts.cpu().numpy().astype(np.int8), rec_r.cpu().numpy(), rec_d.cpu().numpy()
+    st = env.get_state()
+    k2, p2 = env.get_rng_states()
+    threads = max(1, len(os.sched_getaffinity(0)))
+    finished, most = 0, 0
+    for lo in range(0, N, SL):
+        hi = lo + SL
+        ora = OracleBatch(SL, rng_states=[(keys[i], int(pos[i])) for i in range(lo, hi)], **kw)
+        ora.reset()
+        total, o_rew, o_done = ora.rollout(a_host[:, lo:hi], nthreads=threads, record=True)
+        assert total == SL * T
+        assert np.array_equal(r_host[:, lo:hi], o_rew), ('reward', lo)
+        assert np.array_equal(d_host[:, lo:hi], o_done.astype(bool)), ('done', lo)
+        finished += int(o_done.sum())
+        per_env = o_done.sum(axis=0)
+        most = max(most, int(np.add.reduceat(o_done[:448], np.arange(0, 448, 64), axis=0).max()))      # most finishes of one env inside 64 consecutive steps
+        if obs_mode != 'state':
+            f_obs, f_goal, f_init = (obs[k][lo:hi].cpu().numpy() for k in ('observation', 'desired_goal', 'init_observation'))
+        ish = ora.envs[0].img_shape
+        for j, e in enumerate(ora.envs):
+            v, i = e.view(), lo + j
+            if obs_mode != 'state':
+                assert np.array_equal(f_obs[j], np.ctypeslib.as_array(v.obs, shape=ish)), ('observation', i)
+                assert np.array_equal(f_goal[j], np.ctypeslib.as_array(v.desired_img, shape=ish)), ('desired_goal', i)
+                assert np.array_equal(f_init[j], np.ctypeslib.as_array(v.init_img, shape=ish)), ('init_observation', i)
+            assert (st['agent_rc'][i][0], st['agent_rc'][i][1], st['hold'][i], st['achieved'][i], st['desired'][i], st['step_num'][i], st['ep_no'][i]) == \
+                (v.agent_r, v.agent_c, v.hold, v.achieved, v.desired, v.step_num, v.ep_no), ('state', i)
+            assert np.array_equal(st['grid'][i].reshape(-1), np.ctypeslib.as_array(v.grid, shape=(size * size,))), ('grid', i)
+            ok, op = e.get_rng()
+            assert op == int(p2[i]) and np.array_equal(ok, k2[i]), ('rng state', i, int(per_env[j]))
+        del ora
+    c = env._counters_raw.cpu()
+    assert finished == int(c[1]) and 0.8 * finished < int(c[2]) <= finished and finished > 2 * N      # (mostly successes -- the rest walked 300 steps --; each env finished ~3 times)
+    assert most >= 5                                                         # (some env ran its ring of four records empty between two refills ...)
+    assert 0 < int(c[5]) < finished // 100                                   # (... and was reset the slow way: rare, and it changes nothing)
+    env.close()
+
+
 # ------------------------------------------------------------------ (1) golden fixtures
 @pytest.mark.parametrize('obs_mode', ['pixels', 'pixels_dirty'])
 @pytest.mark.parametrize('name', fixture_names())
