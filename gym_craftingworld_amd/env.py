@@ -71,6 +71,10 @@ class CraftingWorldEnv:
                  reward_style=None, device=None, reference_dtypes=False, seed=None, resident=None):
         size = self._default_size if size is None else size
         max_steps = self._default_max_steps if max_steps is None else max_steps
+        # (what copy.deepcopy(env) builds its twin with: the reference env is plain Python and deep-copies -- planners do that --, this one holds an engine)
+        self._ctor_kwargs = dict(size=size, fixed_init_state=fixed_init_state, max_steps=max_steps, store_gif=False, render_save_rate=render_save_rate,
+                                 task_list=task_list, selected_tasks=selected_tasks, number_of_tasks=number_of_tasks, stacking=stacking,
+                                 reward_style=reward_style, device=device, reference_dtypes=reference_dtypes, resident=resident)
         self._vec = CraftingWorldVecEnv(1, size=size, fixed_init_state=fixed_init_state, max_steps=max_steps,
                                         store_gif=False, render_save_rate=render_save_rate, task_list=task_list,
                                         selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
@@ -112,6 +116,8 @@ class CraftingWorldEnv:
         # np_random (ray.py:145-147): the host mirror of the device-resident stream (_EnvRandomState), or the caller's own RandomState once one was assigned
         self._np_random = _EnvRandomState(self)
         self._rng_stale, self._rng_dirty, self._rng_foreign, self._rng_foreign_seen = True, False, None, None
+        # (the stream position the fixed_init_state pool was drawn from: a deep copy taken before the first reset() redraws it from there)
+        self._pool_rng = seeding.mt_state_from_seed(v._seeds[0]) if fixed_init_state else None
         if not fixed_init_state:                    # (else the constructor has drawn the pool from the stream already: the mirror follows at its first use)
             key, pos = seeding.mt_state_from_seed(v._seeds[0])
             np.random.RandomState.set_state(self._np_random, ('MT19937', key, pos, 0, 0.0))   # the seeded state as numpy holds it, ray.py:70
@@ -281,7 +287,7 @@ class CraftingWorldEnv:
         if num_states is not None and int(num_states) != self.fixed_init_state:
             raise ValueError('the pool holds fixed_init_state=%d placements' % self.fixed_init_state)
         from . import _lib as L
-        self._rng_flush()
+        self._pool_rng = self.get_rng_state()        # (flushes what the host did to the generator first)
         L.check(self._lib.cw_generate_fixed_states(self._eng, self._stream), 'cw_generate_fixed_states', self._lib)
         self._rng_device_moved()
         return self.fixed_state_list
@@ -514,6 +520,33 @@ class CraftingWorldEnv:
         self._rng_device_moved()
         self._after_restore()
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(env) -- what a planner does with the reference's plain-Python env to try actions on a copy: a second env on an engine of its own, in
+        the same state down to the RNG stream, the fixed_init_state pool, the episode's frames and counters (an in-memory checkpoint round trip), and from
+        then on independent of this one.  GIF recording is not copied."""
+        twin = type(self)(**self._ctor_kwargs)
+        if self._has_reset:
+            from . import _lib as L
+            self._rng_flush()
+            self._sync_counters_down()
+            n = int(self._lib.cw_checkpoint_bytes(self._eng))
+            buf = np.empty(n, dtype=np.uint8)
+            L.check(self._lib.cw_checkpoint_save(self._eng, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_save', self._lib)
+            L.check(twin._lib.cw_checkpoint_load(twin._eng, buf.ctypes.data_as(C.c_void_p), n), 'cw_checkpoint_load', twin._lib)
+            twin._vec._has_reset = twin._has_reset = True
+            twin._rng_dirty = False
+            twin._rng_device_moved()
+            twin._after_restore()
+        else:
+            if self._pool_rng is not None:           # (no state to checkpoint yet: the pool is redrawn from where this env drew it)
+                twin.set_rng_state(*self._pool_rng)
+                twin.generate_fixed_states()
+            twin.set_rng_state(*self.get_rng_state())
+            twin._step_num, twin.ep_no = self._step_num, self.ep_no
+        twin._pool_rng = self._pool_rng
+        memo[id(self)] = twin
+        return twin
+
     def _after_restore(self):
         st = self._vec.get_state()
         self._step_num, self.ep_no = int(st['step_num'][0]), int(st['ep_no'][0])
@@ -628,6 +661,7 @@ class CraftingWorldEnvFlat(CraftingWorldEnv):
         super().__init__(size=size, max_steps=max_steps, store_gif=store_gif, render_save_rate=render_save_rate,
                          task_list=task_list, selected_tasks=selected_tasks, number_of_tasks=number_of_tasks,
                          stacking=stacking, reward_style=reward_style, **kw)
+        self._ctor_kwargs.pop('fixed_init_state', None)
         P = 4 * self.STATE_W
         self.observation_space = Box(low=0, high=255, shape=(P, P, 3), dtype=self._dtype)   # flat.py:57
 
@@ -723,6 +757,7 @@ class CraftingWorldEnvAltObs(CraftingWorldEnv):
     def __init__(self, *a, stacked_obs=False, **kw):
         super().__init__(*a, **kw)
         self.stacked_obs = stacked_obs
+        self._ctor_kwargs['stacked_obs'] = stacked_obs
         if stacked_obs is True:
             self.observation_space = Box(low=0, high=255, shape=(4,) + self._vec.frame_shape, dtype=self._dtype)
 

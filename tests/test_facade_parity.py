@@ -138,3 +138,48 @@ def test_obs_one_hot_stays_live_on_the_engine():
             env.step_num = env.MAX_STEPS - 1
             assert env.step(0)[2] is True and env.step_num == env.MAX_STEPS
             env.close()
+
+
+@pytest.mark.parametrize('cls_name', ['CraftingWorldEnv', 'CraftingWorldEnvOneHot', 'CraftingWorldEnvFlat', 'CraftingWorldEnvAltObs'])
+def test_deepcopy_gives_an_independent_twin(cls_name):
+    """copy.deepcopy(env), as planners do with the reference's plain-Python env: the twin continues exactly like the original would (same observations,
+    rewards, resets -- the RNG stream, the fixed_init_state pool and the counters travel), stepping one does not move the other, and a copy taken before the
+    first reset() resets to the same first episode."""
+    import copy
+    import gym_craftingworld_amd as cw
+    cls = getattr(cw, cls_name)
+    kw = dict(size=(6, 6), max_steps=25)
+    if cls_name != 'CraftingWorldEnvFlat':
+        kw['fixed_init_state'] = 3
+    a = cls(seed=17, **kw)
+    early = copy.deepcopy(a)                                 # before the first reset
+
+    def frame(o):
+        return o if isinstance(o, np.ndarray) else o['observation']
+    o1, o2 = a.reset(), early.reset()
+    assert np.array_equal(frame(o1), frame(o2)) and np.array_equal(a.desired_goal_vector, early.desired_goal_vector)
+    pol = np.random.RandomState(3)
+    for _ in range(11):
+        if a.step(int(pol.randint(6)))[2]:
+            a.reset()
+    a.ep_no = 9
+    b = copy.deepcopy(a)
+    assert type(b) is cls and b is not a and b._eng.value != a._eng.value and (b.step_num, b.ep_no) == (a.step_num, 9)
+    assert np.array_equal(b.obs_image, a.obs_image) and np.array_equal(b.desired_goal, a.desired_goal) and np.array_equal(b.obs_one_hot, a.obs_one_hot)
+    snap = frame(a._obs_dict() if cls_name != 'CraftingWorldEnvFlat' else a.obs_image).copy()
+    for _ in range(5):                                       # the twin walks off: the original does not move
+        b.step(int(pol.randint(4)))
+    assert np.array_equal(frame(a._obs_dict() if cls_name != 'CraftingWorldEnvFlat' else a.obs_image), snap)
+    c = copy.deepcopy(a)
+    acts = [int(x) for x in pol.randint(0, 6, size=90)]
+    n_resets = 0
+    for t, act in enumerate(acts):
+        ra, rc = a.step(act), c.step(act)
+        assert ra[1:3] == rc[1:3] and np.array_equal(frame(ra[0]), frame(rc[0])), t
+        if ra[2]:
+            oa, oc = a.reset(), c.reset()
+            n_resets += 1
+            assert np.array_equal(frame(oa), frame(oc)) and a.ep_no == c.ep_no
+    assert n_resets >= 2
+    for e in (a, b, c, early):
+        e.close()
