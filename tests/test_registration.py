@@ -45,6 +45,17 @@ for env_id in sorted(registry):
 flat = gym.make('craftingworldflat-v3', seed=1)
 made['flat_defaults'] = [flat.STATE_W, flat.MAX_STEPS]
 flat.close()
+# docs/source/envs/custom_envs.rst:5-16: a user's own id on the reference's entry-point path, and the documented loop (gen_info.rst:62-82)
+from gym.envs.registration import register
+register(id='craftingworldMyCustomEnv-v3', entry_point='gym_craftingworld_amd.envs:CraftingWorldEnvRay', kwargs={'stacking': True})
+custom = gym.make('craftingworldMyCustomEnv-v3', size=(5, 5), max_steps=12, seed=2)
+obs, done, n = custom.reset(), False, 0
+while not done:
+    obs, reward, done, _ = custom.step(custom.action_space.sample())
+    n += 1
+custom.reset()
+made['custom'] = [type(custom).__name__, custom.stacking, custom.render_save_rate, n, custom.ep_no]
+custom.close()
 own = cw.make('craftingworldonehot-v3', size=(5, 5), render_save_rate=2, seed=1)      # the package's own make: the same table, no gym needed
 made['own_make'] = [type(own).__name__, own.render_save_rate, own.stacking]
 own.close()
@@ -69,3 +80,4 @@ def test_reference_ids_resolve_to_the_hip_classes_with_the_reference_kwargs():
         assert m[env_id]['reward'] == -1
     assert m['craftingworld-v3']['obs'] == 'dict' and m['craftingworldonehot-v3']['obs'] == 'dict' and m['craftingworldflat-v3']['obs'] == [24, 24, 3]
     assert m['flat_defaults'] == [8, 100] and m['own_make'] == ['CraftingWorldEnvOneHot', 2, True]
+    assert m['custom'][:3] == ['CraftingWorldEnv', True, 1] and 1 <= m['custom'][3] <= 12 and m['custom'][4] == 1      # (the documented loop ran to done; reset() counted the episode)
